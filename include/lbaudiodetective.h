@@ -1,0 +1,267 @@
+/*
+ * lbaudiodetective.h -- C ABI of the MI355X-native LBAudioDetective hot path.
+ *
+ * Part 1 re-declares, name for name and argument for argument, the public C interface of
+ * the upstream library so that a caller of the reference links against
+ * liblbaudiodetective.so unchanged.  Each declaration cites the upstream declaration it
+ * replaces (D.h = LBAudioDetective/LBAudioDetective.h, Fp.h = LBAudioDetectiveFingerprint.h,
+ * Fr.h = LBAudioDetectiveFrame.h).  Every function that computes (fingerprinting, Haar,
+ * sign extraction, compare) runs HIP kernels on the current device; there is no CPU
+ * fallback and the calls fail with kLBAudioDetectiveDeviceUnavailable when no GPU is usable.
+ *
+ * Part 2 adds what the reference lacks and a GPU needs: PCM-in entry points (Apple's
+ * ExtAudioFile does not exist here), batch fingerprinting on device-resident clips, and a
+ * device-resident reference-fingerprint corpus with a top-1 query that returns a key a
+ * host can all-reduce (max) across GPUs.
+ *
+ * Plain C, plain pointers and sizes only.  "Device pointer" means memory of the current
+ * HIP device (e.g. torch.Tensor.data_ptr()); "stream" is a hipStream_t passed as void*
+ * (NULL = the default stream).
+ */
+#ifndef LBAUDIODETECTIVE_H
+#define LBAUDIODETECTIVE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- MacTypes / CoreAudio types the upstream headers get from Apple's SDK ------------- */
+#if !defined(__MACTYPES__) && !defined(LBAD_HAVE_MACTYPES)
+typedef uint32_t UInt32;
+typedef int32_t SInt32;
+typedef uint64_t UInt64;
+typedef int64_t SInt64;
+typedef float Float32;
+typedef double Float64;
+typedef unsigned char Boolean;
+typedef SInt32 OSStatus;
+enum { noErr = 0 };
+#endif
+
+#if !defined(__CoreAudioTypes_h__) && !defined(LBAD_HAVE_COREAUDIOTYPES)
+/* layout-compatible with CoreAudio's AudioStreamBasicDescription */
+typedef struct AudioStreamBasicDescription {
+    Float64 mSampleRate;
+    UInt32 mFormatID;
+    UInt32 mFormatFlags;
+    UInt32 mBytesPerPacket;
+    UInt32 mFramesPerPacket;
+    UInt32 mBytesPerFrame;
+    UInt32 mChannelsPerFrame;
+    UInt32 mBitsPerChannel;
+    UInt32 mReserved;
+} AudioStreamBasicDescription;
+enum {
+    kAudioFormatLinearPCM = 0x6C70636D, /* 'lpcm' */
+    kAudioFormatFlagIsFloat = 1u << 0,
+    kAudioFormatFlagIsPacked = 1u << 3
+};
+#endif
+
+/* An Objective-C host keeps passing NSURL*; everything else passes a filesystem path. */
+#ifdef __OBJC__
+@class NSURL;
+typedef NSURL* LBAudioDetectiveURLRef;
+#else
+typedef const char* LBAudioDetectiveURLRef;
+#endif
+
+/* ---- constants (D.h:14-20; values LBAudioDetective.m:20-26) ---------------------------- */
+extern const OSStatus kLBAudioDetectiveArgumentInvalid;           /* D.h:14  (= 1) */
+extern const UInt32 kLBAudioDetectiveDefaultWindowSize;           /* D.h:16  (= 2048) */
+extern const UInt32 kLBAudioDetectiveDefaultAnalysisStride;       /* D.h:17  (= 64) */
+extern const UInt32 kLBAudioDetectiveDefaultNumberOfPitchSteps;   /* D.h:18  (= 32) */
+extern const UInt32 kLBAudioDetectiveDefaultSubfingerprintLength; /* D.h:20  (= 200) */
+/* additions: status codes of this implementation */
+extern const OSStatus kLBAudioDetectiveDeviceUnavailable;         /* 'nogp' */
+extern const OSStatus kLBAudioDetectiveDeviceError;               /* 'gper' */
+extern const OSStatus kLBAudioDetectiveUnsupportedFile;           /* 'fmt?' */
+
+typedef struct LBAudioDetective* LBAudioDetectiveRef;                       /* D.h:22 */
+typedef struct LBAudioDetectiveFingerprint* LBAudioDetectiveFingerprintRef; /* Fp.h:11 */
+typedef struct LBAudioDetectiveFrame* LBAudioDetectiveFrameRef;             /* Fr.h:11 */
+
+/* ======================================================================================
+ * Part 1a -- detective (D.h)
+ * ==================================================================================== */
+LBAudioDetectiveRef LBAudioDetectiveNew(void);                                            /* D.h:41 */
+OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective);                        /* D.h:49 */
+AudioStreamBasicDescription LBAudioDetectiveDefaultProcessingFormat(void);                /* D.h:62 */
+Float64 LBAudioDetectiveGetProcessingSampleRate(LBAudioDetectiveRef inDetective);         /* D.h:74 */
+UInt32 LBAudioDetectiveGetNumberOfPitchSteps(LBAudioDetectiveRef inDetective);            /* D.h:85 */
+UInt32 LBAudioDetectiveGetSubfingerprintLength(LBAudioDetectiveRef inDetective);          /* D.h:96,129 */
+UInt32 LBAudioDetectiveGetWindowSize(LBAudioDetectiveRef inDetective);                    /* D.h:107 */
+UInt32 LBAudioDetectiveGetAnalysisStride(LBAudioDetectiveRef inDetective);                /* D.h:118 */
+OSStatus LBAudioDetectiveSetProcessingSampleRate(LBAudioDetectiveRef inDetective, Float64 inSampleRate);        /* D.h:154 */
+OSStatus LBAudioDetectiveSetNumberOfPitchSteps(LBAudioDetectiveRef inDetective, UInt32 inNumberOfPitchSteps);   /* D.h:164 */
+OSStatus LBAudioDetectiveSetSubfingerprintLength(LBAudioDetectiveRef inDetective, UInt32 inSubfingerprintLength); /* D.h:174,205 */
+/* Unlike LBAudioDetective.m:185-187 (which reports an error for every valid size), this
+ * returns noErr for a power of two in [16, 8192] and kLBAudioDetectiveArgumentInvalid,
+ * leaving the detective unchanged, for anything else. */
+OSStatus LBAudioDetectiveSetWindowSize(LBAudioDetectiveRef inDetective, UInt32 inWindowSize);       /* D.h:184 */
+OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef inDetective, UInt32 inAnalysisStride); /* D.h:194 */
+/* File front end: LPCM CAF / WAV already at the processing sample rate (mono, or
+ * multi-channel averaged to mono).  Compressed data or another rate returns
+ * kLBAudioDetectiveUnsupportedFile (Apple's decoder/resampler is out of scope). */
+OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL,
+                                         LBAudioDetectiveFingerprintRef* outFingerprint); /* D.h:218 */
+OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL1,
+                                          LBAudioDetectiveURLRef inFileURL2, UInt32 inComparisonRange,
+                                          Float32* outMatch);                             /* D.h:235 */
+
+/* ======================================================================================
+ * Part 1b -- fingerprint (Fp.h).  Sub-fingerprints cross this API as unpacked Booleans.
+ * ==================================================================================== */
+LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNew(UInt32 inSubfingerprintLength);            /* Fp.h:27 */
+void LBAudioDetectiveFingerprintDispose(LBAudioDetectiveFingerprintRef inFingerprint);                  /* Fp.h:35 */
+LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintCopy(LBAudioDetectiveFingerprintRef inFingerprint); /* Fp.h:45 */
+UInt32 LBAudioDetectiveFingerprintGetSubfingerprintLength(LBAudioDetectiveFingerprintRef inFingerprint);  /* Fp.h:59 */
+UInt32 LBAudioDetectiveFingerprintGetNumberOfSubfingerprints(LBAudioDetectiveFingerprintRef inFingerprint); /* Fp.h:70 */
+UInt32 LBAudioDetectiveFingerprintGetSubfingerprintAtIndex(LBAudioDetectiveFingerprintRef inFingerprint, UInt32 inIndex,
+                                                           Boolean* outSubfingerprint);               /* Fp.h:83 */
+Boolean LBAudioDetectiveFingerprintSetSubfingerprintLength(LBAudioDetectiveFingerprintRef inFingerprint,
+                                                           UInt32* ioSubfingerprintLength);           /* Fp.h:98 */
+void LBAudioDetectiveFingerprintAddSubfingerprint(LBAudioDetectiveFingerprintRef inFingerprint,
+                                                  Boolean* inSubfingerprint);                         /* Fp.h:108 */
+Boolean LBAudioDetectiveFingerprintEqualToFingerprint(LBAudioDetectiveFingerprintRef inFingerprint1,
+                                                      LBAudioDetectiveFingerprintRef inFingerprint2); /* Fp.h:122 */
+/* GPU: XOR/popcount compare kernel; returns NaN if the device call fails. */
+Float32 LBAudioDetectiveFingerprintCompareToFingerprint(LBAudioDetectiveFingerprintRef inFingerprint1,
+                                                        LBAudioDetectiveFingerprintRef inFingerprint2,
+                                                        UInt32 inRange);                              /* Fp.h:134 */
+Float32 LBAudioDetectiveFingerprintCompareSubfingerprints(LBAudioDetectiveFingerprintRef inFingerprint,
+                                                          Boolean* inSubfingerprint1, Boolean* inSubfingerprint2,
+                                                          UInt32 inRange);                            /* Fp.h:147 */
+
+/* ======================================================================================
+ * Part 1c -- frame (Fr.h; "internal" upstream but used by its Haar test)
+ * ==================================================================================== */
+LBAudioDetectiveFrameRef LBAudioDetectiveFrameNew(UInt32 inMaxRowCount);                       /* Fr.h:27 */
+void LBAudioDetectiveFrameDispose(LBAudioDetectiveFrameRef inFrame);                           /* Fr.h:35 */
+LBAudioDetectiveFrameRef LBAudioDetectiveFrameCopy(LBAudioDetectiveFrameRef inFrame);          /* Fr.h:44 */
+UInt32 LBAudioDetectiveFrameGetNumberOfRows(LBAudioDetectiveFrameRef inFrame);                 /* Fr.h:58 */
+Float32* LBAudioDetectiveFrameGetRow(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex);     /* Fr.h:69 */
+Float32 LBAudioDetectiveFrameGetValue(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex, UInt32 inColumnIndex); /* Fr.h:81 */
+Boolean LBAudioDetectiveFrameFull(LBAudioDetectiveFrameRef inFrame);                           /* Fr.h:91 */
+Boolean LBAudioDetectiveFrameSetRow(LBAudioDetectiveFrameRef inFrame, Float32* inRow, UInt32 inRowIndex, UInt32 inCount); /* Fr.h:107 */
+void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame);                         /* Fr.h:119  (GPU Haar) */
+size_t LBAudioDetectiveFrameFingerprintSize(LBAudioDetectiveFrameRef inFrame);                 /* Fr.h:129 */
+UInt32 LBAudioDetectiveFrameFingerprintLength(LBAudioDetectiveFrameRef inFrame);               /* Fr.h:139 */
+void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, UInt32 inNumberOfWavelets,
+                                             Boolean* outFingerprint);                         /* Fr.h:150 (GPU rank) */
+Boolean LBAudioDetectiveFrameEqualToFrame(LBAudioDetectiveFrameRef inFrame1, LBAudioDetectiveFrameRef inFrame2); /* Fr.h:162 */
+
+/* ======================================================================================
+ * Part 2 -- additions
+ * ==================================================================================== */
+
+/* Number of sub-fingerprints a buffer of inNumberOfSamples yields with the detective's
+ * window/stride (framing of LBAudioDetective.m:250-255; 0 when shorter than a window). */
+UInt64 LBAudioDetectiveGetSubfingerprintCount(LBAudioDetectiveRef inDetective, UInt64 inNumberOfSamples);
+
+/* Replaces the ExtAudioFile loop of LBAudioDetective.m:224-290: host float32 mono PCM that
+ * is already at the processing sample rate -> fingerprint. */
+OSStatus LBAudioDetectiveProcessPCM(LBAudioDetectiveRef inDetective, const Float32* inSamples,
+                                    UInt64 inNumberOfSamples, LBAudioDetectiveFingerprintRef* outFingerprint);
+/* LBAudioDetectiveCompareAudioURLs (LBAudioDetective.m:442-464) on two PCM buffers. */
+OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef inDetective, const Float32* inSamples1, UInt64 inCount1,
+                                    const Float32* inSamples2, UInt64 inCount2, UInt32 inComparisonRange,
+                                    Float32* outMatch);
+
+/* Packed sub-fingerprint: LBAD_PACKED_WORDS little-endian 32-bit words; Boolean b of the
+ * sub-fingerprint is bit (b & 31) of word (b >> 5); unused high bits are zero.  The device
+ * path supports subfingerprintLength <= 256. */
+#define LBAD_PACKED_WORDS 8
+#define LBAD_PACKED_BYTES 32
+#define LBAD_MAX_SUBFINGERPRINT_LENGTH 256
+
+/* Batch hot path: inClips = device pointer to inNumberOfClips x inSamplesPerClip float32,
+ * outPacked = device pointer to inNumberOfClips x count x LBAD_PACKED_BYTES, where
+ * count = LBAudioDetectiveGetSubfingerprintCount(d, inSamplesPerClip).  Asynchronous on
+ * inStream. */
+OSStatus LBAudioDetectiveFingerprintClipsDevice(LBAudioDetectiveRef inDetective, const Float32* inClips,
+                                                UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
+                                                void* outPacked, void* inStream);
+/* Same, host buffers in and unpacked Booleans out (count x subfingerprintLength per clip). */
+OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef inDetective, const Float32* inClips,
+                                          UInt64 inNumberOfClips, UInt64 inSamplesPerClip, Boolean* outBooleans);
+/* Kernel selection for the batch path: 0 = automatic, 1 = force the unfused
+ * fft+bands / haar+select kernels, 2 = force the fused per-frame kernel (ArgumentInvalid
+ * if the configuration has no fused specialisation). */
+OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
+/* Debug taps for stage-level parity tests (unfused kernels only): device buffers of
+ * clips x count x 128 x bands float32 receiving the frame before / after the Haar; either may be NULL. */
+OSStatus LBAudioDetectiveFingerprintClipsDeviceTaps(LBAudioDetectiveRef inDetective, const Float32* inClips,
+                                                    UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
+                                                    void* outPacked, Float32* outFramesRaw, Float32* outFramesHaar,
+                                                    void* inStream);
+
+/* Boolean <-> packed conversion on the host (no arithmetic). */
+void LBAudioDetectivePackSubfingerprint(const Boolean* inBooleans, UInt32 inLength, UInt32* outWords);
+void LBAudioDetectiveUnpackSubfingerprint(const UInt32* inWords, UInt32 inLength, Boolean* outBooleans);
+
+/* ---- device-resident reference corpus -------------------------------------------------- */
+typedef struct LBAudioDetectiveCorpus* LBAudioDetectiveCorpusRef;
+
+/* Every entry has inSubfingerprintsPerEntry sub-fingerprints of inSubfingerprintLength
+ * Booleans; inCapacity entries of HBM are reserved up front. */
+LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLength, UInt32 inSubfingerprintsPerEntry,
+                                                    UInt64 inCapacity);
+void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef inCorpus);
+UInt64 LBAudioDetectiveCorpusGetCount(LBAudioDetectiveCorpusRef inCorpus);
+/* bytes of HBM one entry occupies in the scan layout */
+UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef inCorpus);
+/* Append entries from device memory in the packed batch layout
+ * (inNumberOfEntries x perEntry x LBAD_PACKED_BYTES). */
+OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef inCorpus, const void* inPacked,
+                                                  UInt64 inNumberOfEntries, void* inStream);
+/* Append one host fingerprint (must have exactly perEntry sub-fingerprints). */
+OSStatus LBAudioDetectiveCorpusAppendFingerprint(LBAudioDetectiveCorpusRef inCorpus,
+                                                 LBAudioDetectiveFingerprintRef inFingerprint);
+/* Best-match loop of LBAudioDetectiveTests.m:57-91 over the corpus: the query is the fixed
+ * first argument of LBAudioDetectiveFingerprintCompareToFingerprint, every entry the
+ * second; strict '<' from 0.0 so the lowest index wins ties and *outIndex = -1 when
+ * nothing scores above 0.  inRange == 0 means the sub-fingerprint length
+ * (LBAudioDetective.m:443-445). */
+OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
+                                     UInt32 inRange, SInt64* outIndex, Float32* outScore);
+/* Sharded form: scans this GPU's entries (global index = inIndexBase + local) and writes
+ * ONE 64-bit key = (float bits of the best score << 32) | (0xFFFFFFFF - global index) to
+ * the device pointer outKey (0 if the shard is empty).  max() over ranks of the keys
+ * (e.g. an RCCL all-reduce with ncclMax on int64) is the global best match; decode with
+ * LBAudioDetectiveCorpusDecodeKey.  Asynchronous on inStream. */
+OSStatus LBAudioDetectiveCorpusQueryKeyDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
+                                              UInt32 inRange, UInt64 inIndexBase, void* outKey, void* inStream);
+void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* outScore);
+/* Per-entry scores (debug / parity): device pointer to count float32. */
+OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
+                                            UInt32 inRange, Float32* outScores, void* inStream);
+/* Kernel selection: 0 = automatic, 1 = generic slot-layout kernel, 2 = specialised plane kernel. */
+OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef inCorpus, UInt32 inVariant);
+
+/* ---- synthetic inputs generated on the device (bench / tests) -------------------------- */
+/* Integer-arithmetic generator; bit-identical to oracle/lbad_oracle.c:lbo_synth_clip. */
+OSStatus LBAudioDetectiveSynthClipsDevice(UInt32 inSeed, UInt64 inFirstClip, UInt64 inNumberOfClips,
+                                          UInt32 inSampleRateHz, UInt32 inSamplesPerClip, UInt32 inStereoSum,
+                                          Float32* outClips, void* inStream);
+/* Packed batch layout (entries x perEntry x LBAD_PACKED_BYTES); matches lbo_synth_entry. */
+OSStatus LBAudioDetectiveSynthCorpusDevice(UInt32 inSeed, UInt64 inFirstEntry, UInt64 inNumberOfEntries,
+                                           UInt32 inSubfingerprintsPerEntry, UInt32 inSubfingerprintLength,
+                                           void* outPacked, void* inStream);
+
+/* ---- minimal device plumbing for hosts without a HIP binding --------------------------- */
+SInt32 LBAudioDetectiveDeviceCount(void);
+OSStatus LBAudioDetectiveDeviceMalloc(void** outPointer, UInt64 inBytes);
+OSStatus LBAudioDetectiveDeviceFree(void* inPointer);
+OSStatus LBAudioDetectiveDeviceCopyIn(void* inDevice, const void* inHost, UInt64 inBytes);
+OSStatus LBAudioDetectiveDeviceCopyOut(void* inHost, const void* inDevice, UInt64 inBytes);
+OSStatus LBAudioDetectiveDeviceSynchronize(void);
+const char* LBAudioDetectiveVersionString(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBAUDIODETECTIVE_H */

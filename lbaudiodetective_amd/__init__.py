@@ -1,0 +1,17 @@
+"""MI355X-native LBAudioDetective hot path: HIP kernels behind the reference's C interface.
+
+`lbaudiodetective_amd._native.lib()` loads lib/liblbaudiodetective.so (built by
+`_native.build()` / `__graft_entry__.build()`); there is no CPU or PyTorch fallback.
+"""
+from ._native import build, lib, constant, LIB_PATH, PACKED_BYTES, PACKED_WORDS, ROWS_PER_FRAME  # noqa: F401
+from .api import (  # noqa: F401
+    Corpus, Detective, Fingerprint, Frame, LBAudioDetectiveError, noErr, pack_subfingerprint,
+    synth_clips_device, synth_corpus_device, unpack_packed, unpack_subfingerprint,
+)
+from .sharded import ShardedCorpus, shard_range  # noqa: F401
+
+__all__ = [
+    "build", "lib", "constant", "Corpus", "Detective", "Fingerprint", "Frame", "LBAudioDetectiveError",
+    "ShardedCorpus", "shard_range", "pack_subfingerprint", "unpack_subfingerprint", "unpack_packed",
+    "synth_clips_device", "synth_corpus_device",
+]

@@ -1,0 +1,414 @@
+"""Python mirror of the LBAudioDetective C interface over liblbaudiodetective.so.
+
+Class and method names follow the upstream functions (``LBAudioDetectiveFingerprintCompareToFingerprint``
+-> ``Fingerprint.compare_to_fingerprint``), argument meaning and error behaviour are the C
+library's.  Everything that computes goes through the C ABI into HIP kernels; this module only
+marshals buffers (numpy on the host, ``torch`` tensors for device memory and streams).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+noErr = 0
+
+
+class LBAudioDetectiveError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        code = status & 0xFFFFFFFF
+        four = bytes([(code >> s) & 0xFF for s in (24, 16, 8, 0)])
+        tag = f"'{four.decode()}'" if all(32 <= b < 127 for b in four) else str(status)
+        super().__init__(f"{what}: OSStatus {tag}")
+
+
+def _check(status: int, what: str):
+    if status != noErr:
+        raise LBAudioDetectiveError(status, what)
+
+
+def _u8(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _stream_ptr(stream=None):
+    """hipStream_t of a torch stream (default: torch's current stream; None without torch)."""
+    if stream is not None:
+        return C.c_void_p(stream.cuda_stream)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    except ImportError:
+        pass
+    return C.c_void_p(0)
+
+
+def pack_subfingerprint(bools) -> np.ndarray:
+    b = _u8(bools)
+    out = np.zeros(N.PACKED_WORDS, np.uint32)
+    N.lib().LBAudioDetectivePackSubfingerprint(b.ctypes.data, b.size, out.ctypes.data)
+    return out
+
+
+def unpack_subfingerprint(words, length: int) -> np.ndarray:
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    out = np.zeros(length, np.uint8)
+    N.lib().LBAudioDetectiveUnpackSubfingerprint(w.ctypes.data, length, out.ctypes.data)
+    return out
+
+
+def unpack_packed(packed: np.ndarray, length: int) -> np.ndarray:
+    """[..., 8] uint32 (or [..., 32] uint8) packed sub-fingerprints -> [..., length] Booleans."""
+    p = np.ascontiguousarray(packed)
+    if p.dtype == np.uint8:
+        p = p.view(np.uint32)
+    p = p.reshape(-1, N.PACKED_WORDS)
+    bits = ((p[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(np.uint8)
+    return bits.reshape(p.shape[0], 256)[:, :length]
+
+
+class Fingerprint:
+    """LBAudioDetectiveFingerprintRef."""
+
+    def __init__(self, subfingerprint_length: int = 0, _ref=None):
+        self._L = N.lib()
+        self._ref = _ref if _ref is not None else self._L.LBAudioDetectiveFingerprintNew(subfingerprint_length)
+
+    @classmethod
+    def from_bools(cls, bools) -> "Fingerprint":
+        b = _u8(bools)
+        assert b.ndim == 2
+        fp = cls(b.shape[1])
+        for row in b:
+            fp.add_subfingerprint(row)
+        return fp
+
+    def dispose(self):
+        if self._ref:
+            self._L.LBAudioDetectiveFingerprintDispose(self._ref)
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    def copy(self) -> "Fingerprint":
+        return Fingerprint(_ref=self._L.LBAudioDetectiveFingerprintCopy(self._ref))
+
+    @property
+    def subfingerprint_length(self) -> int:
+        return self._L.LBAudioDetectiveFingerprintGetSubfingerprintLength(self._ref)
+
+    @property
+    def number_of_subfingerprints(self) -> int:
+        return self._L.LBAudioDetectiveFingerprintGetNumberOfSubfingerprints(self._ref)
+
+    def subfingerprint_at_index(self, index: int) -> np.ndarray:
+        out = np.zeros(self.subfingerprint_length, np.uint8)
+        self._L.LBAudioDetectiveFingerprintGetSubfingerprintAtIndex(self._ref, index, out.ctypes.data)
+        return out
+
+    def set_subfingerprint_length(self, length: int):
+        io = N.UInt32(length)
+        ok = self._L.LBAudioDetectiveFingerprintSetSubfingerprintLength(self._ref, C.byref(io))
+        return bool(ok), io.value
+
+    def add_subfingerprint(self, bools):
+        b = _u8(bools)
+        assert b.size >= self.subfingerprint_length
+        self._L.LBAudioDetectiveFingerprintAddSubfingerprint(self._ref, b.ctypes.data)
+
+    def equal_to_fingerprint(self, other: "Fingerprint") -> bool:
+        return bool(self._L.LBAudioDetectiveFingerprintEqualToFingerprint(self._ref, other._ref))
+
+    def compare_to_fingerprint(self, other: "Fingerprint", range_: int) -> float:
+        return float(self._L.LBAudioDetectiveFingerprintCompareToFingerprint(self._ref, other._ref, range_))
+
+    def compare_subfingerprints(self, a, b, range_: int) -> float:
+        a, b = _u8(a), _u8(b)
+        return float(self._L.LBAudioDetectiveFingerprintCompareSubfingerprints(self._ref, a.ctypes.data, b.ctypes.data,
+                                                                                range_))
+
+    def to_bools(self) -> np.ndarray:
+        n, L = self.number_of_subfingerprints, self.subfingerprint_length
+        out = np.zeros((n, L), np.uint8)
+        for i in range(n):
+            out[i] = self.subfingerprint_at_index(i)
+        return out
+
+    def to_string(self) -> str:
+        """'0'/'1' per Boolean, sub-fingerprints joined by '+' (LBAudioDetectiveTests.m:22-37)."""
+        return "+".join("".join(str(int(v)) for v in row) for row in self.to_bools())
+
+
+class Frame:
+    """LBAudioDetectiveFrameRef."""
+
+    def __init__(self, max_row_count: int, _ref=None):
+        self._L = N.lib()
+        self._ref = _ref if _ref is not None else self._L.LBAudioDetectiveFrameNew(max_row_count)
+
+    def dispose(self):
+        if self._ref:
+            self._L.LBAudioDetectiveFrameDispose(self._ref)
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    def copy(self) -> "Frame":
+        return Frame(0, _ref=self._L.LBAudioDetectiveFrameCopy(self._ref))
+
+    @property
+    def number_of_rows(self) -> int:
+        return self._L.LBAudioDetectiveFrameGetNumberOfRows(self._ref)
+
+    def full(self) -> bool:
+        return bool(self._L.LBAudioDetectiveFrameFull(self._ref))
+
+    def set_row(self, row, index: int) -> bool:
+        r = _f32(row)
+        return bool(self._L.LBAudioDetectiveFrameSetRow(self._ref, r.ctypes.data, index, r.size))
+
+    def get_value(self, row: int, col: int) -> float:
+        return float(self._L.LBAudioDetectiveFrameGetValue(self._ref, row, col))
+
+    def get_row(self, index: int, count: int) -> np.ndarray:
+        p = self._L.LBAudioDetectiveFrameGetRow(self._ref, index)
+        return np.ctypeslib.as_array(p, shape=(count,)).copy()
+
+    def decompose(self):
+        self._L.LBAudioDetectiveFrameDecompose(self._ref)
+
+    def fingerprint_length(self) -> int:
+        return self._L.LBAudioDetectiveFrameFingerprintLength(self._ref)
+
+    def fingerprint_size(self) -> int:
+        return self._L.LBAudioDetectiveFrameFingerprintSize(self._ref)
+
+    def extract_fingerprint(self, n_wavelets: int) -> np.ndarray:
+        out = np.zeros(2 * n_wavelets, np.uint8)
+        self._L.LBAudioDetectiveFrameExtractFingerprint(self._ref, n_wavelets, out.ctypes.data)
+        return out
+
+    def equal_to_frame(self, other: "Frame") -> bool:
+        return bool(self._L.LBAudioDetectiveFrameEqualToFrame(self._ref, other._ref))
+
+
+class Detective:
+    """LBAudioDetectiveRef."""
+
+    def __init__(self):
+        self._L = N.lib()
+        self._ref = self._L.LBAudioDetectiveNew()
+
+    def dispose(self):
+        if self._ref:
+            self._L.LBAudioDetectiveDispose(self._ref)
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    # getters / setters (D.h:74-205)
+    processing_sample_rate = property(
+        lambda s: s._L.LBAudioDetectiveGetProcessingSampleRate(s._ref),
+        lambda s, v: _check(s._L.LBAudioDetectiveSetProcessingSampleRate(s._ref, float(v)), "SetProcessingSampleRate"))
+    number_of_pitch_steps = property(
+        lambda s: s._L.LBAudioDetectiveGetNumberOfPitchSteps(s._ref),
+        lambda s, v: _check(s._L.LBAudioDetectiveSetNumberOfPitchSteps(s._ref, int(v)), "SetNumberOfPitchSteps"))
+    subfingerprint_length = property(
+        lambda s: s._L.LBAudioDetectiveGetSubfingerprintLength(s._ref),
+        lambda s, v: _check(s._L.LBAudioDetectiveSetSubfingerprintLength(s._ref, int(v)), "SetSubfingerprintLength"))
+    window_size = property(
+        lambda s: s._L.LBAudioDetectiveGetWindowSize(s._ref),
+        lambda s, v: _check(s._L.LBAudioDetectiveSetWindowSize(s._ref, int(v)), "SetWindowSize"))
+    analysis_stride = property(
+        lambda s: s._L.LBAudioDetectiveGetAnalysisStride(s._ref),
+        lambda s, v: _check(s._L.LBAudioDetectiveSetAnalysisStride(s._ref, int(v)), "SetAnalysisStride"))
+
+    def set_window_size_status(self, v: int) -> int:
+        return self._L.LBAudioDetectiveSetWindowSize(self._ref, int(v))
+
+    def configure(self, sample_rate=None, window=None, stride=None, bands=None, subfp_len=None) -> "Detective":
+        if sample_rate is not None:
+            self.processing_sample_rate = sample_rate
+        if window is not None:
+            self.window_size = window
+        if stride is not None:
+            self.analysis_stride = stride
+        if bands is not None:
+            self.number_of_pitch_steps = bands
+        if subfp_len is not None:
+            self.subfingerprint_length = subfp_len
+        return self
+
+    def set_kernel_variant(self, variant: int):
+        _check(self._L.LBAudioDetectiveSetKernelVariant(self._ref, variant), "SetKernelVariant")
+
+    def subfingerprint_count(self, n_samples: int) -> int:
+        return int(self._L.LBAudioDetectiveGetSubfingerprintCount(self._ref, n_samples))
+
+    # file entry points (D.h:218,235)
+    def process_audio_url(self, path: str) -> Fingerprint:
+        out = N.Ref()
+        _check(self._L.LBAudioDetectiveProcessAudioURL(self._ref, path.encode(), C.byref(out)), "ProcessAudioURL")
+        return Fingerprint(_ref=out.value)
+
+    def compare_audio_urls(self, path1: str, path2: str, range_: int = 0) -> float:
+        m = N.Float32(float("nan"))
+        _check(self._L.LBAudioDetectiveCompareAudioURLs(self._ref, path1.encode(), path2.encode(), range_, C.byref(m)),
+               "CompareAudioURLs")
+        return float(m.value)
+
+    # PCM entry points
+    def process_pcm(self, pcm) -> Fingerprint:
+        x = _f32(pcm).reshape(-1)
+        out = N.Ref()
+        _check(self._L.LBAudioDetectiveProcessPCM(self._ref, x.ctypes.data, x.size, C.byref(out)), "ProcessPCM")
+        return Fingerprint(_ref=out.value)
+
+    def compare_pcm(self, pcm1, pcm2, range_: int = 0) -> float:
+        a, b = _f32(pcm1).reshape(-1), _f32(pcm2).reshape(-1)
+        m = N.Float32(float("nan"))
+        _check(self._L.LBAudioDetectiveComparePCM(self._ref, a.ctypes.data, a.size, b.ctypes.data, b.size, range_,
+                                                  C.byref(m)), "ComparePCM")
+        return float(m.value)
+
+    def fingerprint_clips(self, clips) -> np.ndarray:
+        """Host batch: [n_clips, samples] float32 -> [n_clips, count, subfp_len] Booleans."""
+        x = _f32(clips)
+        n, spc = x.shape
+        per = self.subfingerprint_count(spc)
+        out = np.zeros((n, per, self.subfingerprint_length), np.uint8)
+        _check(self._L.LBAudioDetectiveFingerprintClips(self._ref, x.ctypes.data, n, spc, out.ctypes.data),
+               "FingerprintClips")
+        return out
+
+    def fingerprint_clips_device(self, clips, out=None, stream=None, taps: bool = False):
+        """Device batch on torch tensors: clips [n, samples] float32 (cuda) -> packed uint8 [n, count, 32].
+
+        Asynchronous on the given (default: current) torch stream.  With taps=True also returns the
+        128 x bands frames before and after the Haar (unfused kernels only)."""
+        import torch
+        assert clips.is_cuda and clips.dtype == torch.float32 and clips.is_contiguous()
+        n, spc = clips.shape
+        per = self.subfingerprint_count(spc)
+        if out is None:
+            out = torch.empty((n, per, N.PACKED_BYTES), dtype=torch.uint8, device=clips.device)
+        sp = _stream_ptr(stream)
+        if not taps:
+            _check(self._L.LBAudioDetectiveFingerprintClipsDevice(self._ref, clips.data_ptr(), n, spc, out.data_ptr(), sp),
+                   "FingerprintClipsDevice")
+            return out
+        bands = self.number_of_pitch_steps
+        raw = torch.empty((n, per, N.ROWS_PER_FRAME, bands), dtype=torch.float32, device=clips.device)
+        haar = torch.empty_like(raw)
+        _check(self._L.LBAudioDetectiveFingerprintClipsDeviceTaps(self._ref, clips.data_ptr(), n, spc, out.data_ptr(),
+                                                                 raw.data_ptr(), haar.data_ptr(), sp),
+               "FingerprintClipsDeviceTaps")
+        return out, raw, haar
+
+
+class Corpus:
+    """LBAudioDetectiveCorpusRef: device-resident reference fingerprints with a top-1 query."""
+
+    def __init__(self, subfingerprint_length: int, subfingerprints_per_entry: int, capacity: int):
+        self._L = N.lib()
+        self._ref = self._L.LBAudioDetectiveCorpusNew(subfingerprint_length, subfingerprints_per_entry, capacity)
+        if not self._ref:
+            raise LBAudioDetectiveError(1, "CorpusNew (unsupported shape, zero capacity or no HIP device)")
+        self.subfingerprint_length = subfingerprint_length
+        self.subfingerprints_per_entry = subfingerprints_per_entry
+        self.capacity = capacity
+
+    def dispose(self):
+        if self._ref:
+            self._L.LBAudioDetectiveCorpusDispose(self._ref)
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._L.LBAudioDetectiveCorpusGetCount(self._ref))
+
+    @property
+    def entry_stride_bytes(self) -> int:
+        return int(self._L.LBAudioDetectiveCorpusGetEntryStrideBytes(self._ref))
+
+    def set_kernel_variant(self, variant: int):
+        _check(self._L.LBAudioDetectiveCorpusSetKernelVariant(self._ref, variant), "CorpusSetKernelVariant")
+
+    def append_packed_device(self, packed, stream=None):
+        """packed: torch uint8 [n, per_entry, 32] on the device."""
+        assert packed.is_cuda and packed.is_contiguous()
+        n = packed.shape[0]
+        _check(self._L.LBAudioDetectiveCorpusAppendPackedDevice(self._ref, packed.data_ptr(), n, _stream_ptr(stream)),
+               "CorpusAppendPackedDevice")
+
+    def append_fingerprint(self, fp: Fingerprint):
+        _check(self._L.LBAudioDetectiveCorpusAppendFingerprint(self._ref, fp._ref), "CorpusAppendFingerprint")
+
+    def query(self, fp: Fingerprint, range_: int = 0):
+        idx, score = N.SInt64(-1), N.Float32(0.0)
+        _check(self._L.LBAudioDetectiveCorpusQuery(self._ref, fp._ref, range_, C.byref(idx), C.byref(score)), "CorpusQuery")
+        return int(idx.value), float(score.value)
+
+    def query_key_device(self, fp: Fingerprint, key_out, range_: int = 0, index_base: int = 0, stream=None):
+        """Writes the 64-bit (score, ~index) key into key_out (torch int64[1] on the device), async."""
+        _check(self._L.LBAudioDetectiveCorpusQueryKeyDevice(self._ref, fp._ref, range_, index_base, key_out.data_ptr(),
+                                                           _stream_ptr(stream)), "CorpusQueryKeyDevice")
+        return key_out
+
+    def scores_device(self, fp: Fingerprint, range_: int = 0, stream=None):
+        import torch
+        out = torch.empty(len(self), dtype=torch.float32, device="cuda")
+        _check(self._L.LBAudioDetectiveCorpusScoresDevice(self._ref, fp._ref, range_, out.data_ptr(), _stream_ptr(stream)),
+               "CorpusScoresDevice")
+        return out
+
+    @staticmethod
+    def decode_key(key: int):
+        idx, score = N.SInt64(-1), N.Float32(0.0)
+        N.lib().LBAudioDetectiveCorpusDecodeKey(key & 0xFFFFFFFFFFFFFFFF, C.byref(idx), C.byref(score))
+        return int(idx.value), float(score.value)
+
+
+def synth_clips_device(seed: int, first: int, n_clips: int, sample_rate_hz: int, n_samples: int,
+                       stereo_sum: bool = False, out=None, stream=None):
+    import torch
+    if out is None:
+        out = torch.empty((n_clips, n_samples), dtype=torch.float32, device="cuda")
+    _check(N.lib().LBAudioDetectiveSynthClipsDevice(seed & 0xFFFFFFFF, first, n_clips, sample_rate_hz, n_samples,
+                                                    int(stereo_sum), out.data_ptr(), _stream_ptr(stream)),
+           "SynthClipsDevice")
+    return out
+
+
+def synth_corpus_device(seed: int, first: int, n_entries: int, n_sub: int, subfp_len: int, out=None, stream=None):
+    import torch
+    if out is None:
+        out = torch.empty((n_entries, n_sub, N.PACKED_BYTES), dtype=torch.uint8, device="cuda")
+    _check(N.lib().LBAudioDetectiveSynthCorpusDevice(seed & 0xFFFFFFFF, first, n_entries, n_sub, subfp_len,
+                                                     out.data_ptr(), _stream_ptr(stream)), "SynthCorpusDevice")
+    return out

@@ -1,0 +1,156 @@
+// api_corpus.cpp -- device-resident reference-fingerprint corpus and its top-1 query.
+// Scales the best-match loop of LBAudioDetectiveTests/LBAudioDetectiveTests.m:57-91 (one original
+// against N candidates, strict '<', first maximum wins) to an HBM-resident database.
+#include "internal.hpp"
+
+#include <cstring>
+
+namespace lbad {
+namespace {
+
+// stage the query on the device and launch the scan; key_dst is a device pointer
+OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
+                   uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
+    if (!c || !q || !key_dst) return kLBAudioDetectiveArgumentInvalid;
+    if (q->length != c->subfp_len || q->count == 0) return kLBAudioDetectiveArgumentInvalid;
+    if ((size_t)q->count * kPackedWords * 4 > 48 * 1024) return kLBAudioDetectiveArgumentInvalid;
+    if (range == 0) range = c->subfp_len;  // LBAudioDetective.m:443-445
+    std::vector<uint32_t> slots;
+    pack_fingerprint(q, slots);
+    bool fast = planes_fast_supported(c->subfp_len, c->n_sub, q->count);
+    if (c->variant == 1) fast = false;
+    if (c->variant == 2 && !fast) return kLBAudioDetectiveArgumentInvalid;
+    std::vector<uint32_t> block;
+    const std::vector<uint32_t>* up = &slots;
+    if (fast) {
+        build_plane_query(slots.data(), c->n_sub, range, block);
+        up = &block;
+    }
+    if (c->query_cap < up->size()) {
+        if (c->d_query) (void)hipFree(c->d_query);
+        if (c->h_query) (void)hipHostFree(c->h_query);
+        c->d_query = nullptr;
+        c->h_query = nullptr;
+        c->query_cap = 0;
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_query), up->size() * sizeof(uint32_t)));
+        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_query), up->size() * sizeof(uint32_t), hipHostMallocDefault));
+        c->query_cap = (uint32_t)up->size();
+    }
+    // the pinned staging block is reused by every query: wait for the previous one's copy
+    LBAD_HIP(hipStreamSynchronize(stream));
+    std::memcpy(c->h_query, up->data(), up->size() * sizeof(uint32_t));
+    LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, up->size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
+    if (fast) {
+        LBAD_HIP(launch_compare_planes_fast(c->d_planes, c->capacity, c->count, c->n_sub, c->d_query, index_base,
+                                            d_scores, key_dst, stream));
+    } else {
+        LBAD_HIP(launch_compare_planes_generic(c->d_planes, c->capacity, c->count, c->n_sub, c->subfp_len,
+                                               c->d_query, q->count, range, index_base, d_scores, key_dst, stream));
+    }
+    return noErr;
+}
+
+}  // namespace
+}  // namespace lbad
+
+extern "C" {
+
+LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLength, UInt32 inSubfingerprintsPerEntry,
+                                                    UInt64 inCapacity) {
+    if (inCapacity == 0 || inCapacity > 0xFFFFFFFFull) return NULL;  // the key carries a 32-bit index
+    if (!lbad::planes_supported(inSubfingerprintLength, inSubfingerprintsPerEntry)) return NULL;
+    if (!lbad::device_ready()) {
+        fprintf(stderr, "lbaudiodetective: no HIP device, cannot create a corpus\n");
+        return NULL;
+    }
+    LBAudioDetectiveCorpus* c = new LBAudioDetectiveCorpus();
+    c->subfp_len = inSubfingerprintLength;
+    c->n_sub = inSubfingerprintsPerEntry;
+    c->capacity = inCapacity;
+    c->n_planes = lbad::planes_per_entry(inSubfingerprintLength, inSubfingerprintsPerEntry);
+    const size_t bytes = (size_t)c->n_planes * inCapacity * sizeof(uint4);
+    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_planes), bytes), "hipMalloc corpus", __LINE__) != noErr ||
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr) {
+        LBAudioDetectiveCorpusDispose(c);
+        return NULL;
+    }
+    return c;
+}
+
+void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
+    if (!c) return;
+    if (c->d_planes) (void)hipFree(c->d_planes);
+    if (c->d_query) (void)hipFree(c->d_query);
+    if (c->h_query) (void)hipHostFree(c->h_query);
+    if (c->d_key) (void)hipFree(c->d_key);
+    delete c;
+}
+
+UInt64 LBAudioDetectiveCorpusGetCount(LBAudioDetectiveCorpusRef c) { return c ? c->count : 0; }
+
+UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef c) { return c ? c->n_planes * 16u : 0; }
+
+OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef c, UInt32 inVariant) {
+    if (!c || inVariant > 2) return kLBAudioDetectiveArgumentInvalid;
+    c->variant = inVariant;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef c, const void* inPacked,
+                                                  UInt64 inNumberOfEntries, void* inStream) {
+    if (!c || (!inPacked && inNumberOfEntries)) return kLBAudioDetectiveArgumentInvalid;
+    if (c->count + inNumberOfEntries > c->capacity) return kLBAudioDetectiveArgumentInvalid;
+    LBAD_HIP(lbad::launch_pack_planes(static_cast<const uint32_t*>(inPacked), inNumberOfEntries, c->n_sub, c->subfp_len,
+                                      c->d_planes, c->capacity, c->count, static_cast<hipStream_t>(inStream)));
+    c->count += inNumberOfEntries;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveCorpusAppendFingerprint(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef fp) {
+    if (!c || !fp || fp->count != c->n_sub || fp->length != c->subfp_len) return kLBAudioDetectiveArgumentInvalid;
+    std::vector<uint32_t> slots;
+    lbad::pack_fingerprint(fp, slots);
+    uint32_t* d = nullptr;
+    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d), slots.size() * 4));
+    OSStatus st = lbad::hip_status(hipMemcpy(d, slots.data(), slots.size() * 4, hipMemcpyHostToDevice), "copy", __LINE__);
+    if (st == noErr) st = LBAudioDetectiveCorpusAppendPackedDevice(c, d, 1, NULL);
+    if (st == noErr) st = lbad::hip_status(hipStreamSynchronize(nullptr), "sync", __LINE__);
+    (void)hipFree(d);
+    return st;
+}
+
+void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* outScore) {
+    const uint32_t bits = (uint32_t)(inKey >> 32);
+    float score;
+    std::memcpy(&score, &bits, 4);
+    if (outScore) *outScore = score;
+    // strict '<' against an initial 0.0 (LBAudioDetectiveTests.m:60,80): a best score of 0 selects nothing
+    if (outIndex) *outIndex = (inKey == 0 || !(score > 0.0f)) ? -1 : (SInt64)(0xFFFFFFFFu - (uint32_t)inKey);
+}
+
+OSStatus LBAudioDetectiveCorpusQueryKeyDevice(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef inQuery,
+                                              UInt32 inRange, UInt64 inIndexBase, void* outKey, void* inStream) {
+    if (c && inIndexBase + c->count > 0x100000000ull) return kLBAudioDetectiveArgumentInvalid;
+    return lbad::run_query(c, inQuery, inRange, inIndexBase, nullptr, static_cast<unsigned long long*>(outKey),
+                           static_cast<hipStream_t>(inStream));
+}
+
+OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef inQuery,
+                                            UInt32 inRange, Float32* outScores, void* inStream) {
+    if (!c || !outScores) return kLBAudioDetectiveArgumentInvalid;
+    return lbad::run_query(c, inQuery, inRange, 0, outScores, c->d_key, static_cast<hipStream_t>(inStream));
+}
+
+OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef inQuery, UInt32 inRange,
+                                     SInt64* outIndex, Float32* outScore) {
+    if (!c) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = lbad::run_query(c, inQuery, inRange, 0, nullptr, c->d_key, nullptr);
+    if (st != noErr) return st;
+    unsigned long long key = 0;
+    LBAD_HIP(hipMemcpy(&key, c->d_key, sizeof(key), hipMemcpyDeviceToHost));
+    LBAudioDetectiveCorpusDecodeKey(key, outIndex, outScore);
+    return noErr;
+}
+
+}  // extern "C"

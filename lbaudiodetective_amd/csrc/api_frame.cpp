@@ -1,0 +1,137 @@
+// api_frame.cpp -- LBAudioDetectiveFrame* (ragged rows on the host like upstream; the Haar
+// decomposition and the ranked sign extraction run on the GPU).
+// Mirrors LBAudioDetective/LBAudioDetectiveFrame.m; line cites refer to it.
+#include "internal.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+extern "C" {
+
+LBAudioDetectiveFrameRef LBAudioDetectiveFrameNew(UInt32 inMaxRowCount) {  // :22-31
+    LBAudioDetectiveFrame* f = new LBAudioDetectiveFrame();
+    f->max_rows = inMaxRowCount;
+    f->rows.resize(inMaxRowCount);
+    return f;
+}
+
+void LBAudioDetectiveFrameDispose(LBAudioDetectiveFrameRef inFrame) { delete inFrame; }  // :33-44
+
+LBAudioDetectiveFrameRef LBAudioDetectiveFrameCopy(LBAudioDetectiveFrameRef inFrame) {  // :46-63
+    LBAudioDetectiveFrame* f = new LBAudioDetectiveFrame(*inFrame);
+    // upstream copies exactly rowLength floats of the first numberOfRows rows
+    for (uint32_t r = 0; r < f->max_rows; ++r) {
+        if (r < f->n_rows) f->rows[r].resize(f->row_length);
+        else f->rows[r].clear();
+    }
+    return f;
+}
+
+UInt32 LBAudioDetectiveFrameGetNumberOfRows(LBAudioDetectiveFrameRef inFrame) { return inFrame->n_rows; }  // :67
+
+Float32* LBAudioDetectiveFrameGetRow(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex) {  // :71-73 (interior pointer)
+    return inFrame->rows[inRowIndex].data();
+}
+
+Float32 LBAudioDetectiveFrameGetValue(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex, UInt32 inColumnIndex) {  // :75
+    return inFrame->rows[inRowIndex][inColumnIndex];
+}
+
+Boolean LBAudioDetectiveFrameFull(LBAudioDetectiveFrameRef inFrame) {  // :79-81
+    return inFrame->n_rows >= inFrame->max_rows ? 1 : 0;
+}
+
+Boolean LBAudioDetectiveFrameSetRow(LBAudioDetectiveFrameRef inFrame, Float32* inRow, UInt32 inRowIndex,
+                                    UInt32 inCount) {  // :86-105
+    if (LBAudioDetectiveFrameFull(inFrame)) return 0;
+    inFrame->rows[inRowIndex].assign(inRow, inRow + inCount);
+    inFrame->row_length = inFrame->row_length == 0 ? inCount : std::min(inFrame->row_length, inCount);
+    inFrame->n_rows++;
+    return 1;
+}
+
+size_t LBAudioDetectiveFrameFingerprintSize(LBAudioDetectiveFrameRef inFrame) {  // :155-157
+    return (size_t)inFrame->n_rows * inFrame->row_length * 2 * sizeof(Boolean);
+}
+
+UInt32 LBAudioDetectiveFrameFingerprintLength(LBAudioDetectiveFrameRef inFrame) {  // :159-161
+    return inFrame->n_rows * inFrame->row_length * 2;
+}
+
+Boolean LBAudioDetectiveFrameEqualToFrame(LBAudioDetectiveFrameRef a, LBAudioDetectiveFrameRef b) {  // :193-210
+    if (a->row_length != b->row_length || a->n_rows != b->n_rows) return 0;
+    for (uint32_t r = 0; r < a->n_rows; ++r)
+        if (std::memcmp(a->rows[r].data(), b->rows[r].data(), a->row_length * sizeof(Float32)) != 0) return 0;
+    return 1;
+}
+
+}  // extern "C"
+
+namespace {
+
+// gather the first n_rows x row_length block into one dense matrix
+bool dense(const LBAudioDetectiveFrame* f, std::vector<float>& m) {
+    m.assign((size_t)f->n_rows * f->row_length, 0.0f);
+    for (uint32_t r = 0; r < f->n_rows; ++r) {
+        if (f->rows[r].size() < f->row_length) return false;
+        std::memcpy(m.data() + (size_t)r * f->row_length, f->rows[r].data(), f->row_length * sizeof(float));
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame) {  // :113-132
+    LBAudioDetectiveFrame* f = inFrame;
+    const uint32_t rows = f->n_rows, cols = f->row_length;
+    if (rows == 0 || cols == 0) return;
+    std::vector<float> m;
+    if (!dense(f, m)) return;
+    if (!lbad::device_ready()) {
+        fprintf(stderr, "lbaudiodetective: no HIP device, LBAudioDetectiveFrameDecompose did nothing\n");
+        return;
+    }
+    float* d = nullptr;
+    const size_t bytes = m.size() * sizeof(float);
+    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&d), 2 * bytes), "hipMalloc", __LINE__) != noErr) return;
+    bool ok = lbad::hip_status(hipMemcpy(d, m.data(), bytes, hipMemcpyHostToDevice), "copy in", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(lbad::launch_haar2d_generic(d, d + m.size(), rows, cols, nullptr), "haar", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(hipMemcpy(m.data(), d, bytes, hipMemcpyDeviceToHost), "copy out", __LINE__) == noErr;
+    (void)hipFree(d);
+    if (!ok) return;
+    for (uint32_t r = 0; r < rows; ++r)
+        std::memcpy(f->rows[r].data(), m.data() + (size_t)r * cols, cols * sizeof(float));
+}
+
+void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, UInt32 inNumberOfWavelets,
+                                             Boolean* outFingerprint) {  // :165-191
+    LBAudioDetectiveFrame* f = inFrame;
+    const uint32_t n = f->n_rows * f->row_length;
+    if (n == 0 || inNumberOfWavelets == 0) return;
+    std::vector<float> m;
+    if (!dense(f, m)) return;
+    if (!lbad::device_ready()) {
+        fprintf(stderr, "lbaudiodetective: no HIP device, LBAudioDetectiveFrameExtractFingerprint did nothing\n");
+        return;
+    }
+    const uint32_t nw = std::min(inNumberOfWavelets, n);  // upstream indexes past the array beyond n
+    float* d = nullptr;
+    uint8_t* d_out = nullptr;
+    const size_t bytes = m.size() * sizeof(float);
+    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&d), bytes + 2 * (size_t)nw), "hipMalloc", __LINE__) != noErr)
+        return;
+    d_out = reinterpret_cast<uint8_t*>(d) + bytes;
+    std::vector<uint8_t> flags((size_t)2 * nw, 0);
+    bool ok = lbad::hip_status(hipMemcpy(d, m.data(), bytes, hipMemcpyHostToDevice), "copy in", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(lbad::launch_extract_generic(d, n, nw, d_out, nullptr), "extract", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(hipMemcpy(flags.data(), d_out, flags.size(), hipMemcpyDeviceToHost), "copy out", __LINE__) == noErr;
+    (void)hipFree(d);
+    if (!ok) return;
+    // upstream only ever writes TRUE into the caller's (pre-zeroed) buffer
+    for (size_t i = 0; i < flags.size(); ++i)
+        if (flags[i]) outFingerprint[i] = 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// internal.hpp -- shared declarations of the HIP library (not installed; the ABI is include/lbaudiodetective.h)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/lbaudiodetective.h"
+
+namespace lbad {
+
+constexpr uint32_t kRowsPerFrame = 128;  // LBAudioDetective.m:25
+constexpr uint32_t kPackedWords = LBAD_PACKED_WORDS;
+constexpr uint32_t kMaxBands = 64;
+constexpr uint32_t kMinWindow = 16;
+constexpr uint32_t kMaxWindow = 8192;
+
+OSStatus hip_status(hipError_t e, const char* what, int line);
+#define LBAD_HIP(expr)                                                   \
+    do {                                                                 \
+        OSStatus st__ = ::lbad::hip_status((expr), #expr, __LINE__);     \
+        if (st__ != noErr) return st__;                                  \
+    } while (0)
+
+bool device_ready();
+
+// ---- per-configuration device plan ---------------------------------------------------------
+struct BandTable {
+    std::vector<uint32_t> indices;  // bands + 1
+    std::vector<uint32_t> lo, hi;   // bin bounds per band
+    uint32_t kmin = 0, kmax = 0;    // union of [lo, hi) over non-empty bands (kmin == kmax: nothing read)
+};
+
+// host-side, double precision; mirrors LBAudioDetective.m:361-371,382-383
+void make_band_table(double sample_rate, uint32_t window, uint32_t bands, BandTable& out);
+// master twiddle table exp(-2 pi i k / W), k in [0, W/2)
+void make_twiddles(uint32_t W, std::vector<float>& re, std::vector<float>& im);
+
+struct Plan {
+    double sample_rate = 0;
+    uint32_t window = 0, stride = 0, bands = 0, subfp_len = 0;
+    uint32_t log2w = 0;
+    uint32_t keep = 0;  // wavelets whose sign pair survives the truncation to subfp_len Booleans
+    BandTable table;
+    // device copies
+    float* d_tw = nullptr;        // [W/2] re then [W/2] im
+    uint32_t* d_bands = nullptr;  // [bands] lo, [bands] hi, then [bands] divisor as float bits
+    bool valid = false;
+};
+
+// ---- kernel launchers (k_*.hip) -------------------------------------------------------------
+// windows -> frame rows.  frames: [n_clips * frames_per_clip][128][bands]
+hipError_t launch_fft_bands(const Plan& plan, const float* d_pcm, uint64_t n_clips, uint64_t samples_per_clip,
+                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
+// frame rows -> packed sub-fingerprints.  d_haar (optional) receives the decomposed frames.
+hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_frames, uint32_t* d_packed,
+                              float* d_haar_out, hipStream_t stream);
+// fused per-frame kernel; returns hipErrorNotSupported when the plan has no specialisation
+bool fused_supported(const Plan& plan);
+hipError_t launch_fused(const Plan& plan, const float* d_pcm, uint64_t n_clips, uint64_t samples_per_clip,
+                        uint32_t frames_per_clip, uint32_t* d_packed, hipStream_t stream);
+
+// generic matrix ops behind the Frame API
+hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream);
+hipError_t launch_extract_generic(const float* d_m, uint32_t n, uint32_t n_wavelets, uint8_t* d_out,
+                                  hipStream_t stream);
+
+// compare
+// slot layout: entries[e][s][8 words]; writes per-entry score (optional) and atomically maxes the key
+hipError_t launch_compare_slots(const uint32_t* d_entries, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
+                                const uint32_t* d_query, uint32_t n_query, uint32_t range, uint64_t index_base,
+                                float* d_scores, unsigned long long* d_key, hipStream_t stream);
+// plane layout (tight bitstream, 16-byte planes); supported shapes only
+bool planes_supported(uint32_t subfp_len, uint32_t n_sub);
+uint32_t planes_per_entry(uint32_t subfp_len, uint32_t n_sub);
+hipError_t launch_pack_planes(const uint32_t* d_slots, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
+                              uint4* d_planes, uint64_t plane_stride, uint64_t first, hipStream_t stream);
+hipError_t launch_compare_planes_generic(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
+                                         uint32_t n_sub, uint32_t subfp_len, const uint32_t* d_query,
+                                         uint32_t n_query, uint32_t range, uint64_t index_base, float* d_scores,
+                                         unsigned long long* d_key, hipStream_t stream);
+// specialised scan (200-Boolean sub-fingerprints, query and entries of equal count <= 8)
+bool planes_fast_supported(uint32_t subfp_len, uint32_t n_sub, uint32_t n_query);
+uint32_t planes_fast_const_words(uint32_t n_sub);
+void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, std::vector<uint32_t>& out);
+hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
+                                      uint32_t n_sub, const uint32_t* d_qc, uint64_t index_base, float* d_scores,
+                                      unsigned long long* d_key, hipStream_t stream);
+void pack_fingerprint(const struct ::LBAudioDetectiveFingerprint* fp, std::vector<uint32_t>& out);
+
+// synthetic data
+hipError_t launch_synth_clips(uint32_t seed, uint64_t first, uint64_t n_clips, uint32_t rate_hz, uint32_t n_samples,
+                              uint32_t stereo, float* d_out, hipStream_t stream);
+hipError_t launch_synth_corpus(uint32_t seed, uint64_t first, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
+                               uint32_t* d_out, hipStream_t stream);
+
+}  // namespace lbad
+
+// ---- handle layouts ------------------------------------------------------------------------
+struct LBAudioDetectiveFingerprint {
+    uint32_t length = 0;
+    uint32_t count = 0;
+    std::vector<Boolean> data;  // count * length
+};
+
+struct LBAudioDetectiveFrame {
+    uint32_t max_rows = 0;
+    uint32_t n_rows = 0;
+    uint32_t row_length = 0;
+    std::vector<std::vector<Float32>> rows;  // max_rows slots, ragged like the reference
+};
+
+struct LBAudioDetective {
+    AudioStreamBasicDescription format;
+    uint32_t subfp_len;
+    uint32_t window;
+    uint32_t stride;
+    uint32_t bands;
+    uint32_t variant = 0;
+    lbad::Plan plan;         // lazily rebuilt when the configuration changes
+    float* d_frames = nullptr;  // scratch for the unfused path
+    uint64_t d_frames_cap = 0;  // in floats
+};
+
+struct LBAudioDetectiveCorpus {
+    uint32_t subfp_len = 0;
+    uint32_t n_sub = 0;
+    uint64_t capacity = 0;
+    uint64_t count = 0;
+    uint32_t variant = 0;
+    uint4* d_planes = nullptr;    // plane layout [n_planes][capacity]
+    uint32_t n_planes = 0;
+    uint32_t* d_query = nullptr;  // query block on the device
+    uint32_t* h_query = nullptr;  // pinned staging copy of it
+    uint32_t query_cap = 0;       // in words
+    unsigned long long* d_key = nullptr;
+};

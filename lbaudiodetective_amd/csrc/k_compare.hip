@@ -1,0 +1,384 @@
+// k_compare.hip -- fingerprint-vs-fingerprint compare and corpus top-1.
+//
+// Replaces LBAudioDetectiveFingerprintCompareSubfingerprints / ...CompareToFingerprint
+// (LBAudioDetectiveFingerprint.m:119-176) and the best-match loop of the test harness
+// (LBAudioDetectiveTests.m:57-91).
+//
+// Bit form of the per-sub-fingerprint rule.  A sub-fingerprint is a stream of Boolean pairs
+// (pos, neg) at even bit positions.  With A the longer side's sub-fingerprint and B the other:
+//   NZ       = (A | A >> 1) & EVEN & RANGE          pairs where A is non-zero      (Fp.m:159)
+//   Y        = (A ^ B) | (A ^ B) >> 1               pairs that differ in either Boolean
+//   possible = popc(NZ),  hits = popc(NZ & ~Y)      (Fp.m:160-167)
+//   ratio    = hits / possible in float32, 0 when possible == 0   (Fp.m:171-175)
+// Sums run in sub-fingerprint order in float32, then / (Float32)n2, then the running MAX over
+// offsets (Fp.m:136-146), exactly as the oracle does.
+//
+// Two layouts:
+//   slots  : entries[e][s][8 words]            (host fingerprints; one-off compares)
+//   planes : tight bitstream of n_sub * Lp bits per entry (Lp = length rounded up to even),
+//            cut into 16-byte planes stored plane-major so that lane e reads plane p at
+//            planes[p * stride + e] -- fully coalesced 1 KiB per wave-instruction.  At the
+//            default shape (5 x 200 Booleans) an entry is 1000 bits = 8 planes = 128 bytes of
+//            HBM traffic for 125 bytes of information.
+#include "internal.hpp"
+
+#include <cstring>
+
+namespace lbad {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ unsigned long long make_key(float score, uint64_t global_index) {
+    return ((unsigned long long)__float_as_uint(score) << 32) |
+           (unsigned long long)(0xFFFFFFFFu - (uint32_t)global_index);
+}
+
+__device__ __forceinline__ void block_max_key(unsigned long long k, unsigned long long* out) {
+    __shared__ unsigned long long s_k[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    if ((threadIdx.x & 63) == 0) s_k[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = s_k[0];
+        for (int i = 1; i < kThreads / 64; ++i) m = s_k[i] > m ? s_k[i] : m;
+        if (m) atomicMax(out, m);
+    }
+}
+
+// even-position bits of word w (bit positions 32w .. 32w+31 of the sub-fingerprint) that are
+// below 2 * pairs
+__device__ __forceinline__ uint32_t range_mask(uint32_t w, uint32_t pairs) {
+    const uint32_t lim = 2u * pairs;
+    const uint32_t base = 32u * w;
+    if (lim <= base) return 0u;
+    const uint32_t nb = lim - base;
+    const uint32_t m = nb >= 32u ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+    return m & 0x55555555u;
+}
+
+struct SubWords {
+    uint32_t w[kPackedWords];
+};
+
+// word j of sub-fingerprint s of entry e, both layouts
+template <bool PLANES>
+__device__ __forceinline__ SubWords load_sub(const uint32_t* __restrict__ base, uint64_t e, uint64_t stride,
+                                             uint32_t n_sub, uint32_t s, uint32_t lp) {
+    SubWords r;
+    if (!PLANES) {
+        const uint4* p = reinterpret_cast<const uint4*>(base + (e * n_sub + s) * kPackedWords);
+        const uint4 a = p[0], b = p[1];
+        r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+        r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+    } else {
+        const uint32_t total = (n_sub * lp + 31u) >> 5;  // words in the entry's stream (before plane padding)
+        const uint32_t off = s * lp;
+        const uint32_t w0 = off >> 5, sh = off & 31u;
+        auto word = [&](uint32_t w) -> uint32_t {
+            if (w >= total) return 0u;
+            return base[((uint64_t)(w >> 2) * stride + e) * 4u + (w & 3u)];
+        };
+        const uint32_t nwords = (lp + 31u) >> 5;
+        uint32_t prev = word(w0);
+#pragma unroll
+        for (uint32_t j = 0; j < kPackedWords; ++j) {
+            uint32_t v = 0u;
+            if (j < nwords) {
+                const uint32_t next = word(w0 + j + 1);
+                v = sh ? ((prev >> sh) | (next << (32u - sh))) : prev;
+                prev = next;
+                const uint32_t remaining = lp - 32u * j;
+                if (remaining < 32u) v &= (1u << remaining) - 1u;
+            }
+            r.w[j] = v;
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ float sub_ratio(const SubWords& a, const SubWords& b, const uint32_t* s_mask) {
+    uint32_t possible = 0, hits = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kPackedWords; ++w) {
+        const uint32_t nz = (a.w[w] | (a.w[w] >> 1)) & s_mask[w];
+        const uint32_t x = a.w[w] ^ b.w[w];
+        const uint32_t y = x | (x >> 1);
+        possible += __popc(nz);
+        hits += __popc(nz & ~y);
+    }
+    return possible ? __fdiv_rn((float)hits, (float)possible) : 0.0f;
+}
+
+template <bool PLANES>
+__global__ __launch_bounds__(kThreads) void compare_generic_kernel(
+    const uint32_t* __restrict__ entries, uint64_t stride, uint64_t n_entries, uint32_t n_sub, uint32_t lp,
+    const uint32_t* __restrict__ query, uint32_t n_query, uint32_t pairs, uint64_t index_base,
+    float* __restrict__ scores, unsigned long long* __restrict__ key_out) {
+    extern __shared__ uint32_t s_q[];  // n_query * 8 words
+    __shared__ uint32_t s_mask[kPackedWords];
+    for (uint32_t i = threadIdx.x; i < n_query * kPackedWords; i += kThreads) s_q[i] = query[i];
+    if (threadIdx.x < kPackedWords) s_mask[threadIdx.x] = range_mask(threadIdx.x, pairs);
+    __syncthreads();
+
+    unsigned long long best = 0ull;
+    for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
+         e += (uint64_t)gridDim.x * kThreads) {
+        // fp1 = query, fp2 = entry; the reference swaps so that "1" is the longer (Fp.m:123-131)
+        const bool query_is_long = n_query >= n_sub;
+        const uint32_t n1 = query_is_long ? n_query : n_sub;
+        const uint32_t n2 = query_is_long ? n_sub : n_query;
+        float match = 0.0f;
+        for (uint32_t offset = 0; offset + n2 <= n1; ++offset) {
+            float sum = 0.0f;
+            for (uint32_t i = 0; i < n2; ++i) {
+                SubWords a, b;
+                if (query_is_long) {
+#pragma unroll
+                    for (uint32_t w = 0; w < kPackedWords; ++w) a.w[w] = s_q[(i + offset) * kPackedWords + w];
+                    b = load_sub<PLANES>(entries, e, stride, n_sub, i, lp);
+                } else {
+                    a = load_sub<PLANES>(entries, e, stride, n_sub, i + offset, lp);
+#pragma unroll
+                    for (uint32_t w = 0; w < kPackedWords; ++w) b.w[w] = s_q[i * kPackedWords + w];
+                }
+                sum = __fadd_rn(sum, sub_ratio(a, b, s_mask));
+            }
+            const float cand = __fdiv_rn(sum, (float)n2);
+            match = (match < cand) ? cand : match;  // Foundation MAX(A,B) = a < b ? b : a
+        }
+        if (scores) scores[e] = match;
+        const unsigned long long k = make_key(match, index_base + e);
+        best = k > best ? k : best;
+    }
+    block_max_key(best, key_out);
+}
+
+// ---- slots -> planes ----------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void pack_planes_kernel(const uint32_t* __restrict__ slots,
+                                                               uint64_t n_entries, uint32_t n_sub, uint32_t lp,
+                                                               uint32_t n_planes, uint4* __restrict__ planes,
+                                                               uint64_t stride, uint64_t first) {
+    const uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t p = blockIdx.y;
+    if (e >= n_entries || p >= n_planes) return;
+    const uint32_t total_bits = n_sub * lp;
+    const uint32_t* ent = slots + e * n_sub * kPackedWords;
+    uint32_t out[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; ++q) {
+        uint32_t word = 0u, filled = 0u;
+        uint32_t pos = (p * 4u + q) * 32u;
+        while (filled < 32u && pos < total_bits) {
+            const uint32_t s = pos / lp, o = pos % lp;
+            uint32_t take = 32u - filled;
+            if (take > lp - o) take = lp - o;
+            const uint32_t* sw = ent + s * kPackedWords;
+            const uint32_t wi = o >> 5, sh = o & 31u;
+            uint64_t win = sw[wi];
+            if (wi + 1 < kPackedWords) win |= (uint64_t)sw[wi + 1] << 32;
+            uint32_t bits = (uint32_t)(win >> sh);
+            if (take < 32u) bits &= (1u << take) - 1u;
+            word |= bits << filled;
+            filled += take;
+            pos += take;
+        }
+        out[q] = word;
+    }
+    planes[(uint64_t)p * stride + first + e] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// ---- specialised scan: Lp = 200, n_query == n_sub == NSUB, query supplies the mask --------
+constexpr uint32_t kLp = 200;
+constexpr uint32_t kSubSpan = 7;  // a 200-bit field at an even multiple-of-8 bit offset touches <= 7 words
+
+template <int NSUB>
+struct PlaneShape {
+    static constexpr uint32_t bits = NSUB * kLp;
+    static constexpr uint32_t words = (bits + 31) / 32;
+    static constexpr uint32_t planes = (bits + 127) / 128;
+    // constant block handed to the kernel: query stream, per-(sub, span word) NZ masks, possible counts
+    static constexpr uint32_t off_mask = planes * 4;
+    static constexpr uint32_t off_possible = off_mask + NSUB * kSubSpan;
+    static constexpr uint32_t total = off_possible + NSUB;
+};
+
+template <int NSUB>
+__global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* __restrict__ planes, uint64_t stride,
+                                                                  uint64_t n_entries,
+                                                                  const uint32_t* __restrict__ qc,
+                                                                  uint64_t index_base, float* __restrict__ scores,
+                                                                  unsigned long long* __restrict__ key_out) {
+    using S = PlaneShape<NSUB>;
+    __shared__ uint32_t s_c[S::total];
+    for (uint32_t i = threadIdx.x; i < S::total; i += kThreads) s_c[i] = qc[i];
+    __syncthreads();
+
+    unsigned long long best = 0ull;
+    for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
+         e += (uint64_t)gridDim.x * kThreads) {
+        uint32_t y[S::planes * 4];
+#pragma unroll
+        for (uint32_t p = 0; p < S::planes; ++p) {
+            const uint4 v = planes[(uint64_t)p * stride + e];
+            y[4 * p + 0] = v.x; y[4 * p + 1] = v.y; y[4 * p + 2] = v.z; y[4 * p + 3] = v.w;
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < S::planes * 4; ++w) {
+            const uint32_t x = y[w] ^ s_c[w];
+            y[w] = ~(x | (x >> 1));
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (uint32_t s = 0; s < (uint32_t)NSUB; ++s) {
+            const uint32_t w0 = (s * kLp) >> 5;
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kSubSpan; ++j) {
+                if (w0 + j < S::planes * 4) hits += __popc(y[w0 + j] & s_c[S::off_mask + s * kSubSpan + j]);
+            }
+            const float possible = __uint_as_float(s_c[S::off_possible + s]);
+            const float ratio = possible > 0.0f ? __fdiv_rn((float)hits, possible) : 0.0f;
+            sum = __fadd_rn(sum, ratio);
+        }
+        const float cand = __fdiv_rn(sum, (float)NSUB);
+        const float match = (0.0f < cand) ? cand : 0.0f;
+        if (scores) scores[e] = match;
+        const unsigned long long k = make_key(match, index_base + e);
+        best = k > best ? k : best;
+    }
+    block_max_key(best, key_out);
+}
+
+uint32_t grid_for(uint64_t n_entries) {
+    const uint64_t blocks = (n_entries + kThreads - 1) / kThreads;
+    const uint64_t cap = 256ull * 8ull;  // 8 workgroups per CU, grid-stride the rest
+    return (uint32_t)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+template <int NSUB>
+hipError_t launch_planes_n(const uint4* d_planes, uint64_t stride, uint64_t n_entries, const uint32_t* d_qc,
+                           uint64_t index_base, float* d_scores, unsigned long long* d_key, hipStream_t stream) {
+    hipLaunchKernelGGL(compare_planes_kernel<NSUB>, dim3(grid_for(n_entries)), dim3(kThreads), 0, stream, d_planes,
+                       stride, n_entries, d_qc, index_base, d_scores, d_key);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+uint32_t planes_per_entry(uint32_t subfp_len, uint32_t n_sub) {
+    const uint32_t lp = subfp_len + (subfp_len & 1u);
+    return (n_sub * lp + 127u) / 128u;
+}
+
+bool planes_supported(uint32_t subfp_len, uint32_t n_sub) {
+    // the tight layout itself is generic; cap the entry at 64 planes (8192 bits)
+    return subfp_len >= 2 && subfp_len <= LBAD_MAX_SUBFINGERPRINT_LENGTH && n_sub >= 1 &&
+           planes_per_entry(subfp_len, n_sub) <= 64;
+}
+
+hipError_t launch_pack_planes(const uint32_t* d_slots, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
+                              uint4* d_planes, uint64_t plane_stride, uint64_t first, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    const uint32_t lp = subfp_len + (subfp_len & 1u);
+    const uint32_t np = planes_per_entry(subfp_len, n_sub);
+    const uint64_t bx = (n_entries + kThreads - 1) / kThreads;
+    if (bx > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3((uint32_t)bx, np), dim3(kThreads), 0, stream, d_slots, n_entries,
+                       n_sub, lp, np, d_planes, plane_stride, first);
+    return hipGetLastError();
+}
+
+hipError_t launch_compare_slots(const uint32_t* d_entries, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
+                                const uint32_t* d_query, uint32_t n_query, uint32_t range, uint64_t index_base,
+                                float* d_scores, unsigned long long* d_key, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    const uint32_t lim = range < subfp_len ? range : subfp_len;
+    const uint32_t pairs = (lim + 1u) / 2u;
+    const uint32_t lp = subfp_len + (subfp_len & 1u);
+    const size_t lds = (size_t)n_query * kPackedWords * sizeof(uint32_t);
+    hipLaunchKernelGGL(compare_generic_kernel<false>, dim3(grid_for(n_entries)), dim3(kThreads), lds, stream,
+                       d_entries, (uint64_t)0, n_entries, n_sub, lp, d_query, n_query, pairs, index_base, d_scores,
+                       d_key);
+    return hipGetLastError();
+}
+
+hipError_t launch_compare_planes_generic(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
+                                         uint32_t n_sub, uint32_t subfp_len, const uint32_t* d_query,
+                                         uint32_t n_query, uint32_t range, uint64_t index_base, float* d_scores,
+                                         unsigned long long* d_key, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    const uint32_t lim = range < subfp_len ? range : subfp_len;
+    const uint32_t pairs = (lim + 1u) / 2u;
+    const uint32_t lp = subfp_len + (subfp_len & 1u);
+    const size_t lds = (size_t)n_query * kPackedWords * sizeof(uint32_t);
+    hipLaunchKernelGGL(compare_generic_kernel<true>, dim3(grid_for(n_entries)), dim3(kThreads), lds, stream,
+                       reinterpret_cast<const uint32_t*>(d_planes), plane_stride, n_entries, n_sub, lp, d_query,
+                       n_query, pairs, index_base, d_scores, d_key);
+    return hipGetLastError();
+}
+
+bool planes_fast_supported(uint32_t subfp_len, uint32_t n_sub, uint32_t n_query) {
+    return subfp_len == kLp && n_query == n_sub && n_sub >= 1 && n_sub <= 8;
+}
+
+uint32_t planes_fast_const_words(uint32_t n_sub) {
+    const uint32_t planes = (n_sub * kLp + 127) / 128;
+    return planes * 4 + n_sub * kSubSpan + n_sub;
+}
+
+// Host: build the constant block of the specialised kernel from the query's slot words.
+void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, std::vector<uint32_t>& out) {
+    const uint32_t planes = (n_sub * kLp + 127) / 128;
+    const uint32_t words = planes * 4;
+    out.assign(planes_fast_const_words(n_sub), 0u);
+    const uint32_t lim = range < kLp ? range : kLp;
+    const uint32_t pairs = (lim + 1u) / 2u;
+    for (uint32_t s = 0; s < n_sub; ++s) {
+        uint32_t possible = 0;
+        for (uint32_t b = 0; b < kLp; ++b) {
+            const uint32_t bit = (q_slots[s * kPackedWords + (b >> 5)] >> (b & 31)) & 1u;
+            const uint32_t pos = s * kLp + b;
+            if (bit) out[pos >> 5] |= 1u << (pos & 31);
+        }
+        const uint32_t w0 = (s * kLp) >> 5;
+        for (uint32_t p = 0; p < pairs; ++p) {
+            const uint32_t b0 = 2 * p, b1 = 2 * p + 1;
+            const uint32_t v0 = (q_slots[s * kPackedWords + (b0 >> 5)] >> (b0 & 31)) & 1u;
+            const uint32_t v1 = b1 < kLp ? (q_slots[s * kPackedWords + (b1 >> 5)] >> (b1 & 31)) & 1u : 0u;
+            if (v0 | v1) {
+                ++possible;
+                const uint32_t pos = s * kLp + b0;
+                const uint32_t j = (pos >> 5) - w0;
+                out[words + s * kSubSpan + j] |= 1u << (pos & 31);
+            }
+        }
+        const float pf = (float)possible;
+        uint32_t pbits;
+        memcpy(&pbits, &pf, 4);
+        out[words + n_sub * kSubSpan + s] = pbits;
+    }
+}
+
+hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
+                                      uint32_t n_sub, const uint32_t* d_qc, uint64_t index_base, float* d_scores,
+                                      unsigned long long* d_key, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    switch (n_sub) {
+        case 1: return launch_planes_n<1>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 2: return launch_planes_n<2>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 3: return launch_planes_n<3>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 4: return launch_planes_n<4>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 5: return launch_planes_n<5>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 6: return launch_planes_n<6>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 7: return launch_planes_n<7>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 8: return launch_planes_n<8>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        default: return hipErrorNotSupported;
+    }
+}
+
+}  // namespace lbad

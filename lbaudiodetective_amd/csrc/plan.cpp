@@ -1,0 +1,86 @@
+// plan.cpp -- host-side tables of the fingerprint path (double precision, computed once per
+// configuration instead of once per window as LBAudioDetective.m:361-371 does).
+#include "internal.hpp"
+
+#include <cmath>
+
+namespace lbad {
+
+OSStatus hip_status(hipError_t e, const char* what, int line) {
+    if (e == hipSuccess) return noErr;
+    fprintf(stderr, "lbaudiodetective: HIP error %d (%s) at %s, line %d\n", (int)e, hipGetErrorString(e), what, line);
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver)
+        return kLBAudioDetectiveDeviceUnavailable;
+    return kLBAudioDetectiveDeviceError;
+}
+
+bool device_ready() {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+namespace {
+// (UInt32) of a Float64: values below zero give 0 (the reference's ARM targets saturate; see
+// SURVEY.md Q4 -- negative fractions occur for the first bands at 44.1 kHz / 1024).
+uint32_t to_u32(double v) {
+    if (!(v > 0.0)) return 0u;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+}  // namespace
+
+void make_band_table(double sample_rate, uint32_t window, uint32_t bands, BandTable& out) {
+    out.indices.assign(bands + 1, 0);
+    out.lo.assign(bands, 0);
+    out.hi.assign(bands, 0);
+    // LBAudioDetective.m:362-366
+    const double top = sample_rate / 2.0;
+    const double bottom = 318.0;
+    const double base = std::exp(std::log(top / bottom) / bands);
+    const double coef = (double)window / sample_rate * bottom;
+    for (uint32_t j = 0; j <= bands; ++j)  // :368-371
+        out.indices[j] = to_u32((std::pow(base, (double)j) - 1.0) * coef) + to_u32(coef);
+    // :382-383 -- the edges are FFT bin numbers but get converted once more as if they were Hz
+    const double bin_hz = sample_rate / window;
+    const uint32_t nyq = window / 2;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    for (uint32_t i = 0; i < bands; ++i) {
+        uint32_t l = to_u32((double)(uint32_t)(2u * out.indices[i]) / bin_hz - 1.0);
+        uint32_t h = to_u32((double)(uint32_t)(2u * out.indices[i + 1]) / bin_hz - 1.0);
+        if (l > nyq) l = nyq;  // bins past the buffer are not read (the reference would overrun)
+        if (h > nyq) h = nyq;
+        out.lo[i] = l;
+        out.hi[i] = h;
+        if (l < h) {
+            if (l < kmin) kmin = l;
+            if (h > kmax) kmax = h;
+        }
+    }
+    if (kmin > kmax) kmin = kmax = 0;
+    out.kmin = kmin;
+    out.kmax = kmax;
+}
+
+void make_twiddles(uint32_t W, std::vector<float>& re, std::vector<float>& im) {
+    const uint32_t half = W / 2, quarter = W / 4, eighth = W / 8;
+    re.assign(half, 0.0f);
+    im.assign(half, 0.0f);
+    // first octant from libm in double, the rest by symmetry so that e.g. cos(pi/4) == sin(pi/4)
+    // and cos(pi/2) == 0 hold exactly in float32
+    for (uint32_t k = 0; k < half; ++k) {
+        uint32_t f = k;
+        bool mirror = false, transpose = false;
+        if (f > quarter) { f = half - f; mirror = true; }
+        if (f > eighth) { f = quarter - f; transpose = true; }
+        const double a = (2.0 * M_PI * (double)f) / (double)W;
+        float c = (float)std::cos(a), s = (float)std::sin(a);
+        if (f == eighth) s = c;
+        if (transpose) std::swap(c, s);
+        if (mirror) c = -c;
+        if (k == quarter) c = 0.0f;
+        re[k] = c;
+        im[k] = -s;
+    }
+}
+
+}  // namespace lbad

@@ -1,0 +1,64 @@
+"""Corpus sharded across the GPUs of one node (one process per GPU, torch.distributed).
+
+Each rank holds a contiguous index range of the reference-fingerprint database and scans only
+that.  The single exchange step is a MAX all-reduce of one int64 per query:
+``key = float_bits(best score) << 32 | (0xFFFFFFFF - global index)``.  Scores are >= 0, so their
+IEEE bit patterns order like the values, and the complemented index makes the LOWEST index win
+ties -- the strict '<' of the upstream best-match loop (LBAudioDetectiveTests.m:80-83).  With the
+"nccl" backend (RCCL on ROCm) the 8-byte message travels over xGMI; "gloo" is used by the CPU
+tests of this reduction logic.
+"""
+from __future__ import annotations
+
+
+def shard_range(n_entries: int, rank: int, world_size: int):
+    """Contiguous [begin, end) of rank's shard; sizes differ by at most one."""
+    base, extra = divmod(n_entries, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def make_key(score_bits: int, global_index: int) -> int:
+    return (score_bits << 32) | (0xFFFFFFFF - global_index)
+
+
+def decode_key(key: int):
+    """(index, score) from a reduced key; index -1 when nothing scored above 0."""
+    import struct
+    key &= 0xFFFFFFFFFFFFFFFF
+    score = struct.unpack("<f", struct.pack("<I", key >> 32))[0]
+    if key == 0 or not score > 0.0:
+        return -1, score
+    return 0xFFFFFFFF - (key & 0xFFFFFFFF), score
+
+
+def allreduce_best(key_tensor, group=None):
+    """In-place MAX all-reduce of an int64 key tensor (any device the backend supports)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(key_tensor, op=dist.ReduceOp.MAX, group=group)
+    return key_tensor
+
+
+class ShardedCorpus:
+    """This rank's shard of a global corpus plus the collective top-1 query."""
+
+    def __init__(self, subfingerprint_length: int, subfingerprints_per_entry: int, n_entries_global: int,
+                 rank: int = 0, world_size: int = 1, group=None):
+        from .api import Corpus
+        self.rank, self.world_size, self.group = rank, world_size, group
+        self.n_entries_global = n_entries_global
+        self.begin, self.end = shard_range(n_entries_global, rank, world_size)
+        self.local = Corpus(subfingerprint_length, subfingerprints_per_entry, max(1, self.end - self.begin))
+
+    def append_packed_device(self, packed, stream=None):
+        self.local.append_packed_device(packed, stream)
+
+    def query(self, fp, range_: int = 0, key_out=None):
+        """Collective: every rank calls it with the same query; returns (global index, score)."""
+        import torch
+        if key_out is None:
+            key_out = torch.zeros(1, dtype=torch.int64, device="cuda")
+        self.local.query_key_device(fp, key_out, range_, index_base=self.begin)
+        allreduce_best(key_out, self.group)
+        return decode_key(int(key_out.item()))

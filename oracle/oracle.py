@@ -1,0 +1,236 @@
+"""ctypes front end for the CPU parity oracle (oracle/lbad_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (lbaudiodetective_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liblbad_oracle.so")
+
+ROWS_PER_FRAME = 128
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_double),
+        ("window", C.c_uint32),
+        ("stride", C.c_uint32),
+        ("bands", C.c_uint32),
+        ("subfp_len", C.c_uint32),
+    ]
+
+    def __init__(self, sample_rate=5512.0, window=2048, stride=64, bands=32, subfp_len=200):
+        super().__init__(float(sample_rate), int(window), int(stride), int(bands), int(subfp_len))
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (no GPU involved)."""
+    src = os.path.join(_HERE, "lbad_oracle.c")
+    hdr = os.path.join(_HERE, "lbad_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+    cfgp = C.POINTER(Config)
+
+    def sig(name, res, args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+    sig("lbo_twiddles", None, [C.c_uint32, f32p, f32p])
+    sig("lbo_rfft_packed", C.c_int, [f32p, C.c_uint32, f32p])
+    sig("lbo_band_table", None, [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p])
+    sig("lbo_band_energies", None, [f32p, C.c_uint32, C.c_uint32, u32p, u32p, u32p, f32p])
+    sig("lbo_window_row", C.c_int, [f32p, cfgp, f32p])
+    sig("lbo_haar_1d", None, [f32p, C.c_uint32])
+    sig("lbo_haar_2d", None, [f32p, C.c_uint32, C.c_uint32])
+    sig("lbo_extract", None, [f32p, C.c_uint32, C.c_uint32, C.c_uint32, u8p])
+    sig("lbo_subfingerprint_count", C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32])
+    sig("lbo_fingerprint_pcm", C.c_uint64, [f32p, C.c_uint64, cfgp, u8p])
+    sig("lbo_fingerprint_pcm_taps", C.c_uint64, [f32p, C.c_uint64, cfgp, u8p, C.c_void_p, C.c_void_p])
+    sig("lbo_fingerprint_batch", C.c_int, [f32p, C.c_uint64, C.c_uint64, cfgp, u8p, C.c_int])
+    sig("lbo_compare_sub", C.c_float, [u8p, u8p, C.c_uint32, C.c_uint32])
+    sig("lbo_compare_fp", C.c_float, [u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32])
+    sig("lbo_corpus_best", None, [u8p, C.c_uint32, u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)])
+    sig("lbo_synth_sine_table", None, [i16p])
+    sig("lbo_synth_clip", None, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_int, f32p])
+    sig("lbo_synth_entry", None, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, u8p])
+    _lib = L
+    return L
+
+
+# ---------------------------------------------------------------------------------------------
+# thin numpy wrappers
+# ---------------------------------------------------------------------------------------------
+def twiddles(W: int):
+    re = np.empty(W // 2, np.float32)
+    im = np.empty(W // 2, np.float32)
+    lib().lbo_twiddles(W, re, im)
+    return re, im
+
+
+def rfft_packed(x: np.ndarray) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    if lib().lbo_rfft_packed(x, x.size, out) != 0:
+        raise ValueError("window must be a power of two >= 8")
+    return out
+
+
+def band_table(sample_rate: float, window: int, bands: int = 32, n_frames: int | None = None):
+    n_frames = window if n_frames is None else n_frames
+    idx = np.empty(bands + 1, np.uint32)
+    lo = np.empty(bands, np.uint32)
+    hi = np.empty(bands, np.uint32)
+    lib().lbo_band_table(sample_rate, window, n_frames, bands, idx, lo, hi)
+    return idx, lo, hi
+
+
+def band_energies(spectrum: np.ndarray, idx, lo, hi) -> np.ndarray:
+    spectrum = np.ascontiguousarray(spectrum, np.float32)
+    out = np.empty(len(lo), np.float32)
+    lib().lbo_band_energies(spectrum, spectrum.size, len(lo), idx, lo, hi, out)
+    return out
+
+
+def window_row(pcm_window: np.ndarray, cfg: Config) -> np.ndarray:
+    w = np.ascontiguousarray(pcm_window, np.float32)
+    out = np.empty(cfg.bands, np.float32)
+    if lib().lbo_window_row(w, C.byref(cfg), out) != 0:
+        raise ValueError("invalid config")
+    return out
+
+
+def haar_1d(a: np.ndarray) -> np.ndarray:
+    a = np.array(a, np.float32, order="C")
+    lib().lbo_haar_1d(a, a.size)
+    return a
+
+
+def haar_2d(m: np.ndarray) -> np.ndarray:
+    m = np.array(m, np.float32, order="C")
+    lib().lbo_haar_2d(m, m.shape[0], m.shape[1])
+    return m
+
+
+def extract(m: np.ndarray, n_wavelets: int) -> np.ndarray:
+    m = np.ascontiguousarray(m, np.float32)
+    out = np.zeros(2 * n_wavelets, np.uint8)
+    lib().lbo_extract(m, m.shape[0], m.shape[1], n_wavelets, out)
+    return out
+
+
+def subfingerprint_count(n_samples: int, window: int, stride: int) -> int:
+    return int(lib().lbo_subfingerprint_count(n_samples, window, stride))
+
+
+def fingerprint_pcm(pcm: np.ndarray, cfg: Config, taps: bool = False):
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    n = subfingerprint_count(pcm.size, cfg.window, cfg.stride)
+    out = np.zeros((n, cfg.subfp_len), np.uint8)
+    if not taps:
+        got = lib().lbo_fingerprint_pcm(pcm, pcm.size, C.byref(cfg), out.reshape(-1) if n else np.zeros(1, np.uint8))
+        if got == 2**64 - 1:
+            raise ValueError("invalid config")
+        return out
+    raw = np.zeros((n, ROWS_PER_FRAME, cfg.bands), np.float32)
+    haar = np.zeros_like(raw)
+    got = lib().lbo_fingerprint_pcm_taps(
+        pcm, pcm.size, C.byref(cfg), out.reshape(-1) if n else np.zeros(1, np.uint8),
+        raw.ctypes.data_as(C.c_void_p), haar.ctypes.data_as(C.c_void_p))
+    if got == 2**64 - 1:
+        raise ValueError("invalid config")
+    return out, raw, haar
+
+
+def fingerprint_batch(pcm: np.ndarray, cfg: Config, nthreads: int = 1) -> np.ndarray:
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    n_clips, spc = pcm.shape
+    per = subfingerprint_count(spc, cfg.window, cfg.stride)
+    out = np.zeros((n_clips, per, cfg.subfp_len), np.uint8)
+    rc = lib().lbo_fingerprint_batch(pcm.reshape(-1), n_clips, spc, C.byref(cfg),
+                                     out.reshape(-1) if out.size else np.zeros(1, np.uint8), nthreads)
+    if rc != 0:
+        raise ValueError("invalid config")
+    return out
+
+
+def compare_sub(a: np.ndarray, b: np.ndarray, range_: int) -> float:
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return float(lib().lbo_compare_sub(a, b, a.size, range_))
+
+
+def compare_fp(fp1: np.ndarray, fp2: np.ndarray, range_: int, subfp_len: int | None = None) -> float:
+    fp1 = np.ascontiguousarray(fp1, np.uint8)
+    fp2 = np.ascontiguousarray(fp2, np.uint8)
+    L = subfp_len if subfp_len is not None else (fp1.shape[1] if fp1.ndim == 2 and fp1.shape[0] else fp2.shape[1])
+    n1 = fp1.shape[0] if fp1.ndim == 2 else 0
+    n2 = fp2.shape[0] if fp2.ndim == 2 else 0
+    d1 = fp1.reshape(-1) if fp1.size else np.zeros(1, np.uint8)
+    d2 = fp2.reshape(-1) if fp2.size else np.zeros(1, np.uint8)
+    return float(lib().lbo_compare_fp(d1, n1, d2, n2, L, range_))
+
+
+def corpus_best(query: np.ndarray, corpus: np.ndarray, range_: int, nthreads: int = 1):
+    query = np.ascontiguousarray(query, np.uint8)
+    corpus = np.ascontiguousarray(corpus, np.uint8)
+    n_entries, n_sub, L = corpus.shape
+    bi = C.c_int64(-1)
+    bs = C.c_float(0.0)
+    lib().lbo_corpus_best(query.reshape(-1), query.shape[0], corpus.reshape(-1), n_entries, n_sub, L, range_,
+                          nthreads, C.byref(bi), C.byref(bs))
+    return int(bi.value), float(bs.value)
+
+
+def synth_sine_table() -> np.ndarray:
+    t = np.zeros(1024, np.int16)
+    lib().lbo_synth_sine_table(t)
+    return t
+
+
+def synth_clip(seed: int, clip: int, sample_rate: float, n_samples: int, stereo_sum: bool = False) -> np.ndarray:
+    out = np.empty(n_samples, np.float32)
+    lib().lbo_synth_clip(seed & 0xFFFFFFFF, clip, sample_rate, n_samples, int(stereo_sum), out)
+    return out
+
+
+def synth_clips(seed: int, first: int, count: int, sample_rate: float, n_samples: int, stereo_sum=False):
+    return np.stack([synth_clip(seed, first + i, sample_rate, n_samples, stereo_sum) for i in range(count)])
+
+
+def synth_entry(seed: int, entry: int, n_sub: int, subfp_len: int) -> np.ndarray:
+    out = np.zeros((n_sub, subfp_len), np.uint8)
+    lib().lbo_synth_entry(seed & 0xFFFFFFFF, entry, n_sub, subfp_len, out.reshape(-1))
+    return out
+
+
+def synth_corpus(seed: int, first: int, count: int, n_sub: int, subfp_len: int) -> np.ndarray:
+    return np.stack([synth_entry(seed, first + i, n_sub, subfp_len) for i in range(count)])

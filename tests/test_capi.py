@@ -1,0 +1,156 @@
+"""CPU tests of the C ABI: the library loads, exports every symbol the header declares, the
+host-side containers behave like the upstream ones, and compute entry points refuse to run
+(loudly, no fallback) when there is no GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_exports_every_declared_symbol(lb):
+    funcs, consts = lb._native.declared_symbols()
+    assert len(funcs) >= 60 and len(consts) == 8
+    raw = C.CDLL(lb.LIB_PATH)
+    for name in funcs + consts:
+        assert hasattr(raw, name), f"{name} declared in include/lbaudiodetective.h but not exported"
+    assert sorted(lb._native._SIGNATURES) == funcs
+    assert sorted(lb._native.CONSTANTS) == consts
+
+
+def test_constants(lb):
+    # LBAudioDetective.m:20-26
+    assert lb.constant("kLBAudioDetectiveArgumentInvalid") == 1
+    assert lb.constant("kLBAudioDetectiveDefaultWindowSize") == 2048
+    assert lb.constant("kLBAudioDetectiveDefaultAnalysisStride") == 64
+    assert lb.constant("kLBAudioDetectiveDefaultNumberOfPitchSteps") == 32
+    assert lb.constant("kLBAudioDetectiveDefaultSubfingerprintLength") == 200
+
+
+def test_detective_defaults_and_setters(lb):
+    d = lb.Detective()
+    assert (d.processing_sample_rate, d.window_size, d.analysis_stride, d.number_of_pitch_steps,
+            d.subfingerprint_length) == (5512.0, 2048, 64, 32, 200)
+    f = lb.lib().LBAudioDetectiveDefaultProcessingFormat()   # LBAudioDetective.m:116-131
+    assert (f.mSampleRate, f.mFormatID, f.mFormatFlags, f.mBitsPerChannel, f.mChannelsPerFrame,
+            f.mBytesPerFrame, f.mBytesPerPacket, f.mFramesPerPacket) == (5512.0, 0x6C70636D, 9, 32, 1, 4, 4, 1)
+    d.configure(sample_rate=44100, window=1024, stride=32, bands=16, subfp_len=64)
+    assert (d.processing_sample_rate, d.window_size, d.analysis_stride, d.number_of_pitch_steps,
+            d.subfingerprint_length) == (44100.0, 1024, 32, 16, 64)
+    # SetWindowSize: power of two -> noErr, anything else -> ArgumentInvalid and no change
+    assert d.set_window_size_status(4096) == 0 and d.window_size == 4096
+    assert d.set_window_size_status(1000) == 1 and d.window_size == 4096
+    assert d.set_window_size_status(0) == 1 and d.set_window_size_status(1 << 20) == 1
+    assert lb.lib().LBAudioDetectiveDispose(None) == 1      # LBAudioDetective.m:93-95
+    d.dispose()
+
+
+def test_subfingerprint_count(lb):
+    d = lb.Detective().configure(sample_rate=44100, window=1024)
+    assert d.subfingerprint_count(44100) == 5
+    assert d.subfingerprint_count(1000) == 0                # shorter than a window
+    assert d.subfingerprint_count(1024 + 128 * 64) == 1
+
+
+def test_fingerprint_container(lb):
+    """Container semantics of LBAudioDetectiveFingerprint.m:18-117 (host memory only)."""
+    rng = np.random.default_rng(3)
+    fp = lb.Fingerprint(0)
+    assert fp.subfingerprint_length == 0 and fp.number_of_subfingerprints == 0
+    assert fp.set_subfingerprint_length(200) == (True, 200)
+    rows = rng.integers(0, 2, (3, 200)).astype(np.uint8)
+    for r in rows:
+        fp.add_subfingerprint(r)
+    assert fp.number_of_subfingerprints == 3
+    assert fp.set_subfingerprint_length(100) == (False, 200)    # frozen once non-empty (Fp.m:81-89)
+    assert np.array_equal(fp.to_bools(), rows)
+    cp = fp.copy()                                              # upstream testFingerprintComparison
+    assert fp.equal_to_fingerprint(cp) and cp.equal_to_fingerprint(fp)
+    cp.add_subfingerprint(rows[0])
+    assert not fp.equal_to_fingerprint(cp)
+    assert fp.to_string().count("+") == 2 and len(fp.to_string()) == 3 * 200 + 2
+    lb.lib().LBAudioDetectiveFingerprintDispose(None)           # NULL tolerated (Fp.m:29-31)
+
+
+def test_frame_container(lb):
+    """LBAudioDetectiveFrame.m:22-105,155-161,193-210."""
+    fr = lb.Frame(3)
+    assert not fr.full() and fr.number_of_rows == 0
+    assert fr.set_row([1, 2, 3, 4], 0) and fr.set_row([5, 6, 7, 8, 9], 1) and fr.set_row([9, 8, 7, 6], 2)
+    assert fr.full() and not fr.set_row([0, 0, 0, 0], 2)
+    assert fr.number_of_rows == 3 and fr.fingerprint_length() == 3 * 4 * 2 and fr.fingerprint_size() == 24
+    assert fr.get_value(1, 2) == 7.0
+    assert np.array_equal(fr.get_row(2, 4), np.array([9, 8, 7, 6], np.float32))
+    cp = fr.copy()
+    assert fr.equal_to_frame(cp)
+    other = lb.Frame(3)
+    for i, r in enumerate([[1, 2, 3, 4], [5, 6, 7, 8], [9, 8, 7, 5]]):
+        other.set_row(r, i)
+    assert not fr.equal_to_frame(other)
+    lb.lib().LBAudioDetectiveFrameDispose(None)
+
+
+def test_pack_unpack_roundtrip(lb):
+    rng = np.random.default_rng(0)
+    for L in (1, 2, 31, 32, 33, 199, 200, 255, 256):
+        b = rng.integers(0, 2, L).astype(np.uint8)
+        w = lb.pack_subfingerprint(b)
+        assert np.array_equal(lb.unpack_subfingerprint(w, L), b)
+        assert np.array_equal(lb.unpack_packed(w[None, :], L)[0], b)
+        assert int(sum(bin(int(x)).count("1") for x in w)) == int(b.sum())
+
+
+def test_decode_key(lb):
+    import struct
+    bits = struct.unpack("<I", struct.pack("<f", 0.75))[0]
+    assert lb.Corpus.decode_key((bits << 32) | (0xFFFFFFFF - 123)) == (123, 0.75)
+    assert lb.Corpus.decode_key(0xFFFFFFFF - 5) == (-1, 0.0)     # best score 0 selects nothing (Tests.m:80)
+    assert lb.Corpus.decode_key(0) == (-1, 0.0)
+    from lbaudiodetective_amd import sharded
+    assert sharded.decode_key(sharded.make_key(bits, 123)) == (123, 0.75)
+
+
+def test_empty_fingerprint_compare_is_zero(lb):
+    a, b = lb.Fingerprint(200), lb.Fingerprint(200)
+    b.add_subfingerprint(np.ones(200, np.uint8))
+    assert a.compare_to_fingerprint(b, 200) == 0.0
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU behaviour")
+def test_compute_calls_fail_loudly_without_gpu(lb):
+    """No CPU fallback: every compute entry point reports kLBAudioDetectiveDeviceUnavailable."""
+    nogp = lb.constant("kLBAudioDetectiveDeviceUnavailable")
+    d = lb.Detective().configure(sample_rate=44100, window=1024)
+    with pytest.raises(lb.LBAudioDetectiveError) as e:
+        d.process_pcm(np.zeros(44100, np.float32))
+    assert e.value.status == nogp
+    with pytest.raises(lb.LBAudioDetectiveError):
+        d.fingerprint_clips(np.zeros((2, 44100), np.float32))
+    a = lb.Fingerprint.from_bools(np.ones((1, 200), np.uint8))
+    assert np.isnan(a.compare_to_fingerprint(a, 200))
+    with pytest.raises(lb.LBAudioDetectiveError):
+        lb.Corpus(200, 5, 10)
+    assert lb.lib().LBAudioDetectiveDeviceCount() == 0
+
+
+def test_missing_library_raises(lb, monkeypatch, tmp_path):
+    from lbaudiodetective_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", str(tmp_path / "absent.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_unsupported_and_missing_files(lb, tmp_path):
+    d = lb.Detective()
+    out = lb._native.Ref()
+    assert lb.lib().LBAudioDetectiveProcessAudioURL(d._ref, None, C.byref(out)) == 1     # nil URL (D.m:211-214)
+    assert lb.lib().LBAudioDetectiveProcessAudioURL(d._ref, str(tmp_path / "nope.caf").encode(), C.byref(out)) == -43
+    p = tmp_path / "junk.caf"
+    p.write_bytes(b"not audio at all")
+    assert lb.lib().LBAudioDetectiveProcessAudioURL(d._ref, str(p).encode(), C.byref(out)) == \
+        lb.constant("kLBAudioDetectiveUnsupportedFile")

@@ -1,0 +1,391 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bit-exact everywhere: sub-fingerprint Booleans, frame rows and Haar coefficients (float32,
++0 == -0), compare scores (float32 bit patterns), best-match indices.  No tolerance is used.
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SEED = 0x4C424144
+CSEED = 0x4C424145
+
+
+def _bits(lb, packed, length):
+    p = packed.cpu().numpy()
+    return lb.unpack_packed(p, length).reshape(p.shape[0], p.shape[1], length)
+
+
+def _fingerprint_device(lb, gpu, pcm, cfg, variant=0, taps=False):
+    det = lb.Detective().configure(sample_rate=cfg.sample_rate, window=cfg.window, stride=cfg.stride,
+                                   bands=cfg.bands, subfp_len=cfg.subfp_len)
+    det.set_kernel_variant(variant)
+    clips = gpu.from_numpy(np.ascontiguousarray(pcm, np.float32)).cuda()
+    out = det.fingerprint_clips_device(clips, taps=taps)
+    gpu.cuda.synchronize()
+    if taps:
+        return _bits(lb, out[0], cfg.subfp_len), out[1].cpu().numpy(), out[2].cpu().numpy()
+    return _bits(lb, out, cfg.subfp_len)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic generators
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rate,n,stereo", [(44100, 44100, False), (48000, 48000, True), (5512, 9000, False)])
+def test_device_pcm_generator_matches_oracle(lb, gpu, oracle, rate, n, stereo):
+    dev = lb.synth_clips_device(SEED, 5, 3, rate, n, stereo).cpu().numpy()
+    host = oracle.synth_clips(SEED, 5, 3, rate, n, stereo)
+    assert np.array_equal(dev, host)
+
+
+def test_device_corpus_generator_matches_oracle(lb, gpu, oracle):
+    for n_sub, L in [(5, 200), (3, 33), (1, 256)]:
+        dev = _bits(lb, lb.synth_corpus_device(CSEED, 10, 50, n_sub, L), L)
+        assert np.array_equal(dev, oracle.synth_corpus(CSEED, 10, 50, n_sub, L))
+
+
+# ---------------------------------------------------------------------------------------------
+# fingerprint leg, stage by stage (unfused kernels expose the frame before / after the Haar)
+# ---------------------------------------------------------------------------------------------
+CONFIGS = {
+    "B_44k_1024": dict(sample_rate=44100, window=1024),                 # BASELINE configs 2-4
+    "A_default": dict(),                                                # BASELINE config 1
+    "C_48k_4096": dict(sample_rate=48000, window=4096),                 # BASELINE config 5
+    "small_odd": dict(sample_rate=8000, window=64, stride=16, bands=7, subfp_len=33),
+    "wide": dict(sample_rate=16000, window=256, stride=100, bands=64, subfp_len=256),
+    "tiny_bands": dict(sample_rate=11025, window=512, stride=64, bands=2, subfp_len=20),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_stages_bit_exact(lb, gpu, oracle, name):
+    cfg = oracle.Config(**CONFIGS[name])
+    n = cfg.window + cfg.stride * (128 * 2 + 17)          # two full frames and a ragged tail
+    rate = int(cfg.sample_rate)
+    pcm = oracle.synth_clips(SEED, 100, 3, rate, n, stereo_sum=(name == "C_48k_4096"))
+    bits, raw, haar = _fingerprint_device(lb, gpu, pcm, cfg, variant=1, taps=True)
+    for c in range(3):
+        obits, oraw, ohaar = oracle.fingerprint_pcm(pcm[c], cfg, taps=True)
+        assert oraw.shape == raw[c].shape == (2, 128, cfg.bands)
+        assert np.array_equal(raw[c], oraw), f"{name}: band energies differ (clip {c})"
+        assert np.array_equal(haar[c], ohaar), f"{name}: Haar coefficients differ (clip {c})"
+        assert np.array_equal(bits[c], obits), f"{name}: sub-fingerprint bits differ (clip {c})"
+
+
+def test_committed_vectors(lb, gpu, oracle):
+    g = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    cfg = oracle.Config(44100, 1024)
+    pcm = g["B_pcm_i16"].astype(np.float32) / np.float32(32768)
+    bits, raw, haar = _fingerprint_device(lb, gpu, pcm, cfg, variant=1, taps=True)
+    assert np.array_equal(bits, g["B_bits"])
+    assert np.array_equal(raw[0][0], g["B_raw_frame0"]) and np.array_equal(haar[0][0], g["B_haar_frame0"])
+    pcm = g["A_pcm_i16"].astype(np.float32) / np.float32(32768)
+    assert np.array_equal(_fingerprint_device(lb, gpu, pcm[None, :], oracle.Config())[0], g["A_bits"])
+    pcm = g["C_pcm_i32"].astype(np.float32) / np.float32(65536)
+    assert np.array_equal(_fingerprint_device(lb, gpu, pcm[None, :], oracle.Config(48000, 4096))[0], g["C_bits"])
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_batch_bits_bit_exact_44k(lb, gpu, oracle, variant):
+    """BASELINE config 2 shape at a size the oracle finishes in seconds."""
+    cfg = oracle.Config(44100, 1024)
+    pcm = oracle.synth_clips(SEED, 0, 64, 44100, 44100)
+    got = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant)
+    want = oracle.fingerprint_batch(pcm, cfg, nthreads=8)
+    assert got.shape == want.shape == (64, 5, 200)
+    assert np.array_equal(got, want)
+
+
+def test_edge_inputs(lb, gpu, oracle):
+    cfg = oracle.Config(44100, 1024)
+    n = 1024 + 64 * 128
+    rng = np.random.default_rng(1)
+    cases = {
+        "silence": np.zeros(n, np.float32),                                   # every key ties at 0
+        "dc": np.full(n, 0.5, np.float32),
+        "impulse": np.eye(1, n, 4000, dtype=np.float32)[0],
+        "full_scale_square": np.where((np.arange(n) // 50) % 2 == 0, 1.0, -1.0).astype(np.float32),
+        "tiny": (rng.standard_normal(n) * 1e-30).astype(np.float32),          # denormal-range energies
+        "huge": (rng.standard_normal(n) * 1e18).astype(np.float32),           # energies overflow to inf
+        "sine": np.sin(2 * np.pi * 440 * np.arange(n) / 44100).astype(np.float32),
+    }
+    pcm = np.stack(list(cases.values()))
+    for variant in (0, 1):
+        got = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant)
+        for i, name in enumerate(cases):
+            assert np.array_equal(got[i], oracle.fingerprint_pcm(pcm[i], cfg)), f"{name} (variant {variant})"
+    assert not got[0].any()                                                   # silence -> all "00" pairs
+
+
+def test_short_and_ragged_lengths(lb, gpu, oracle):
+    cfg = oracle.Config(44100, 1024)
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    for n in (0, 500, 1024, 1024 + 64 * 128 - 1, 1024 + 64 * 128, 30000):
+        pcm = oracle.synth_clip(SEED, n, 44100, max(n, 1))[:n]
+        fp = det.process_pcm(pcm)
+        want = oracle.fingerprint_pcm(pcm, cfg)
+        assert fp.number_of_subfingerprints == want.shape[0]
+        if want.shape[0]:
+            assert fp.subfingerprint_length == 200 and np.array_equal(fp.to_bools(), want)
+        else:
+            assert fp.subfingerprint_length == 0      # New(0), never given a length (D.m:297,326)
+
+
+def test_fingerprint_versatility(lb, gpu, oracle):
+    """Upstream testFingerprintVersatility (LBAudioDetectiveTests.m:119-139): two independent
+    detectives, ten times, identical fingerprints."""
+    pcm = oracle.synth_clip(SEED, 42, 5512, 5512 * 4)
+    first = lb.Detective()
+    for _ in range(10):
+        fp1 = first.process_pcm(pcm)
+        other = lb.Detective()
+        fp2 = other.process_pcm(pcm)
+        assert fp1.equal_to_fingerprint(fp2)
+        other.dispose()
+    copy = fp1.copy()                                    # upstream testFingerprintComparison
+    assert fp1.equal_to_fingerprint(copy)
+    assert fp1.compare_to_fingerprint(copy, fp1.subfingerprint_length) == 1.0
+
+
+def test_invalid_configurations_are_rejected(lb, gpu):
+    d = lb.Detective().configure(sample_rate=44100, window=1024)
+    pcm = np.zeros(44100, np.float32)
+    for kw in (dict(stride=0), dict(bands=0), dict(bands=65), dict(subfp_len=0), dict(subfp_len=257),
+               dict(sample_rate=0)):
+        e = lb.Detective().configure(sample_rate=44100, window=1024).configure(**kw)
+        with pytest.raises(lb.LBAudioDetectiveError) as err:
+            e.process_pcm(pcm)
+        assert err.value.status == 1
+    d.configure(bands=1, subfp_len=200)                  # asks for more wavelets than 128 x 1 coefficients
+    with pytest.raises(lb.LBAudioDetectiveError):
+        d.process_pcm(pcm)
+
+
+# ---------------------------------------------------------------------------------------------
+# frame API (Haar known answer through the upstream-shaped interface)
+# ---------------------------------------------------------------------------------------------
+def test_haar_wavelet_decomposition(lb, gpu, oracle):
+    """Upstream testHaarWaveletDecomposition (LBAudioDetectiveTests.m:157-176) + essay Fig. 13."""
+    import json
+    g = json.load(open(os.path.join(GOLD, "haar_known_answer.json")))
+    frame = lb.Frame(3)
+    for i, row in enumerate(g["input"]):
+        frame.set_row(row, i)
+    frame.decompose()
+    got = np.array([[frame.get_value(r, c) for c in range(4)] for r in range(3)], np.float32)
+    assert np.array_equal(np.rint(got).astype(int), np.array(g["expected_integers"]))
+    assert np.array_equal(got, oracle.haar_2d(np.array(g["input"], np.float32)))
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 4), (5, 7), (128, 32), (128, 33), (64, 100)])
+def test_frame_decompose_and_extract(lb, gpu, oracle, rows, cols):
+    rng = np.random.default_rng(rows * 1000 + cols)
+    m = (rng.standard_normal((rows, cols)) * 100).astype(np.float32)
+    m[rng.random(m.shape) < 0.2] = 0
+    if rows * cols > 4:
+        m.flat[3] = m.flat[1]                             # tie between two positions
+    frame = lb.Frame(rows)
+    for r in range(rows):
+        frame.set_row(m[r], r)
+    frame.decompose()
+    got = np.stack([frame.get_row(r, cols) for r in range(rows)])
+    want = oracle.haar_2d(m)
+    assert np.array_equal(got, want)
+    nw = min(200, rows * cols)
+    assert np.array_equal(frame.extract_fingerprint(nw), oracle.extract(want, nw))
+
+
+# ---------------------------------------------------------------------------------------------
+# compare leg
+# ---------------------------------------------------------------------------------------------
+def test_compare_committed_cases(lb, gpu):
+    g = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    pa = pb = 0
+    for (n1, n2, rg), bits in zip(g["cmp_cases"], g["cmp_expected_bits"]):
+        a = g["cmp_a"][pa:pa + n1 * 200].reshape(n1, 200); pa += n1 * 200
+        b = g["cmp_b"][pb:pb + n2 * 200].reshape(n2, 200); pb += n2 * 200
+        got = lb.Fingerprint.from_bools(a).compare_to_fingerprint(lb.Fingerprint.from_bools(b), int(rg))
+        assert struct.unpack("<I", struct.pack("<f", got))[0] == bits, (n1, n2, rg)
+
+
+@pytest.mark.parametrize("L", [200, 33, 256, 2, 1])
+def test_compare_random_lengths_and_ranges(lb, gpu, oracle, L):
+    rng = np.random.default_rng(L)
+    for n1, n2 in [(1, 1), (4, 4), (6, 2), (2, 6)]:
+        a = oracle.synth_corpus(L, 0, 1, n1, L)[0]
+        b = oracle.synth_corpus(L, 1, 1, n2, L)[0]
+        b[: min(n1, n2), : L // 2] = a[: min(n1, n2), : L // 2]
+        fa, fb = lb.Fingerprint.from_bools(a), lb.Fingerprint.from_bools(b)
+        for rg in sorted({1, 2, L // 2, L - 1, L, L + 7} - {0}):
+            want = np.float32(oracle.compare_fp(a, b, rg))
+            got = np.float32(fa.compare_to_fingerprint(fb, rg))
+            assert got.view(np.uint32) == want.view(np.uint32), (L, n1, n2, rg)
+        sa, sb = a[0], b[0]
+        assert np.float32(fa.compare_subfingerprints(sa, sb, L)).view(np.uint32) == \
+            np.float32(oracle.compare_sub(sa, sb, L)).view(np.uint32)
+
+
+def test_compare_pcm_end_to_end(lb, gpu, oracle):
+    """LBAudioDetectiveCompareAudioURLs' body (D.m:442-464) on PCM: a 4 s crop against its 9 s
+    original at the default settings, like upstream Test 1."""
+    cfg = oracle.Config()
+    orig = oracle.synth_clip(SEED, 1, 5512, 5512 * 9)
+    crop = orig[5512 * 2: 5512 * 6].copy()
+    other = oracle.synth_clip(SEED, 2, 5512, 5512 * 4)
+    det = lb.Detective()
+    f_orig, f_crop, f_other = (oracle.fingerprint_pcm(x, cfg) for x in (orig, crop, other))
+    for a, b, fa, fb in [(orig, crop, f_orig, f_crop), (crop, orig, f_crop, f_orig), (orig, other, f_orig, f_other)]:
+        got = np.float32(det.compare_pcm(a, b, 0))                  # range 0 -> subfingerprint length
+        want = np.float32(oracle.compare_fp(fa, fb, 200))
+        assert got.view(np.uint32) == want.view(np.uint32)
+        assert abs(float(got) - float(want)) <= 1e-5                # the north star's stated tolerance
+
+
+def test_file_entry_points(lb, gpu, oracle, tmp_path):
+    """ProcessAudioURL / CompareAudioURLs on float32 LPCM CAF and int16 WAV written here."""
+    rate = 5512
+    a = oracle.synth_clip(SEED, 3, rate, rate * 5)
+    b = a[rate: rate * 4].copy()
+
+    def caf(path, x):
+        desc = struct.pack(">d4sIIIII", float(rate), b"lpcm", 1, 4, 1, 1, 32)      # big-endian float32
+        data = struct.pack(">I", 0) + x.astype(">f4").tobytes()
+        with open(path, "wb") as f:
+            f.write(b"caff" + struct.pack(">HH", 1, 0))
+            f.write(b"desc" + struct.pack(">q", len(desc)) + desc)
+            f.write(b"data" + struct.pack(">q", len(data)) + data)
+
+    def wav(path, x):
+        pcm = np.round(x * 32768).astype("<i2").tobytes()
+        fmt = struct.pack("<HHIIHH", 1, 1, rate, rate * 2, 2, 16)
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE")
+            f.write(b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+    pa, pb = str(tmp_path / "a.caf"), str(tmp_path / "b.wav")
+    caf(pa, a)
+    wav(pb, b)
+    det = lb.Detective()
+    cfg = oracle.Config()
+    assert np.array_equal(det.process_audio_url(pa).to_bools(), oracle.fingerprint_pcm(a, cfg))
+    want = np.float32(oracle.compare_fp(oracle.fingerprint_pcm(a, cfg), oracle.fingerprint_pcm(b, cfg), 200))
+    assert np.float32(det.compare_audio_urls(pa, pb, 0)).view(np.uint32) == want.view(np.uint32)
+    det.processing_sample_rate = 44100                    # file is 5512 Hz: no resampler yet
+    with pytest.raises(lb.LBAudioDetectiveError) as e:
+        det.process_audio_url(pa)
+    assert e.value.status == lb.constant("kLBAudioDetectiveUnsupportedFile")
+
+
+# ---------------------------------------------------------------------------------------------
+# corpus
+# ---------------------------------------------------------------------------------------------
+def _planted_query(oracle, corpus_entry, flip_pct, seed=9):
+    q = corpus_entry.copy()
+    rng = np.random.default_rng(seed)
+    flip = rng.random((q.shape[0], q.shape[1] // 2)) < flip_pct
+    pos, neg = q[:, 0::2].copy(), q[:, 1::2].copy()
+    q[:, 0::2] = np.where(flip, neg, pos)
+    q[:, 1::2] = np.where(flip, pos, neg)
+    return q
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+def test_corpus_top1_and_scores(lb, gpu, oracle, variant):
+    n = 20000
+    packed = lb.synth_corpus_device(CSEED, 0, n, 5, 200)
+    host = oracle.synth_corpus(CSEED, 0, n, 5, 200)
+    corpus = lb.Corpus(200, 5, n)
+    corpus.append_packed_device(packed[:7000])
+    corpus.append_packed_device(packed[7000:])             # appends land at the right offset
+    assert len(corpus) == n and corpus.entry_stride_bytes == 128
+    corpus.set_kernel_variant(variant)
+    q = _planted_query(oracle, host[12345], 0.07)
+    fq = lb.Fingerprint.from_bools(q)
+    for rg in (0, 200, 64, 7):
+        idx, score = corpus.query(fq, rg)
+        oi, osc = oracle.corpus_best(q, host, rg if rg else 200, nthreads=8)
+        assert (idx, np.float32(score).view(np.uint32)) == (oi, np.float32(osc).view(np.uint32)), rg
+    assert idx == 12345 or rg < 200
+    scores = corpus.scores_device(fq, 200).cpu().numpy()
+    want = np.array([oracle.compare_fp(q, host[e], 200) for e in range(0, n, 37)], np.float32)
+    assert np.array_equal(scores[::37].view(np.uint32), want.view(np.uint32))
+
+
+def test_corpus_ties_and_zero(lb, gpu, oracle):
+    n = 3000
+    host = oracle.synth_corpus(CSEED, 0, n, 5, 200)
+    host[2500] = host[700]                                 # duplicate: the lower index must win
+    corpus = lb.Corpus(200, 5, n)
+    words = np.stack([[lb.pack_subfingerprint(s) for s in e] for e in host])      # host-side packing
+    corpus.append_packed_device(gpu.from_numpy(words.view(np.uint8).reshape(n, 5, 32)).cuda())
+    for variant in (1, 2):
+        corpus.set_kernel_variant(variant)
+        assert corpus.query(lb.Fingerprint.from_bools(host[700])) == (700, 1.0)
+        zero = lb.Fingerprint.from_bools(np.zeros((5, 200), np.uint8))
+        assert corpus.query(zero) == (-1, 0.0)             # strict '<' from 0 (Tests.m:80)
+
+
+@pytest.mark.parametrize("n_sub,L,n_query", [(5, 200, 3), (3, 200, 7), (4, 33, 4), (9, 200, 9), (2, 256, 2), (6, 64, 1)])
+def test_corpus_generic_shapes_and_sliding(lb, gpu, oracle, n_sub, L, n_query):
+    n = 1500
+    packed = lb.synth_corpus_device(CSEED + 1, 0, n, n_sub, L)
+    host = oracle.synth_corpus(CSEED + 1, 0, n, n_sub, L)
+    corpus = lb.Corpus(L, n_sub, n)
+    corpus.append_packed_device(packed)
+    base = np.concatenate([host[321], host[322]])[:n_query] if n_query > n_sub else host[321][:n_query]
+    q = _planted_query(oracle, base, 0.1)
+    fq = lb.Fingerprint.from_bools(q)
+    for rg in (0, max(1, L // 3)):
+        got = corpus.query(fq, rg)
+        want = oracle.corpus_best(q, host, rg if rg else L, nthreads=8)
+        assert (got[0], np.float32(got[1]).view(np.uint32)) == (want[0], np.float32(want[1]).view(np.uint32))
+    scores = corpus.scores_device(fq, L).cpu().numpy()
+    want = np.array([oracle.compare_fp(q, host[e], L) for e in range(0, n, 11)], np.float32)
+    assert np.array_equal(scores[::11].view(np.uint32), want.view(np.uint32))
+
+
+def test_corpus_from_fingerprints_and_pipeline(lb, gpu, oracle):
+    """Fingerprint clips on the device, build the corpus from the packed output without leaving
+    HBM, query with a host fingerprint: the whole hot path end to end."""
+    cfg = oracle.Config(44100, 1024)
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    clips = lb.synth_clips_device(SEED, 0, 48, 44100, 44100)
+    packed = det.fingerprint_clips_device(clips)
+    corpus = lb.Corpus(200, 5, 64)
+    corpus.append_packed_device(packed)
+    extra = det.process_pcm(oracle.synth_clip(SEED, 1000, 44100, 44100))
+    corpus.append_fingerprint(extra)
+    assert len(corpus) == 49
+    host = oracle.fingerprint_batch(oracle.synth_clips(SEED, 0, 48, 44100, 44100), cfg, nthreads=8)
+    host = np.concatenate([host, extra.to_bools()[None]])
+    for probe in (17, 48):
+        got = corpus.query(lb.Fingerprint.from_bools(host[probe]))
+        assert got == oracle.corpus_best(host[probe], host, 200) and got == (probe, 1.0)
+
+
+def test_sharded_on_one_device(lb, gpu, oracle):
+    """BASELINE config 4 shape on one GPU: N contiguous shards scanned one after another, keys
+    combined with max -- exactly what the all-reduce does across ranks."""
+    from lbaudiodetective_amd import sharded
+    n, world = 40000, 8
+    host_q = _planted_query(oracle, oracle.synth_entry(CSEED, 33333, 5, 200), 0.07)
+    fq = lb.Fingerprint.from_bools(host_q)
+    keys = []
+    for r in range(world):
+        sc = lb.ShardedCorpus(200, 5, n, rank=r, world_size=world)
+        sc.append_packed_device(lb.synth_corpus_device(CSEED, sc.begin, sc.end - sc.begin, 5, 200))
+        key = gpu.zeros(1, dtype=gpu.int64, device="cuda")
+        sc.local.query_key_device(fq, key, 0, index_base=sc.begin)
+        keys.append(int(key.item()))
+    got = sharded.decode_key(max(keys))
+    whole = lb.Corpus(200, 5, n)
+    whole.append_packed_device(lb.synth_corpus_device(CSEED, 0, n, 5, 200))
+    assert got == whole.query(fq) and got[0] == 33333
+    sc = lb.ShardedCorpus(200, 5, n)                        # world size 1: query() without a process group
+    sc.append_packed_device(lb.synth_corpus_device(CSEED, 0, n, 5, 200))
+    assert sc.query(fq) == got

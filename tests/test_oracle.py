@@ -1,0 +1,232 @@
+"""CPU tests of the parity oracle: pin it to the reference's known answers and to an
+independent restatement, so the GPU parity tests compare against something trustworthy."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_haar_known_answer(oracle):
+    """Upstream testHaarWaveletDecomposition (LBAudioDetectiveTests.m:157-176) + essay Fig. 13."""
+    g = json.load(open(os.path.join(GOLD, "haar_known_answer.json")))
+    got = oracle.haar_2d(np.array(g["input"], np.float32))
+    assert np.array_equal(np.rint(got).astype(int), np.array(g["expected_integers"]))
+    assert np.allclose(got, np.array(g["expected_float32"], np.float32), rtol=0, atol=6e-5)
+
+
+def test_haar_1d_non_power_of_two(oracle):
+    # length 3: pre-scale all, butterfly only the first pair (integer halving, Frame.m:143-152)
+    a = np.array([3.0, 5.0, 7.0], np.float32)
+    got = oracle.haar_1d(a)
+    r3, r2 = np.sqrt(np.float32(3)), np.sqrt(np.float32(2))
+    s = a / r3
+    want = np.array([(s[0] + s[1]) / r2, (s[0] - s[1]) / r2, s[2]], np.float32)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["A", "B", "C"])
+def test_band_tables_match_survey(oracle, name):
+    g = json.load(open(os.path.join(GOLD, "band_tables.json")))[name]
+    idx, lo, hi = oracle.band_table(g["sample_rate"], g["window"])
+    assert list(idx) == g["indices"]
+    if "ranges" in g:
+        assert [[int(a), int(b)] for a, b in zip(lo, hi)] == g["ranges"]
+    else:
+        assert list(lo) == g["lo"] and list(hi) == g["hi"]
+    if "divisors" in g:
+        assert list(np.diff(idx.astype(np.int64))) == g["divisors"]
+
+
+def test_band_quirks_at_44k(oracle):
+    """at 44.1 kHz / 1024 only bins 0..21 are read and 17 bands are empty."""
+    _, lo, hi = oracle.band_table(44100, 1024)
+    assert int(hi.max()) == 22 and int(lo.min()) == 0
+    assert int((lo == hi).sum()) == 17
+    x = np.zeros(1024, np.float32)
+    x[0] = 1.0  # impulse: flat spectrum, 2*DFT = 2 everywhere
+    row = oracle.window_row(x, oracle.Config(44100, 1024))
+    assert np.count_nonzero(row) == 15
+
+
+def _rfft_packed_f64(x):
+    ref = np.fft.rfft(x.astype(np.float64)) * 2
+    out = np.empty(x.size)
+    out[0], out[1] = ref[0].real, ref[-1].real
+    out[2::2], out[3::2] = ref[1:-1].real, ref[1:-1].imag
+    return out
+
+
+@pytest.mark.parametrize("W", [8, 16, 64, 512, 1024, 2048, 4096, 8192])
+def test_fft_against_float64(oracle, W):
+    rng = np.random.default_rng(W)
+    x = (rng.integers(-32768, 32768, W) / 32768).astype(np.float32)
+    got = oracle.rfft_packed(x).astype(np.float64)
+    want = _rfft_packed_f64(x)
+    # float32 radix-2 error grows ~ log2(W) * eps * |X|
+    assert np.abs(got - want).max() <= 4e-7 * np.log2(W) * np.abs(want).max()
+
+
+def test_fft_packing_dc_and_nyquist(oracle):
+    W = 64
+    x = np.ones(W, np.float32)
+    y = oracle.rfft_packed(x)
+    assert y[0] == 2 * W and y[1] == 0 and not y[2:].any()
+    x = np.where(np.arange(W) % 2 == 0, 1, -1).astype(np.float32)
+    y = oracle.rfft_packed(x)
+    assert y[0] == 0 and y[1] == 2 * W and not y[2:].any()
+
+
+def test_twiddle_symmetry(oracle):
+    re, im = oracle.twiddles(1024)
+    assert re[0] == 1 and im[0] == 0 and re[256] == 0 and im[256] == -1
+    assert re[128] == -im[128]
+    assert np.array_equal(re[1:256], -re[512 - 1:256:-1])
+    assert np.array_equal(re[1:128], -im[255:128:-1])
+
+
+def _bands_numpy(spec, idx, lo, hi, n_frames):
+    """Independent float32 restatement of LBAudioDetective.m:373-405."""
+    norm = np.float32((n_frames // 2) // 2)
+    out = np.zeros(len(lo), np.float32)
+    for i in range(len(lo)):
+        p = np.float32(0)
+        for k in range(int(lo[i]), int(hi[i])):
+            re, im = spec[2 * k], spec[2 * k + 1]
+            if re > 0:
+                re = np.float32(re / norm)
+            if im > 0:
+                im = np.float32(im / norm)
+            v = np.float32(np.float32(re * re) + np.float32(im * im))
+            if np.isfinite(v):
+                p = np.float32(p + v)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            out[i] = np.float32(p) / np.float32(int(idx[i + 1]) - int(idx[i]))
+    return out
+
+
+@pytest.mark.parametrize("rate,W", [(5512, 2048), (44100, 1024), (48000, 4096)])
+def test_band_energies_against_numpy(oracle, rate, W):
+    rng = np.random.default_rng(rate)
+    spec = (rng.standard_normal(W) * 50).astype(np.float32)
+    idx, lo, hi = oracle.band_table(rate, W)
+    assert np.array_equal(oracle.band_energies(spec, idx, lo, hi), _bands_numpy(spec, idx, lo, hi, W))
+
+
+def _extract_numpy(m, n_wavelets):
+    flat = m.reshape(-1)
+    order = np.argsort(-np.abs(flat.astype(np.float64)), kind="stable")  # ties: ascending index
+    out = np.zeros(2 * n_wavelets, np.uint8)
+    for i in range(min(n_wavelets, flat.size)):
+        v = flat[order[i]]
+        if v > 0:
+            out[2 * i] = 1
+        elif v < 0:
+            out[2 * i + 1] = 1
+    return out
+
+
+def test_extract_against_numpy_with_ties(oracle):
+    rng = np.random.default_rng(5)
+    m = rng.standard_normal((128, 32)).astype(np.float32)
+    m[rng.random(m.shape) < 0.3] = 0.0
+    m[5, 5] = m[9, 1] = 3.25       # equal magnitudes, different positions
+    m[7, 7] = -3.25
+    assert np.array_equal(oracle.extract(m, 200), _extract_numpy(m, 200))
+    assert np.array_equal(oracle.extract(np.zeros((128, 32), np.float32), 200), np.zeros(400, np.uint8))
+
+
+def _compare_sub_py(a, b, length, rng_):
+    poss = hits = 0
+    for i in range(0, min(rng_, length), 2):
+        a0, a1 = a[i], a[i + 1] if i + 1 < length else 0
+        if a0 or a1:
+            poss += 1
+            b0, b1 = b[i], b[i + 1] if i + 1 < length else 0
+            if a0 == b0 and a1 == b1:
+                hits += 1
+    return np.float32(0) if poss == 0 else np.float32(np.float32(hits) / np.float32(poss))
+
+
+def _compare_fp_py(f1, f2, rng_):
+    """Independent restatement of Fingerprint.m:119-149."""
+    if len(f1) < len(f2):
+        f1, f2 = f2, f1
+    n1, n2, L = len(f1), len(f2), f1.shape[1]
+    match = np.float32(0)
+    for off in range(n1 - n2 + 1):
+        s = np.float32(0)
+        for i in range(n2):
+            s = np.float32(s + _compare_sub_py(f1[i + off], f2[i], L, rng_))
+        cand = np.float32(s / np.float32(n2))
+        match = cand if match < cand else match
+    return match
+
+
+def test_compare_against_python(oracle):
+    g = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    pa = pb = 0
+    for (n1, n2, rg), bits in zip(g["cmp_cases"], g["cmp_expected_bits"]):
+        a = g["cmp_a"][pa:pa + n1 * 200].reshape(n1, 200); pa += n1 * 200
+        b = g["cmp_b"][pb:pb + n2 * 200].reshape(n2, 200); pb += n2 * 200
+        want = _compare_fp_py(a, b, int(rg))
+        got = np.float32(oracle.compare_fp(a, b, int(rg)))
+        assert got.view(np.uint32) == want.view(np.uint32) == bits, (n1, n2, rg)
+
+
+def test_compare_invariants(oracle):
+    """What the upstream tests rely on: a copy compares equal and scores 1.0
+    (LBAudioDetectiveTests.m:119-155); unrelated fingerprints sit near 0.5 (essay p.43)."""
+    a = oracle.synth_corpus(1, 0, 1, 5, 200)[0]
+    b = oracle.synth_corpus(1, 1, 1, 5, 200)[0]
+    assert oracle.compare_fp(a, a.copy(), 200) == 1.0
+    assert 0.4 < oracle.compare_fp(a, b, 200) < 0.6
+    zero = np.zeros_like(a)
+    assert oracle.compare_fp(zero, a, 200) == 0.0          # no possible hits -> 0 (Fp.m:171-173)
+    assert oracle.compare_fp(a[:0], a, 200, subfp_len=200) == 0.0   # empty side: NaN never wins Foundation's MAX
+
+
+def test_framing_counts(oracle):
+    # 1 s at 44.1 kHz / 1024 -> 673 windows -> 5 frames; 48 kHz / 4096 -> 686 -> 5
+    assert oracle.subfingerprint_count(44100, 1024, 64) == 5
+    assert oracle.subfingerprint_count(48000, 4096, 64) == 5
+    assert oracle.subfingerprint_count(1023, 1024, 64) == 0
+    assert oracle.subfingerprint_count(1024 + 128 * 64 - 1, 1024, 64) == 0
+    assert oracle.subfingerprint_count(1024 + 128 * 64, 1024, 64) == 1
+
+
+def test_oracle_matches_committed_vectors(oracle):
+    g = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    pcm = g["B_pcm_i16"].astype(np.float32) / np.float32(32768)
+    bits, raw, haar = oracle.fingerprint_pcm(pcm[0], oracle.Config(44100, 1024), taps=True)
+    assert np.array_equal(bits, g["B_bits"][0])
+    assert np.array_equal(raw[0], g["B_raw_frame0"]) and np.array_equal(haar[0], g["B_haar_frame0"])
+    pcm = g["A_pcm_i16"].astype(np.float32) / np.float32(32768)
+    assert np.array_equal(oracle.fingerprint_pcm(pcm, oracle.Config()), g["A_bits"])
+    pcm = g["C_pcm_i32"].astype(np.float32) / np.float32(65536)
+    assert np.array_equal(oracle.fingerprint_pcm(pcm, oracle.Config(48000, 4096)), g["C_bits"])
+
+
+def test_truncation_keeps_top_100_wavelets(oracle):
+    """Extract is asked for 200 wavelets but only 200 Booleans (= 100 pairs) survive."""
+    g = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    full = oracle.extract(g["B_haar_frame0"], 200)
+    assert np.array_equal(full[:200], g["B_bits"][0][0])
+    assert full[:200].reshape(100, 2).sum(axis=1).max() <= 1
+
+
+def test_synth_is_deterministic_and_int16(oracle):
+    a = oracle.synth_clip(0x4C424144, 3, 44100, 2000)
+    assert np.array_equal(a, oracle.synth_clip(0x4C424144, 3, 44100, 2000))
+    assert np.array_equal(a * 32768, np.rint(a * 32768)) and np.abs(a).max() <= 1
+    assert not np.array_equal(a, oracle.synth_clip(0x4C424144, 4, 44100, 2000))
+    g = np.load(os.path.join(GOLD, "oracle_vectors.npz"))
+    assert np.array_equal(np.round(oracle.synth_clip(0x4C424144, 0, 44100, 44100) * 32768).astype(np.int16), g["B_pcm_i16"][0])
+
+
+def test_batch_threads_agree(oracle):
+    pcm = oracle.synth_clips(9, 0, 6, 44100, 1024 + 128 * 64 * 2)
+    cfg = oracle.Config(44100, 1024)
+    assert np.array_equal(oracle.fingerprint_batch(pcm, cfg, 1), oracle.fingerprint_batch(pcm, cfg, 4))
