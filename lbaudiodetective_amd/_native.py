@@ -155,6 +155,14 @@ def lib():
             f"{LIB_PATH} is missing: the HIP library has not been built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C lbaudiodetective_amd/csrc). "
             "There is no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64 with the same SONAMEs as
+    # /opt/rocm's.  If ours were loaded first, torch would later bring a SECOND HIP runtime into the
+    # process and whichever initialises second finds no device.  Importing torch first makes our
+    # library bind to the runtime torch already loaded (one runtime, shared streams and pointers).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is missing
