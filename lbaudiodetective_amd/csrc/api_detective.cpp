@@ -19,6 +19,7 @@ static bool valid_window(uint32_t w) { return w >= kMinWindow && w <= kMaxWindow
 static void free_plan(Plan& p) {
     if (p.d_tw) (void)hipFree(p.d_tw);
     if (p.d_bands) (void)hipFree(p.d_bands);
+    if (p.d_bin_const) (void)hipFree(p.d_bin_const);
     p = Plan();
 }
 
@@ -61,6 +62,13 @@ OSStatus ensure_plan(LBAudioDetective* d) {
     }
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bands), tbl.size() * sizeof(uint32_t)));
     LBAD_HIP(hipMemcpy(p.d_bands, tbl.data(), tbl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    p.pruned_ok = rows_pruned_supported(p);
+    if (p.pruned_ok) {
+        std::vector<float> bc;
+        rows_pruned_constants(bc);
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bin_const), bc.size() * sizeof(float)));
+        LBAD_HIP(hipMemcpy(p.d_bin_const, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     p.valid = true;
     return noErr;
 }
@@ -84,21 +92,17 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
     const uint64_t per = subfingerprint_count(spc, p.window, p.stride);
     if (per == 0 || n_clips == 0) return noErr;
     if (per > 0xFFFFFFFFull / kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
-    const bool taps = d_raw || d_haar;
-    bool fused = false;
-    if (d->variant == 2) {
-        if (!fused_supported(p) || taps) return kLBAudioDetectiveArgumentInvalid;
-        fused = true;
-    } else if (d->variant == 0) {
-        fused = fused_supported(p) && !taps;
-    }
-    if (fused) {
-        LBAD_HIP(launch_fused(p, d_pcm, n_clips, spc, (uint32_t)per, d_packed, stream));
-        return noErr;
-    }
+    // variant 0: specialised kernels when the configuration has them; 1: generic kernels; 2: specialised or error
+    bool special = p.pruned_ok;
+    if (d->variant == 1) special = false;
+    if (d->variant == 2 && !special) return kLBAudioDetectiveArgumentInvalid;
+    auto stage1 = [&](const float* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
+        return special ? launch_rows_pruned(p, p.d_bin_const, pcm_in, nc, spc, (uint32_t)per, frames_out, stream)
+                       : launch_fft_bands(p, pcm_in, nc, spc, (uint32_t)per, frames_out, stream);
+    };
     const uint64_t frame_floats = (uint64_t)kRowsPerFrame * p.bands;
     if (d_raw) {  // the caller's tap buffer doubles as the inter-kernel scratch
-        LBAD_HIP(launch_fft_bands(p, d_pcm, n_clips, spc, (uint32_t)per, d_raw, stream));
+        LBAD_HIP(stage1(d_pcm, n_clips, d_raw));
         LBAD_HIP(launch_haar_select(p, d_raw, n_clips * per, d_packed, d_haar, stream));
         return noErr;
     }
@@ -110,7 +114,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
     if (st != noErr) return st;
     for (uint64_t c0 = 0; c0 < n_clips; c0 += chunk) {
         const uint64_t nc = (n_clips - c0) < chunk ? (n_clips - c0) : chunk;
-        LBAD_HIP(launch_fft_bands(p, d_pcm + c0 * spc, nc, spc, (uint32_t)per, d->d_frames, stream));
+        LBAD_HIP(stage1(d_pcm + c0 * spc, nc, d->d_frames));
         LBAD_HIP(launch_haar_select(p, d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
                                     d_haar ? d_haar + c0 * per * frame_floats : nullptr, stream));
     }

@@ -47,6 +47,8 @@ struct Plan {
     // device copies
     float* d_tw = nullptr;        // [W/2] re then [W/2] im
     uint32_t* d_bands = nullptr;  // [bands] lo, [bands] hi, then [bands] divisor as float bits
+    float* d_bin_const = nullptr; // per-bin twiddles of the pruned kernel (only when pruned_ok)
+    bool pruned_ok = false;
     bool valid = false;
 };
 
@@ -57,10 +59,12 @@ hipError_t launch_fft_bands(const Plan& plan, const float* d_pcm, uint64_t n_cli
 // frame rows -> packed sub-fingerprints.  d_haar (optional) receives the decomposed frames.
 hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_frames, uint32_t* d_packed,
                               float* d_haar_out, hipStream_t stream);
-// fused per-frame kernel; returns hipErrorNotSupported when the plan has no specialisation
-bool fused_supported(const Plan& plan);
-hipError_t launch_fused(const Plan& plan, const float* d_pcm, uint64_t n_clips, uint64_t samples_per_clip,
-                        uint32_t frames_per_clip, uint32_t* d_packed, hipStream_t stream);
+// specialised stage 1 (k_rows_pruned.hip): 1024-sample windows whose bands read only bins 0..21
+bool rows_pruned_supported(const Plan& plan);
+void rows_pruned_constants(std::vector<float>& out);
+hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const float* d_pcm, uint64_t n_clips,
+                              uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
+                              hipStream_t stream);
 
 // generic matrix ops behind the Frame API
 hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream);

@@ -1,0 +1,319 @@
+// k_rows_pruned.hip -- specialised stage 1 for 1024-sample windows whose bands read only the
+// lowest FFT bins (44.1 kHz / 1024: bins 0..21): windows -> 128 x 32 frame rows.
+//
+// Same arithmetic as k_fft_bands.hip / oracle rfft_exec (radix-2 DIT, nested-fma butterflies),
+// but only the butterflies the 22 consumed bins depend on are executed:
+//
+//   * 8 lanes own one window.  Lane r holds the 64 complex points z[r + 8m] and runs DIT stages
+//     1..5 (two 32-point blocks) entirely in registers with compile-time twiddles.
+//   * Stage 6 is pruned to the 43 outputs k64 in [0,21] u [43,63] that feed bins 0..21 and their
+//     mirror bins 491..511 (needed by the real-FFT split pass).
+//   * Stages 7..9 combine the 8 lanes.  Each needed bin is a 7-butterfly reduction tree over the
+//     8 lanes' values of one stage-6 output; the values cross lanes through a per-wave LDS
+//     transpose buffer and one lane evaluates both trees of a bin pair (k, 512-k), the split
+//     pass, the positive-only normalisation and the power term.
+//   * A workgroup owns one frame: the frame's PCM span (127 * 64 + 1024 samples) is read from
+//     HBM once into LDS, so the 16x window overlap costs no extra HBM traffic.
+//
+// Executed work per window: ~10.3 k float operations instead of 25.6 k for the full transform;
+// results are bit-identical because every surviving butterfly is evaluated exactly as in the
+// full network.
+#include "internal.hpp"
+#include "twiddle64.inc"
+
+namespace lbad {
+namespace {
+
+constexpr int kW = 1024;
+constexpr int kStride = 64;
+constexpr int kBands = 32;
+constexpr int kBins = 22;           // bins 0..21
+constexpr int kRows = 43;           // stage-6 outputs kept per lane
+constexpr int kRowDw = 20;          // dwords per transpose row: 8 lanes x 8 B, padded 64 -> 80 B
+constexpr int kWinDw = 880;         // 43 rows x 20 = 860, padded so that window stride = 16 (mod 32) banks
+constexpr int kSpan = 127 * kStride + kW;                 // 9152 samples per frame
+constexpr int kSpanDw = kSpan + 16 * (kSpan >> 6);        // 16-dword skew per 64 samples: 11440
+constexpr int kTDw = 4 * 8 * kWinDw;                      // 4 waves x 8 windows
+constexpr int kVDw = 4 * 8 * 24;                          // power terms, 22 (padded 24) per window
+constexpr int kLdsBytes = (kSpanDw + kTDw + kVDw) * 4;    // 161 472 B
+
+struct cplx {
+    float x, y;
+};
+
+__device__ __forceinline__ constexpr int brev6(int v) {
+    return ((v & 1) << 5) | ((v & 2) << 3) | ((v & 4) << 1) | ((v & 8) >> 1) | ((v & 16) >> 3) | ((v & 32) >> 5);
+}
+
+// full butterfly on registers, twiddle index t into the W_64 table (compile time)
+template <int T>
+__device__ __forceinline__ void bfly(cplx& u, cplx& v) {
+    if constexpr (T == 0) {
+        const cplx a = u, b = v;
+        u.x = a.x + b.x; u.y = a.y + b.y;
+        v.x = a.x - b.x; v.y = a.y - b.y;
+    } else if constexpr (T == 16) {  // w = -i
+        const cplx a = u, b = v;
+        u.x = a.x + b.y; u.y = a.y - b.x;
+        v.x = a.x - b.y; v.y = a.y + b.x;
+    } else {
+        constexpr float wr = kTw64Re[T], wi = kTw64Im[T];
+        const cplx a = u, b = v;
+        u.x = __fmaf_rn(wr, b.x, __fmaf_rn(-wi, b.y, a.x));
+        u.y = __fmaf_rn(wr, b.y, __fmaf_rn(wi, b.x, a.y));
+        v.x = __fmaf_rn(-wr, b.x, __fmaf_rn(wi, b.y, a.x));
+        v.y = __fmaf_rn(-wr, b.y, __fmaf_rn(-wi, b.x, a.y));
+    }
+}
+
+template <int S, int BASE, int J>
+__device__ __forceinline__ void stage_block_j(cplx (&x)[64]) {
+    constexpr int half = 1 << (S - 1);
+    if constexpr (J < half) {
+        bfly<J*(64 >> S)>(x[BASE + J], x[BASE + J + half]);
+        stage_block_j<S, BASE, J + 1>(x);
+    }
+}
+
+template <int S, int BASE>
+__device__ __forceinline__ void stage_blocks(cplx (&x)[64]) {
+    if constexpr (BASE < 64) {
+        stage_block_j<S, BASE, 0>(x);
+        stage_blocks<S, BASE + (1 << S)>(x);
+    }
+}
+
+// u + w v with a run-time twiddle (tree stages and the split pass use per-lane tables)
+__device__ __forceinline__ cplx madd(cplx u, float wr, float wi, cplx v) {
+    cplx o;
+    o.x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
+    o.y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
+    return o;
+}
+
+// stage-6 outputs: row i < 22 is k64 = i ("+" output of pair j = i); row i >= 22 is k64 = i + 21
+// ("-" output of pair j = i - 11)
+template <int I>
+__device__ __forceinline__ cplx stage6_row(const cplx (&x)[64]) {
+    constexpr int j = I < 22 ? I : I - 11;
+    constexpr bool plus = I < 22;
+    const cplx u = x[j], v = x[j + 32];
+    cplx o;
+    if constexpr (j == 0) {
+        o.x = u.x + v.x; o.y = u.y + v.y;   // only the "+" output of pair 0 is needed
+    } else if constexpr (j == 16) {
+        if constexpr (plus) { o.x = u.x + v.y; o.y = u.y - v.x; }
+        else { o.x = u.x - v.y; o.y = u.y + v.x; }
+    } else {
+        constexpr float wr = kTw64Re[j], wi = kTw64Im[j];
+        if constexpr (plus) {
+            o.x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
+            o.y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
+        } else {
+            o.x = __fmaf_rn(-wr, v.x, __fmaf_rn(wi, v.y, u.x));
+            o.y = __fmaf_rn(-wr, v.y, __fmaf_rn(-wi, v.x, u.y));
+        }
+    }
+    return o;
+}
+
+template <int I>
+__device__ __forceinline__ void store_rows(const cplx (&x)[64], float* trow) {
+    if constexpr (I < kRows) {
+        const cplx o = stage6_row<I>(x);
+        *reinterpret_cast<float2*>(trow + I * kRowDw) = make_float2(o.x, o.y);
+        store_rows<I + 1>(x, trow);
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void load_points(cplx (&x)[64], const float* src) {
+    if constexpr (M < 64) {
+        // sample 2r + 16 M of the window sits (M & 3) * 16 + (M >> 2) * 80 dwords after the lane base
+        const float2 v = *reinterpret_cast<const float2*>(src + (M & 3) * 16 + (M >> 2) * 80);
+        x[brev6(M)].x = v.x;
+        x[brev6(M)].y = v.y;
+        load_points<M + 1>(x, src);
+    }
+}
+
+// 7-butterfly reduction over the 8 lanes' values of one stage-6 row (DIT stages 7, 8, 9)
+__device__ __forceinline__ cplx tree(const float* row, const float* tw) {
+    const float4 q0 = *reinterpret_cast<const float4*>(row);
+    const float4 q1 = *reinterpret_cast<const float4*>(row + 4);
+    const float4 q2 = *reinterpret_cast<const float4*>(row + 8);
+    const float4 q3 = *reinterpret_cast<const float4*>(row + 12);
+    const cplx x0{q0.x, q0.y}, x1{q0.z, q0.w}, x2{q1.x, q1.y}, x3{q1.z, q1.w};
+    const cplx x4{q2.x, q2.y}, x5{q2.z, q2.w}, x6{q3.x, q3.y}, x7{q3.z, q3.w};
+    const cplx y0 = madd(x0, tw[0], tw[1], x4), y1 = madd(x1, tw[0], tw[1], x5);
+    const cplx y2 = madd(x2, tw[0], tw[1], x6), y3 = madd(x3, tw[0], tw[1], x7);
+    const cplx z0 = madd(y0, tw[2], tw[3], y2), z1 = madd(y1, tw[2], tw[3], y3);
+    return madd(z0, tw[4], tw[5], z1);
+}
+
+// per-bin constants: [0..5] twiddles of the "+" tree (stages 7, 8, 9), [6..11] of the mirror
+// tree, [12..13] split-pass twiddle W_1024^k
+constexpr int kBinConst = 14;
+
+__global__ __launch_bounds__(256, 1) void frame_rows_pruned_kernel(const float* __restrict__ pcm,
+                                                                    uint64_t samples_per_clip,
+                                                                    uint32_t frames_per_clip,
+                                                                    const float* __restrict__ bin_const,
+                                                                    const uint32_t* __restrict__ band_tbl,
+                                                                    float* __restrict__ frames, int aligned16) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* span = smem;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    float* tbuf = smem + kSpanDw + wave * (8 * kWinDw);
+    float* vbuf = smem + kSpanDw + kTDw + wave * (8 * 24);
+
+    const uint64_t frame = blockIdx.x;
+    const uint64_t clip = frame / frames_per_clip;
+    const uint32_t fi = (uint32_t)(frame % frames_per_clip);
+    const float* src = pcm + clip * samples_per_clip + (uint64_t)fi * (128 * kStride);
+
+    // ---- A: PCM span -> LDS (skewed by 16 dwords per 64 samples so that the 4 windows of a
+    //         32-lane group hit disjoint bank quarters in phase B1) ------------------------------
+    if (aligned16) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        for (int i = threadIdx.x; i < kSpan / 4; i += 256) {
+            const float4 v = s4[i];
+            const int s = 4 * i;
+            *reinterpret_cast<float4*>(span + s + 16 * (s >> 6)) = v;
+        }
+    } else {
+        for (int s = threadIdx.x; s < kSpan; s += 256) span[s + 16 * (s >> 6)] = src[s];
+    }
+
+    // ---- per-lane constants of phase B4/B5 ----------------------------------------------------
+    // bin tasks: t = lane + 64 * round over 8 windows x 22 bins
+    int task_w[3], task_k[3];
+    float tc[3][kBinConst];
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+        const int t = lane + 64 * rd;
+        const int tw_ = t < 8 * kBins ? t / kBins : 0;
+        const int tk = t < 8 * kBins ? t % kBins : -1;
+        task_w[rd] = tw_;
+        task_k[rd] = tk;
+#pragma unroll
+        for (int c = 0; c < kBinConst; ++c) tc[rd][c] = tk >= 0 ? bin_const[tk * kBinConst + c] : 0.0f;
+    }
+    const int band = lane & 31;
+    const uint32_t b_lo = band_tbl[band], b_hi = band_tbl[kBands + band];
+    const float b_div = __uint_as_float(band_tbl[2 * kBands + band]);
+    __syncthreads();
+
+    const int w8 = lane >> 3, r = lane & 7;
+    const float inv_norm = 1.0f / (float)(kW / 4);
+
+    for (int it = 0; it < 4; ++it) {
+        const int win = 32 * it + 8 * wave + w8;
+        // ---- B1 + B2: 64 points of this lane, DIT stages 1..5 in registers ----------------------
+        cplx x[64];
+        load_points<0>(x, span + 80 * win + 2 * r);
+        stage_blocks<1, 0>(x);
+        stage_blocks<2, 0>(x);
+        stage_blocks<3, 0>(x);
+        stage_blocks<4, 0>(x);
+        stage_blocks<5, 0>(x);
+        // ---- B3: pruned stage 6 straight into the transpose buffer -----------------------------
+        store_rows<0>(x, tbuf + w8 * kWinDw + 2 * r);
+
+        // ---- B4: bin tasks: two reduction trees, split pass, power term ------------------------
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+            const int k = task_k[rd];
+            if (k >= 0) {
+                const float* wbase = tbuf + task_w[rd] * kWinDw;
+                const cplx a = tree(wbase + k * kRowDw, &tc[rd][0]);
+                const cplx b = tree(wbase + (k ? 43 - k : 0) * kRowDw, &tc[rd][6]);
+                float re, im;
+                if (k == 0) {
+                    const float sm = a.x + a.y, df = a.x - a.y;
+                    re = sm + sm;
+                    im = df + df;
+                } else {
+                    const float sr = a.x + b.x, si = a.y - b.y;
+                    const float dr = a.x - b.x, di = a.y + b.y;
+                    const float wr = tc[rd][12], wi = tc[rd][13];
+                    re = __fmaf_rn(wr, di, __fmaf_rn(wi, dr, sr));
+                    im = __fmaf_rn(-wr, dr, __fmaf_rn(wi, di, si));
+                }
+                if (re > 0.0f) re = __fmul_rn(re, inv_norm);
+                if (im > 0.0f) im = __fmul_rn(im, inv_norm);
+                vbuf[task_w[rd] * 24 + k] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+            }
+        }
+
+        // ---- B5: band means, 8 windows x 32 bands per wave-iteration ----------------------------
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ww = 2 * q + (lane >> 5);
+            float p = 0.0f;
+            for (uint32_t k = b_lo; k < b_hi; ++k) {
+                const float v = vbuf[ww * 24 + k];
+                if (v == v && fabsf(v) != INFINITY) p = __fadd_rn(p, v);
+            }
+            const uint32_t row = 32 * it + 8 * wave + ww;
+            frames[(frame * 128 + row) * kBands + band] = __fdiv_rn(p, b_div);
+        }
+    }
+}
+
+}  // namespace
+
+bool rows_pruned_supported(const Plan& p) {
+    if (p.window != (uint32_t)kW || p.stride != (uint32_t)kStride || p.bands != (uint32_t)kBands) return false;
+    if (p.table.kmax > (uint32_t)kBins) return false;
+    // the compile-time W_64 table must be bit-identical to the run-time master table
+    std::vector<float> re, im;
+    make_twiddles(kW, re, im);
+    for (int t = 0; t < 32; ++t)
+        if (re[16 * t] != kTw64Re[t] || im[16 * t] != kTw64Im[t]) return false;
+    return true;
+}
+
+// per-bin twiddle block (see kBinConst)
+void rows_pruned_constants(std::vector<float>& out) {
+    std::vector<float> re, im;
+    make_twiddles(kW, re, im);
+    out.assign((size_t)kBins * kBinConst, 0.0f);
+    for (int k = 0; k < kBins; ++k) {
+        float* c = &out[(size_t)k * kBinConst];
+        // "+" tree of Z[k]: W_128^k, W_256^k, W_512^k
+        c[0] = re[8 * k]; c[1] = im[8 * k];
+        c[2] = re[4 * k]; c[3] = im[4 * k];
+        c[4] = re[2 * k]; c[5] = im[2 * k];
+        if (k > 0) {
+            // mirror tree of Z[512 - k]: exponents 128 - k, 256 - k, 512 - k all lie in the upper half of
+            // their stage, i.e. the "u - w v" output: w' = -W^(e - m/2)
+            c[6] = -re[8 * (64 - k)];   c[7] = -im[8 * (64 - k)];
+            c[8] = -re[4 * (128 - k)];  c[9] = -im[4 * (128 - k)];
+            c[10] = -re[2 * (256 - k)]; c[11] = -im[2 * (256 - k)];
+            c[12] = re[k]; c[13] = im[k];   // W_1024^k of the split pass
+        }
+    }
+}
+
+hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const float* d_pcm, uint64_t n_clips,
+                              uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
+                              hipStream_t stream) {
+    const uint64_t n_frames = n_clips * frames_per_clip;
+    if (n_frames == 0) return hipSuccess;
+    if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_rows_pruned_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int aligned16 = ((reinterpret_cast<uintptr_t>(d_pcm) & 15) == 0 && (samples_per_clip & 3) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(frame_rows_pruned_kernel, dim3((uint32_t)n_frames), dim3(256), kLdsBytes, stream, d_pcm,
+                       samples_per_clip, frames_per_clip, d_bin_const, plan.d_bands, d_frames, aligned16);
+    return hipGetLastError();
+}
+
+}  // namespace lbad

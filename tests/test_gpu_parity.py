@@ -68,14 +68,21 @@ def test_stages_bit_exact(lb, gpu, oracle, name):
     n = cfg.window + cfg.stride * (128 * 2 + 17)          # two full frames and a ragged tail
     rate = int(cfg.sample_rate)
     pcm = oracle.synth_clips(SEED, 100, 3, rate, n, stereo_sum=(name == "C_48k_4096"))
-    bits, raw, haar = _fingerprint_device(lb, gpu, pcm, cfg, variant=1, taps=True)
-    for c in range(3):
-        obits, oraw, ohaar = oracle.fingerprint_pcm(pcm[c], cfg, taps=True)
-        assert oraw.shape == raw[c].shape == (2, 128, cfg.bands)
-        # equal_nan: zero-width bands give 0/0 in the reference arithmetic ("wide" has some)
-        assert np.array_equal(raw[c], oraw, equal_nan=True), f"{name}: band energies differ (clip {c})"
-        assert np.array_equal(haar[c], ohaar, equal_nan=True), f"{name}: Haar coefficients differ (clip {c})"
-        assert np.array_equal(bits[c], obits), f"{name}: sub-fingerprint bits differ (clip {c})"
+    variants = (1, 2) if name == "B_44k_1024" else (1,)      # 2 = specialised kernels (config B has them)
+    for variant in variants:
+        bits, raw, haar = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant, taps=True)
+        for c in range(3):
+            obits, oraw, ohaar = oracle.fingerprint_pcm(pcm[c], cfg, taps=True)
+            assert oraw.shape == raw[c].shape == (2, 128, cfg.bands)
+            # equal_nan: zero-width bands give 0/0 in the reference arithmetic ("wide" has some)
+            assert np.array_equal(raw[c], oraw, equal_nan=True), f"{name}/v{variant}: band energies differ (clip {c})"
+            assert np.array_equal(haar[c], ohaar, equal_nan=True), f"{name}/v{variant}: Haar coefficients differ (clip {c})"
+            assert np.array_equal(bits[c], obits), f"{name}/v{variant}: sub-fingerprint bits differ (clip {c})"
+    if name != "B_44k_1024":
+        det = lb.Detective().configure(**CONFIGS[name])
+        det.set_kernel_variant(2)                            # no specialisation for this configuration
+        with pytest.raises(lb.LBAudioDetectiveError):
+            det.fingerprint_clips_device(gpu.zeros((1, n), dtype=gpu.float32, device="cuda"))
 
 
 def test_committed_vectors(lb, gpu, oracle):
@@ -91,7 +98,7 @@ def test_committed_vectors(lb, gpu, oracle):
     assert np.array_equal(_fingerprint_device(lb, gpu, pcm[None, :], oracle.Config(48000, 4096))[0], g["C_bits"])
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_batch_bits_bit_exact_44k(lb, gpu, oracle, variant):
     """BASELINE config 2 shape at a size the oracle finishes in seconds."""
     cfg = oracle.Config(44100, 1024)
@@ -116,7 +123,7 @@ def test_edge_inputs(lb, gpu, oracle):
         "sine": np.sin(2 * np.pi * 440 * np.arange(n) / 44100).astype(np.float32),
     }
     pcm = np.stack(list(cases.values()))
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         got = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant)
         for i, name in enumerate(cases):
             assert np.array_equal(got[i], oracle.fingerprint_pcm(pcm[i], cfg)), f"{name} (variant {variant})"
