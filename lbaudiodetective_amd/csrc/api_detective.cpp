@@ -100,10 +100,15 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
         return special ? launch_rows_pruned(p, p.d_bin_const, pcm_in, nc, spc, (uint32_t)per, frames_out, stream)
                        : launch_fft_bands(p, pcm_in, nc, spc, (uint32_t)per, frames_out, stream);
     };
+    const bool special2 = d->variant != 1 && haar_select32_supported(p);
+    auto stage2 = [&](float* frames_in, uint64_t nf, uint32_t* packed_out, float* haar_out) -> hipError_t {
+        return special2 ? launch_haar_select32(p, frames_in, nf, packed_out, haar_out, stream)
+                        : launch_haar_select(p, frames_in, nf, packed_out, haar_out, stream);
+    };
     const uint64_t frame_floats = (uint64_t)kRowsPerFrame * p.bands;
     if (d_raw) {  // the caller's tap buffer doubles as the inter-kernel scratch
         LBAD_HIP(stage1(d_pcm, n_clips, d_raw));
-        LBAD_HIP(launch_haar_select(p, d_raw, n_clips * per, d_packed, d_haar, stream));
+        LBAD_HIP(stage2(d_raw, n_clips * per, d_packed, d_haar));
         return noErr;
     }
     // bound the scratch (16 KiB per frame at 32 bands) to ~1 GiB by walking the clips in chunks
@@ -115,8 +120,8 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
     for (uint64_t c0 = 0; c0 < n_clips; c0 += chunk) {
         const uint64_t nc = (n_clips - c0) < chunk ? (n_clips - c0) : chunk;
         LBAD_HIP(stage1(d_pcm + c0 * spc, nc, d->d_frames));
-        LBAD_HIP(launch_haar_select(p, d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
-                                    d_haar ? d_haar + c0 * per * frame_floats : nullptr, stream));
+        LBAD_HIP(stage2(d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
+                        d_haar ? d_haar + c0 * per * frame_floats : nullptr));
     }
     return noErr;
 }

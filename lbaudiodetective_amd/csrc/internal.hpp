@@ -66,6 +66,11 @@ hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const 
                               uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
                               hipStream_t stream);
 
+// specialised stage 2 (k_haar_select32.hip): 128 x 32 frames, keep <= 128
+bool haar_select32_supported(const Plan& plan);
+hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_t n_frames, uint32_t* d_packed,
+                                float* d_haar_out, hipStream_t stream);
+
 // generic matrix ops behind the Frame API
 hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream);
 hipError_t launch_extract_generic(const float* d_m, uint32_t n, uint32_t n_wavelets, uint8_t* d_out,

@@ -1,0 +1,249 @@
+// k_haar_select32.hip -- specialised stage 2 for 128 x 32 frames: 2-D Haar + ranked top-K signs.
+//
+// Same results as k_haar_select.hip (LBAudioDetectiveFrame.m:113-153,165-191 and the truncating
+// copy at LBAudioDetective.m:326-328), restructured for the default frame shape:
+//
+//   * row pass: two threads per row, 16 values each, Haar levels 1..4 in registers, level 5 with
+//     one lane exchange; results go to LDS already transposed (column-major, 16-row chunks);
+//   * column pass: eight threads per column, 16 values each, levels 1..4 in registers, levels
+//     5..7 with three lane exchanges; every thread ends up owning 16 final coefficients whose
+//     flat positions are known in closed form, so the select works on registers;
+//   * select: bisect the |v| bit patterns for a threshold that leaves [keep, 128] candidates
+//     (one workgroup reduction per step), then rank only the candidates by the composite key
+//     (|v| bits, lower flat index first) and emit the sign pairs of ranks < keep.
+//
+// Every arithmetic operation is the reference's: x / sqrtf(n) pre-scale, (a +- b) / sqrtf(2)
+// butterflies, correctly rounded divisions.
+#include "internal.hpp"
+
+namespace lbad {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kCols = 32;
+constexpr uint32_t kCand = 128;     // candidates ranked exhaustively
+constexpr int kChunkDw = 20;        // 16 floats + 4 pad: conflict-free ds_read_b128 across lanes
+
+#ifndef LBAD_EXACT_CONST_DIV
+#define LBAD_EXACT_CONST_DIV 0
+#endif
+
+__device__ __forceinline__ float div_root(float x, float root) { return __fdiv_rn(x, root); }
+
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red, int parity) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    uint32_t* slot = s_red + 4 * parity;   // double-buffered: one barrier per reduction
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return slot[0] + slot[1] + slot[2] + slot[3];
+}
+
+// levels 1..4 of a 16-value line held in registers.  On return d[0..7] = level-1 details,
+// d[8..11] = level 2, d[12..13] = level 3, d[14] = level 4 and the return value is the level-4
+// average that continues into the cross-lane levels.
+__device__ __forceinline__ float haar16(float (&a)[16], float (&d)[15], float root, float root2) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = div_root(a[i], root);
+    float s1[8], s2[4], s3[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        s1[i] = div_root(__fadd_rn(a[2 * i], a[2 * i + 1]), root2);
+        d[i] = div_root(__fsub_rn(a[2 * i], a[2 * i + 1]), root2);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s2[i] = div_root(__fadd_rn(s1[2 * i], s1[2 * i + 1]), root2);
+        d[8 + i] = div_root(__fsub_rn(s1[2 * i], s1[2 * i + 1]), root2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        s3[i] = div_root(__fadd_rn(s2[2 * i], s2[2 * i + 1]), root2);
+        d[12 + i] = div_root(__fsub_rn(s2[2 * i], s2[2 * i + 1]), root2);
+    }
+    d[14] = div_root(__fsub_rn(s3[0], s3[1]), root2);
+    return div_root(__fadd_rn(s3[0], s3[1]), root2);
+}
+
+__global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
+                                                                 uint32_t subfp_len, uint32_t* __restrict__ packed,
+                                                                 float* __restrict__ haar_out) {
+    __shared__ __attribute__((aligned(16))) float s_t[kCols * 8 * kChunkDw];   // [col][chunk][20]
+    __shared__ unsigned long long s_cand[kCand];
+    __shared__ uint32_t s_rank[kCand];
+    __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_ncand;
+    __shared__ uint32_t s_bits[kPackedWords];
+
+    const int t = threadIdx.x;
+    const uint64_t frame = blockIdx.x;
+    const float root2 = __fsqrt_rn(2.0f);
+
+    if (t < (int)kPackedWords) s_bits[t] = 0;
+    if (t < (int)kCand) s_rank[t] = 0;
+    if (t == 0) s_ncand = 0;
+
+    // ---- row pass: thread = (row, half) ---------------------------------------------------------
+    {
+        const int row = t >> 1, h = t & 1;
+        const float4* src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + row * kCols + 16 * h);
+        float a[16], d[15];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = src[q];
+            a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+        }
+        const float s4 = haar16(a, d, __fsqrt_rn((float)kCols), root2);
+        // level 5 pairs the two halves of the row
+        const float other = __shfl_xor(s4, 1, 64);
+        const float lo = h ? other : s4, hi = h ? s4 : other;
+        const float last = h ? div_root(__fsub_rn(lo, hi), root2) : div_root(__fadd_rn(lo, hi), root2);
+        // transposed store: coefficient at ordered position p of this row -> s_t[p][row >> 4][row & 15]
+        float* base = s_t + (row >> 4) * kChunkDw + (row & 15);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) base[(16 + 8 * h + i) * (8 * kChunkDw)] = d[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) base[(8 + 4 * h + i) * (8 * kChunkDw)] = d[8 + i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) base[(4 + 2 * h + i) * (8 * kChunkDw)] = d[12 + i];
+        base[(2 + h) * (8 * kChunkDw)] = d[14];
+        base[h * (8 * kChunkDw)] = last;
+    }
+    __syncthreads();
+
+    // ---- column pass: thread = (column, chunk of 16 rows) -----------------------------------------
+    const int col = t >> 3, j = t & 7;
+    float v[16];
+    uint32_t pos[16];
+    {
+        float a[16], d[15];
+        const float4* src = reinterpret_cast<const float4*>(s_t + (col * 8 + j) * kChunkDw);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = src[q];
+            a[4 * q] = x.x; a[4 * q + 1] = x.y; a[4 * q + 2] = x.z; a[4 * q + 3] = x.w;
+        }
+        float cur = haar16(a, d, __fsqrt_rn((float)kRowsPerFrame), root2);
+        // levels 5..7 across the 8 chunks of the column; a lane leaves with its detail value as soon
+        // as its chunk index has the level's bit set
+        float fin = 0.0f;
+        bool done = false;
+#pragma unroll
+        for (int m = 1; m <= 4; m <<= 1) {
+            const float other = __shfl_xor(cur, m, 64);
+            const bool upper = (j & m) != 0;
+            const float lo = upper ? other : cur, hi = upper ? cur : other;
+            const float sm = div_root(__fadd_rn(lo, hi), root2);
+            const float df = div_root(__fsub_rn(lo, hi), root2);
+            if (!done && upper) { fin = df; done = true; }
+            cur = sm;
+        }
+        if (!done) fin = cur;   // chunk 0 keeps the overall average
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[i] = d[i]; pos[i] = 64 + 8 * j + i; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[8 + i] = d[8 + i]; pos[8 + i] = 32 + 4 * j + i; }
+        v[12] = d[12]; pos[12] = 16 + 2 * j;
+        v[13] = d[13]; pos[13] = 17 + 2 * j;
+        v[14] = d[14]; pos[14] = 8 + j;
+        // chunk -> ordered position of its cross-lane value: 0,4,2,5,1,6,3,7
+        const uint32_t cross = (j & 1) ? 4u + (j >> 1) : (j & 2) ? 2u + (j >> 2) : (j ? 1u : 0u);
+        v[15] = fin; pos[15] = cross;
+    }
+    if (haar_out) {
+        float* dst = haar_out + frame * (kRowsPerFrame * kCols);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[pos[i] * kCols + col] = v[i];
+    }
+
+    uint32_t key[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) key[i] = __float_as_uint(v[i]) & 0x7fffffffu;
+
+    // ---- threshold search ---------------------------------------------------------------------------
+    uint32_t lo = 0, hi = 0x80000000u, cnt_lo = kRowsPerFrame * kCols;
+    uint32_t idx_bound = kRowsPerFrame * kCols;
+    int parity = 0;
+    while (cnt_lo > kCand && hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) c += key[i] >= mid ? 1u : 0u;
+        c = block_sum(c, s_red, parity);
+        parity ^= 1;
+        if (c >= keep) { lo = mid; cnt_lo = c; } else { hi = mid; }
+    }
+    if (cnt_lo > kCand) {
+        // plateau: more than kCand coefficients share the threshold key (e.g. digital silence).  Take
+        // every key above it, then the tied ones in ascending flat-index order until `keep` is reached.
+        uint32_t g = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g += key[i] > lo ? 1u : 0u;
+        g = block_sum(g, s_red, parity);
+        parity ^= 1;
+        uint32_t ilo = 0, ihi = kRowsPerFrame * kCols;
+        while (ilo < ihi) {
+            const uint32_t im = ilo + ((ihi - ilo) >> 1);
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c += (key[i] == lo && pos[i] * kCols + col < im) ? 1u : 0u;
+            c = block_sum(c, s_red, parity);
+            parity ^= 1;
+            if (g + c >= keep) ihi = im; else ilo = im + 1;
+        }
+        idx_bound = ilo;
+    }
+
+    // ---- gather candidates: composite = key << 14 | (4095 - idx) << 2 | sign code -------------------
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t idx = pos[i] * kCols + col;
+        if (key[i] > lo || (key[i] == lo && idx < idx_bound)) {
+            const uint32_t at = atomicAdd(&s_ncand, 1u);
+            const uint32_t sg = v[i] > 0.0f ? 1u : (v[i] < 0.0f ? 2u : 0u);
+            s_cand[at] = ((unsigned long long)key[i] << 14) | ((unsigned long long)(4095u - idx) << 2) | sg;
+        }
+    }
+    __syncthreads();
+    const uint32_t nc = s_ncand;
+
+    // ---- rank: 2 threads per candidate, each scans half of the list ----------------------------------
+    {
+        const uint32_t i = t & 127, part = t >> 7;
+        if (i < nc) {
+            const unsigned long long mine = s_cand[i];
+            const uint32_t half = (nc + 1) >> 1;
+            const uint32_t j0 = part ? half : 0, j1 = part ? nc : half;
+            uint32_t r = 0;
+            for (uint32_t q = j0; q < j1; ++q) r += s_cand[q] > mine ? 1u : 0u;
+            if (r) atomicAdd(&s_rank[i], r);
+        }
+    }
+    __syncthreads();
+    if (t < (int)nc) {
+        const uint32_t rank = s_rank[t];
+        if (rank < keep) {
+            const uint32_t sg = (uint32_t)s_cand[t] & 3u;
+            const uint32_t b = 2 * rank;
+            if (sg == 1u) atomicOr(&s_bits[b >> 5], 1u << (b & 31));
+            else if (sg == 2u && b + 1 < subfp_len) atomicOr(&s_bits[(b + 1) >> 5], 1u << ((b + 1) & 31));
+        }
+    }
+    __syncthreads();
+    if (t < (int)kPackedWords) packed[frame * kPackedWords + t] = s_bits[t];
+}
+
+}  // namespace
+
+bool haar_select32_supported(const Plan& p) { return p.bands == (uint32_t)kCols && p.keep <= kCand && p.keep >= 1; }
+
+hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_t n_frames, uint32_t* d_packed,
+                                float* d_haar_out, hipStream_t stream) {
+    if (n_frames == 0) return hipSuccess;
+    if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(haar_select32_kernel, dim3((uint32_t)n_frames), dim3(kThreads), 0, stream, d_frames, plan.keep,
+                       plan.subfp_len, d_packed, d_haar_out);
+    return hipGetLastError();
+}
+
+}  // namespace lbad
