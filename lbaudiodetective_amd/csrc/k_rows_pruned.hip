@@ -29,17 +29,25 @@ constexpr int kStride = 64;
 constexpr int kBands = 32;
 constexpr int kBins = 22;           // bins 0..21
 constexpr int kRows = 43;           // stage-6 outputs kept per lane
+constexpr int kRowsA = 22;          // pass 1: rows 0..21 ("+" side), pass 2: rows 22..42 (mirror side)
 constexpr int kRowDw = 20;          // dwords per transpose row: 8 lanes x 8 B, padded 64 -> 80 B
-constexpr int kWinDw = 880;         // 43 rows x 20 = 860, padded so that window stride = 16 (mod 32) banks
-constexpr int kSpan = 127 * kStride + kW;                 // 9152 samples per frame
-constexpr int kSpanDw = kSpan + 16 * (kSpan >> 6);        // 16-dword skew per 64 samples: 11440
-constexpr int kTDw = 4 * 8 * kWinDw;                      // 4 waves x 8 windows
-constexpr int kVDw = 4 * 8 * 24;                          // power terms, 22 (padded 24) per window
-constexpr int kLdsBytes = (kSpanDw + kTDw + kVDw) * 4;    // 161 472 B
+constexpr int kWinDw = 464;         // 22 rows x 20 = 440, padded so that window stride = 16 (mod 32) banks
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+constexpr int kUnitWindows = 32;    // a workgroup owns a quarter frame: 4 waves x 8 windows
+constexpr int kSpan = (kUnitWindows - 1) * kStride + kW;  // 3008 samples
+constexpr int kSpanDw = kSpan + 16 * (kSpan >> 6);        // 16-dword skew per 64 samples: 3760
+constexpr int kTDw = kWaves * 8 * kWinDw;                 // per wave: 8 windows x one pass of rows
+constexpr int kBinConst = 14;       // per-bin twiddle block, see rows_pruned_constants()
+constexpr int kConstDw = kBins * 16;
+constexpr int kLdsBytes = (kSpanDw + kTDw + kConstDw) * 4;   // 75 840 B: two workgroups per CU
+static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
 struct cplx {
     float x, y;
 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) volatile f32x2 lds_vf32x2;   // LDS, not mergeable into ds_*2_b64
 
 __device__ __forceinline__ constexpr int brev6(int v) {
     return ((v & 1) << 5) | ((v & 2) << 3) | ((v & 4) << 1) | ((v & 8) >> 1) | ((v & 16) >> 3) | ((v & 32) >> 5);
@@ -117,12 +125,18 @@ __device__ __forceinline__ cplx stage6_row(const cplx (&x)[64]) {
     return o;
 }
 
-template <int I>
+// rows [I, END) of stage 6 -> transpose buffer rows [I - FIRST, ...).  volatile keeps the compiler
+// from fusing pairs into ds_write2_b64 / ds_read2_b64, which run at half the rate of the plain
+// 64-bit forms on gfx950.
+template <int I, int END, int FIRST>
 __device__ __forceinline__ void store_rows(const cplx (&x)[64], float* trow) {
-    if constexpr (I < kRows) {
+    if constexpr (I < END) {
         const cplx o = stage6_row<I>(x);
-        *reinterpret_cast<float2*>(trow + I * kRowDw) = make_float2(o.x, o.y);
-        store_rows<I + 1>(x, trow);
+        f32x2 ov;
+        ov.x = o.x;
+        ov.y = o.y;
+        *(lds_vf32x2*)(trow + (I - FIRST) * kRowDw) = ov;
+        store_rows<I + 1, END, FIRST>(x, trow);
     }
 }
 
@@ -130,7 +144,7 @@ template <int M>
 __device__ __forceinline__ void load_points(cplx (&x)[64], const float* src) {
     if constexpr (M < 64) {
         // sample 2r + 16 M of the window sits (M & 3) * 16 + (M >> 2) * 80 dwords after the lane base
-        const float2 v = *reinterpret_cast<const float2*>(src + (M & 3) * 16 + (M >> 2) * 80);
+        const f32x2 v = *(const lds_vf32x2*)(src + (M & 3) * 16 + (M >> 2) * 80);
         x[brev6(M)].x = v.x;
         x[brev6(M)].y = v.y;
         load_points<M + 1>(x, src);
@@ -151,54 +165,53 @@ __device__ __forceinline__ cplx tree(const float* row, const float* tw) {
     return madd(z0, tw[4], tw[5], z1);
 }
 
-// per-bin constants: [0..5] twiddles of the "+" tree (stages 7, 8, 9), [6..11] of the mirror
-// tree, [12..13] split-pass twiddle W_1024^k
-constexpr int kBinConst = 14;
-
-__global__ __launch_bounds__(256, 1) void frame_rows_pruned_kernel(const float* __restrict__ pcm,
-                                                                    uint64_t samples_per_clip,
-                                                                    uint32_t frames_per_clip,
-                                                                    const float* __restrict__ bin_const,
-                                                                    const uint32_t* __restrict__ band_tbl,
-                                                                    float* __restrict__ frames, int aligned16) {
+// per-bin constants (kBinConst floats, padded to 16): [0..5] twiddles of the "+" tree (stages 7, 8,
+// 9), [6..11] of the mirror tree, [12..13] split-pass twiddle W_1024^k
+__global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const float* __restrict__ pcm,
+                                                                         uint64_t samples_per_clip,
+                                                                         uint32_t frames_per_clip,
+                                                                         const float* __restrict__ bin_const,
+                                                                         const uint32_t* __restrict__ band_tbl,
+                                                                         float* __restrict__ frames, int aligned16) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* span = smem;
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     float* tbuf = smem + kSpanDw + wave * (8 * kWinDw);
-    float* vbuf = smem + kSpanDw + kTDw + wave * (8 * 24);
+    float* vbuf = tbuf;                       // power terms reuse the wave's transpose area after the trees
+    float* cbuf = smem + kSpanDw + kTDw;
 
-    const uint64_t frame = blockIdx.x;
+    const uint64_t unit = blockIdx.x;         // quarter frame
+    const uint64_t frame = unit >> 2;
+    const uint32_t quarter = (uint32_t)(unit & 3);
     const uint64_t clip = frame / frames_per_clip;
     const uint32_t fi = (uint32_t)(frame % frames_per_clip);
-    const float* src = pcm + clip * samples_per_clip + (uint64_t)fi * (128 * kStride);
+    const float* src = pcm + clip * samples_per_clip + ((uint64_t)fi * 128 + quarter * kUnitWindows) * kStride;
 
-    // ---- A: PCM span -> LDS (skewed by 16 dwords per 64 samples so that the 4 windows of a
-    //         32-lane group hit disjoint bank quarters in phase B1) ------------------------------
+    // ---- A: PCM span -> LDS, skewed by 16 dwords per 64 samples so that the 4 windows of a 32-lane
+    //         group hit disjoint bank quarters in phase B1.  All loads are issued before the first
+    //         LDS store: one HBM round trip is exposed, and the co-resident workgroup covers it. ----
     if (aligned16) {
         const float4* s4 = reinterpret_cast<const float4*>(src);
-        for (int i = threadIdx.x; i < kSpan / 4; i += 256) {
-            const float4 v = s4[i];
+        constexpr int kIter = (kSpan / 4 + kThreads - 1) / kThreads;
+        float4 v[kIter];
+#pragma unroll
+        for (int q = 0; q < kIter; ++q) {
+            const int i = threadIdx.x + kThreads * q;
+            v[q] = i < kSpan / 4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int i = threadIdx.x; i < kBins * kBinConst; i += kThreads)
+            cbuf[(i / kBinConst) * 16 + (i % kBinConst)] = bin_const[i];
+#pragma unroll
+        for (int q = 0; q < kIter; ++q) {
+            const int i = threadIdx.x + kThreads * q;
             const int s = 4 * i;
-            *reinterpret_cast<float4*>(span + s + 16 * (s >> 6)) = v;
+            if (i < kSpan / 4) *reinterpret_cast<float4*>(span + s + 16 * (s >> 6)) = v[q];
         }
     } else {
-        for (int s = threadIdx.x; s < kSpan; s += 256) span[s + 16 * (s >> 6)] = src[s];
-    }
-
-    // ---- per-lane constants of phase B4/B5 ----------------------------------------------------
-    // bin tasks: t = lane + 64 * round over 8 windows x 22 bins
-    int task_w[3], task_k[3];
-    float tc[3][kBinConst];
-#pragma unroll
-    for (int rd = 0; rd < 3; ++rd) {
-        const int t = lane + 64 * rd;
-        const int tw_ = t < 8 * kBins ? t / kBins : 0;
-        const int tk = t < 8 * kBins ? t % kBins : -1;
-        task_w[rd] = tw_;
-        task_k[rd] = tk;
-#pragma unroll
-        for (int c = 0; c < kBinConst; ++c) tc[rd][c] = tk >= 0 ? bin_const[tk * kBinConst + c] : 0.0f;
+        for (int i = threadIdx.x; i < kBins * kBinConst; i += kThreads)
+            cbuf[(i / kBinConst) * 16 + (i % kBinConst)] = bin_const[i];
+        for (int s = threadIdx.x; s < kSpan; s += kThreads) span[s + 16 * (s >> 6)] = src[s];
     }
     const int band = lane & 31;
     const uint32_t b_lo = band_tbl[band], b_hi = band_tbl[kBands + band];
@@ -208,57 +221,72 @@ __global__ __launch_bounds__(256, 1) void frame_rows_pruned_kernel(const float* 
     const int w8 = lane >> 3, r = lane & 7;
     const float inv_norm = 1.0f / (float)(kW / 4);
 
-    for (int it = 0; it < 4; ++it) {
-        const int win = 32 * it + 8 * wave + w8;
-        // ---- B1 + B2: 64 points of this lane, DIT stages 1..5 in registers ----------------------
-        cplx x[64];
-        load_points<0>(x, span + 80 * win + 2 * r);
-        stage_blocks<1, 0>(x);
-        stage_blocks<2, 0>(x);
-        stage_blocks<3, 0>(x);
-        stage_blocks<4, 0>(x);
-        stage_blocks<5, 0>(x);
-        // ---- B3: pruned stage 6 straight into the transpose buffer -----------------------------
-        store_rows<0>(x, tbuf + w8 * kWinDw + 2 * r);
+    // ---- B1 + B2: 64 points of this lane, DIT stages 1..5 in registers ----------------------------
+    cplx x[64];
+    load_points<0>(x, span + 80 * (8 * wave + w8) + 2 * r);
+    stage_blocks<1, 0>(x);
+    stage_blocks<2, 0>(x);
+    stage_blocks<3, 0>(x);
+    stage_blocks<4, 0>(x);
+    stage_blocks<5, 0>(x);
 
-        // ---- B4: bin tasks: two reduction trees, split pass, power term ------------------------
+    // ---- B3/B4 pass 1: "+" rows through the transpose buffer, tree of Z[k] per bin task -----------
+    // bin tasks: t = lane + 64 * round over 8 windows x 22 bins
+    store_rows<0, kRowsA, 0>(x, tbuf + w8 * kWinDw + 2 * r);
+    cplx za[3];
 #pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
-            const int k = task_k[rd];
-            if (k >= 0) {
-                const float* wbase = tbuf + task_w[rd] * kWinDw;
-                const cplx a = tree(wbase + k * kRowDw, &tc[rd][0]);
-                const cplx b = tree(wbase + (k ? 43 - k : 0) * kRowDw, &tc[rd][6]);
-                float re, im;
-                if (k == 0) {
-                    const float sm = a.x + a.y, df = a.x - a.y;
-                    re = sm + sm;
-                    im = df + df;
-                } else {
-                    const float sr = a.x + b.x, si = a.y - b.y;
-                    const float dr = a.x - b.x, di = a.y + b.y;
-                    const float wr = tc[rd][12], wi = tc[rd][13];
-                    re = __fmaf_rn(wr, di, __fmaf_rn(wi, dr, sr));
-                    im = __fmaf_rn(-wr, dr, __fmaf_rn(wi, di, si));
-                }
-                if (re > 0.0f) re = __fmul_rn(re, inv_norm);
-                if (im > 0.0f) im = __fmul_rn(im, inv_norm);
-                vbuf[task_w[rd] * 24 + k] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-            }
+    for (int rd = 0; rd < 3; ++rd) {
+        const int t = lane + 64 * rd;
+        const int tw_ = t < 8 * kBins ? t / kBins : 0;
+        const int tk = t < 8 * kBins ? t % kBins : 0;
+        za[rd] = tree(tbuf + tw_ * kWinDw + tk * kRowDw, cbuf + tk * 16);
+    }
+    // ---- pass 2: mirror rows reuse the same buffer (in-order LDS: the stores cannot pass the reads) --
+    store_rows<kRowsA, kRows, kRowsA>(x, tbuf + w8 * kWinDw + 2 * r);
+    float pw[3];
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+        const int t = lane + 64 * rd;
+        const int tw_ = t < 8 * kBins ? t / kBins : 0;
+        const int k = t < 8 * kBins ? t % kBins : 0;
+        const float* c = cbuf + k * 16;
+        // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror)
+        const cplx b = tree(tbuf + tw_ * kWinDw + (k ? 21 - k : 0) * kRowDw, c + 6);
+        const cplx a = za[rd];
+        float re, im;
+        if (k == 0) {
+            const float sm = a.x + a.y, df = a.x - a.y;
+            re = sm + sm;
+            im = df + df;
+        } else {
+            const float sr = a.x + b.x, si = a.y - b.y;
+            const float dr = a.x - b.x, di = a.y + b.y;
+            const float wr = c[12], wi = c[13];
+            re = __fmaf_rn(wr, di, __fmaf_rn(wi, dr, sr));
+            im = __fmaf_rn(-wr, dr, __fmaf_rn(wi, di, si));
         }
+        if (re > 0.0f) re = __fmul_rn(re, inv_norm);
+        if (im > 0.0f) im = __fmul_rn(im, inv_norm);
+        pw[rd] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    }
+    // power terms -> LDS only after every tree of the wave has read its rows
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+        const int t = lane + 64 * rd;
+        if (t < 8 * kBins) vbuf[(t / kBins) * 24 + (t % kBins)] = pw[rd];
+    }
 
-        // ---- B5: band means, 8 windows x 32 bands per wave-iteration ----------------------------
+    // ---- B5: band means, 8 windows x 32 bands per wave ---------------------------------------------
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ww = 2 * q + (lane >> 5);
-            float p = 0.0f;
-            for (uint32_t k = b_lo; k < b_hi; ++k) {
-                const float v = vbuf[ww * 24 + k];
-                if (v == v && fabsf(v) != INFINITY) p = __fadd_rn(p, v);
-            }
-            const uint32_t row = 32 * it + 8 * wave + ww;
-            frames[(frame * 128 + row) * kBands + band] = __fdiv_rn(p, b_div);
+    for (int q = 0; q < 4; ++q) {
+        const int ww = 2 * q + (lane >> 5);
+        float p = 0.0f;
+        for (uint32_t k = b_lo; k < b_hi; ++k) {
+            const float v = vbuf[ww * 24 + k];
+            if (v == v && fabsf(v) != INFINITY) p = __fadd_rn(p, v);
         }
+        const uint32_t row = quarter * kUnitWindows + 8 * wave + ww;
+        frames[(frame * 128 + row) * kBands + band] = __fdiv_rn(p, b_div);
     }
 }
 
@@ -311,7 +339,8 @@ hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const 
         attr_set = true;
     }
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_pcm) & 15) == 0 && (samples_per_clip & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(frame_rows_pruned_kernel, dim3((uint32_t)n_frames), dim3(256), kLdsBytes, stream, d_pcm,
+    if (n_frames * 4 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(frame_rows_pruned_kernel, dim3((uint32_t)(n_frames * 4)), dim3(kThreads), kLdsBytes, stream, d_pcm,
                        samples_per_clip, frames_per_clip, d_bin_const, plan.d_bands, d_frames, aligned16);
     return hipGetLastError();
 }
