@@ -39,7 +39,8 @@ constexpr int kSpan = (kUnitWindows - 1) * kStride + kW;  // 3008 samples
 constexpr int kSpanDw = kSpan + 16 * (kSpan >> 6);        // 16-dword skew per 64 samples: 3760
 constexpr int kTDw = kWaves * 8 * kWinDw;                 // per wave: 8 windows x one pass of rows
 constexpr int kBinConst = 14;       // per-bin twiddle block, see rows_pruned_constants()
-constexpr int kConstDw = kBins * 16;
+constexpr int kConstStride = 20;    // 14 floats per bin padded to 80 B: lanes with different bins hit different banks
+constexpr int kConstDw = kBins * kConstStride;
 constexpr int kLdsBytes = (kSpanDw + kTDw + kConstDw) * 4;   // 75 840 B: two workgroups per CU
 static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
@@ -165,7 +166,7 @@ __device__ __forceinline__ cplx tree(const float* row, const float* tw) {
     return madd(z0, tw[4], tw[5], z1);
 }
 
-// per-bin constants (kBinConst floats, padded to 16): [0..5] twiddles of the "+" tree (stages 7, 8,
+// per-bin constants (kBinConst floats, padded to kConstStride): [0..5] twiddles of the "+" tree (stages 7, 8,
 // 9), [6..11] of the mirror tree, [12..13] split-pass twiddle W_1024^k
 __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const float* __restrict__ pcm,
                                                                          uint64_t samples_per_clip,
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const fl
             v[q] = i < kSpan / 4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         for (int i = threadIdx.x; i < kBins * kBinConst; i += kThreads)
-            cbuf[(i / kBinConst) * 16 + (i % kBinConst)] = bin_const[i];
+            cbuf[(i / kBinConst) * kConstStride + (i % kBinConst)] = bin_const[i];
 #pragma unroll
         for (int q = 0; q < kIter; ++q) {
             const int i = threadIdx.x + kThreads * q;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const fl
         }
     } else {
         for (int i = threadIdx.x; i < kBins * kBinConst; i += kThreads)
-            cbuf[(i / kBinConst) * 16 + (i % kBinConst)] = bin_const[i];
+            cbuf[(i / kBinConst) * kConstStride + (i % kBinConst)] = bin_const[i];
         for (int s = threadIdx.x; s < kSpan; s += kThreads) span[s + 16 * (s >> 6)] = src[s];
     }
     const int band = lane & 31;
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const fl
         const int t = lane + 64 * rd;
         const int tw_ = t < 8 * kBins ? t / kBins : 0;
         const int tk = t < 8 * kBins ? t % kBins : 0;
-        za[rd] = tree(tbuf + tw_ * kWinDw + tk * kRowDw, cbuf + tk * 16);
+        za[rd] = tree(tbuf + tw_ * kWinDw + tk * kRowDw, cbuf + tk * kConstStride);
     }
     // ---- pass 2: mirror rows reuse the same buffer (in-order LDS: the stores cannot pass the reads) --
     store_rows<kRowsA, kRows, kRowsA>(x, tbuf + w8 * kWinDw + 2 * r);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const fl
         const int t = lane + 64 * rd;
         const int tw_ = t < 8 * kBins ? t / kBins : 0;
         const int k = t < 8 * kBins ? t % kBins : 0;
-        const float* c = cbuf + k * 16;
+        const float* c = cbuf + k * kConstStride;
         // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror)
         const cplx b = tree(tbuf + tw_ * kWinDw + (k ? 21 - k : 0) * kRowDw, c + 6);
         const cplx a = za[rd];
