@@ -109,6 +109,7 @@ def main() -> None:
         step()
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    det.set_stage_timing(True)      # HIP events around each kernel, on the launch stream, inside the timed region
     t0 = time.perf_counter()
     for s in range(args.steps):
         ev[s][0].record()
@@ -124,6 +125,11 @@ def main() -> None:
     value = n_gpus * n_clips * args.steps / elapsed            # audio-seconds per second, whole job
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
     kern_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    stage1_ms, stage2_ms, launches = det.stage_times()      # summed over the K timed steps
+    det.set_stage_timing(False)
+    launches_per_step = launches // args.steps
+    rows_ms = stage1_ms / launches                          # dominant kernel: average launch duration
+    clips_per_launch = n_clips / launches_per_step
 
     # ---- parity of the bench's own data against the oracle (untimed, rank 0) -------------------
     result = None
@@ -131,6 +137,18 @@ def main() -> None:
         alg_bytes = algorithmic_bytes_per_clip(SAMPLES, WINDOW, STRIDE)
         achieved = alg_bytes * n_clips / (kern_avg_ms * 1e-3) / 1e9
         canon_flops = per * 128 * 2.5 * WINDOW * 10            # 2.5 W log2 W per window
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE, corrected as
+        # MI355X_MICROARCH.md prescribes); they cannot be collected from inside this process
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "stage1_pruned" if args.variant != 1 else "stage1_generic"
+                if key in tj:
+                    traffic = round(tj[key]["hbm_bytes_per_clip"] * clips_per_launch)
+            except (OSError, ValueError, KeyError):
+                traffic = None
         result = {
             "metric": "audio_seconds_fingerprinted_per_sec",
             "value": round(value, 1),
@@ -154,18 +172,23 @@ def main() -> None:
             "per_gpu_value": round(value / n_gpus, 1),
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fingerprint pass (all launches of one step)",
-                "achieved": round(achieved, 2),
+                "kernel": "stage 1, windows -> frame rows (frame_rows_pruned_kernel when the pruned FFT applies, "
+                          "else fft_bands_kernel): dominant kernel of the pass",
+                "achieved": round(alg_bytes * clips_per_launch / (rows_ms * 1e-3) / 1e9, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "frac": round(alg_bytes * clips_per_launch / (rows_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
                 "algorithmic_bytes_per_clip": alg_bytes,
-                "kernel_ms_avg": round(kern_avg_ms, 4),
-                "kernel_ms_min": round(kernel_ms[0], 4),
-                # the fingerprint pass is FP32-VALU bound, not HBM bound: canonical-FFT rate beside it
-                "fp32_canonical_tflops": round(canon_flops * n_clips / (kern_avg_ms * 1e-3) / 1e12, 3),
+                "clips_per_launch": clips_per_launch,
+                "launches_per_step": launches_per_step,
+                "kernel_ms_avg": round(rows_ms, 4),
+                "stage2_kernel_ms_avg": round(stage2_ms / launches, 4),
+                "step_ms_avg": round(kern_avg_ms, 4),
+                # the pass is FP32-VALU/LDS bound, not HBM bound: canonical-FFT rate beside it
+                "fp32_canonical_tflops": round(canon_flops * clips_per_launch / (rows_ms * 1e-3) / 1e12, 3),
                 "fp32_peak_tflops": FP32_PEAK_TFLOPS,
+                "whole_pass_achieved_GBps": round(achieved, 2),
             },
         }
 
@@ -179,7 +202,7 @@ def main() -> None:
 
         if not args.no_cpu_baseline:
             threads = usable_cores()
-            n_cpu = args.cpu_sample or min(n_clips, 1500 * threads)     # ~10 s at ~6 ms per clip per thread
+            n_cpu = args.cpu_sample or min(n_clips, 4000 * threads)     # ~11 s at ~2.8 ms per clip per thread
             sample = clips[:n_cpu].cpu().numpy()
             O.fingerprint_batch(sample[: 2 * threads], cfg, nthreads=threads)    # warm the caches/threads
             t1 = time.perf_counter()

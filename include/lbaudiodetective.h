@@ -188,11 +188,21 @@ OSStatus LBAudioDetectiveFingerprintClipsDevice(LBAudioDetectiveRef inDetective,
 /* Same, host buffers in and unpacked Booleans out (count x subfingerprintLength per clip). */
 OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef inDetective, const Float32* inClips,
                                           UInt64 inNumberOfClips, UInt64 inSamplesPerClip, Boolean* outBooleans);
-/* Kernel selection for the batch path: 0 = automatic, 1 = force the unfused
- * fft+bands / haar+select kernels, 2 = force the fused per-frame kernel (ArgumentInvalid
- * if the configuration has no fused specialisation). */
+/* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band
+ * count), 2 = specialised kernels (pruned 1024-point FFT for bands that read only bins 0..21, register
+ * Haar/select for 128 x 32 frames); 2 returns ArgumentInvalid when the configuration has none. */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
-/* Debug taps for stage-level parity tests (unfused kernels only): device buffers of
+/* HBM the frame-row buffer between the two kernels may take (default 16 GiB; 16 KiB per frame at 32
+ * bands).  Batches that need more are processed in several launches. */
+OSStatus LBAudioDetectiveSetScratchLimit(LBAudioDetectiveRef inDetective, UInt64 inBytes);
+/* Measurement aid: once enabled, every batch call records HIP events on its stream around the two
+ * kernels; GetStageTimes waits for the last batch and returns, summed over all batch calls since
+ * timing was (re-)enabled, the durations (ms) of stage 1 (windows -> frame rows) and stage 2
+ * (Haar + select) and the number of launches of each. */
+OSStatus LBAudioDetectiveSetStageTiming(LBAudioDetectiveRef inDetective, UInt32 inEnabled);
+OSStatus LBAudioDetectiveGetStageTimes(LBAudioDetectiveRef inDetective, Float32* outStage1Ms, Float32* outStage2Ms,
+                                       UInt32* outLaunches);
+/* Debug taps for stage-level parity tests: device buffers of
  * clips x count x 128 x bands float32 receiving the frame before / after the Haar; either may be NULL. */
 OSStatus LBAudioDetectiveFingerprintClipsDeviceTaps(LBAudioDetectiveRef inDetective, const Float32* inClips,
                                                     UInt64 inNumberOfClips, UInt64 inSamplesPerClip,

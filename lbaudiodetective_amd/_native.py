@@ -95,6 +95,9 @@ _SIGNATURES = {
     "LBAudioDetectiveFingerprintClipsDevice": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveFingerprintClips": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, C.c_void_p]),
     "LBAudioDetectiveSetKernelVariant": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveSetScratchLimit": (OSStatus, [Ref, UInt64]),
+    "LBAudioDetectiveSetStageTiming": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveGetStageTimes": (OSStatus, [Ref, _P(Float32), _P(Float32), _P(UInt32)]),
     "LBAudioDetectiveFingerprintClipsDeviceTaps": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, C.c_void_p, C.c_void_p,
                                                               C.c_void_p, C.c_void_p]),
     "LBAudioDetectivePackSubfingerprint": (None, [C.c_void_p, UInt32, C.c_void_p]),

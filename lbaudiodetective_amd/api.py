@@ -262,6 +262,18 @@ class Detective:
     def set_kernel_variant(self, variant: int):
         _check(self._L.LBAudioDetectiveSetKernelVariant(self._ref, variant), "SetKernelVariant")
 
+    def set_scratch_limit(self, n_bytes: int):
+        _check(self._L.LBAudioDetectiveSetScratchLimit(self._ref, n_bytes), "SetScratchLimit")
+
+    def set_stage_timing(self, enabled: bool):
+        _check(self._L.LBAudioDetectiveSetStageTiming(self._ref, int(enabled)), "SetStageTiming")
+
+    def stage_times(self):
+        """(stage 1 ms, stage 2 ms, launches per stage) of the last batch call; waits for it."""
+        a, b, n = N.Float32(0), N.Float32(0), N.UInt32(0)
+        _check(self._L.LBAudioDetectiveGetStageTimes(self._ref, C.byref(a), C.byref(b), C.byref(n)), "GetStageTimes")
+        return float(a.value), float(b.value), int(n.value)
+
     def subfingerprint_count(self, n_samples: int) -> int:
         return int(self._L.LBAudioDetectiveGetSubfingerprintCount(self._ref, n_samples))
 

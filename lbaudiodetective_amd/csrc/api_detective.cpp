@@ -111,17 +111,30 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
         LBAD_HIP(stage2(d_raw, n_clips * per, d_packed, d_haar));
         return noErr;
     }
-    // bound the scratch (16 KiB per frame at 32 bands) to ~1 GiB by walking the clips in chunks
-    uint64_t chunk = (1ull << 28) / (per * frame_floats);
+    // the inter-stage buffer (16 KiB per frame at 32 bands) is capped; larger batches walk in chunks
+    uint64_t chunk = (d->scratch_limit / sizeof(float)) / (per * frame_floats);
     if (chunk == 0) chunk = 1;
     if (chunk > n_clips) chunk = n_clips;
     st = ensure_scratch(d, chunk * per * frame_floats);
     if (st != noErr) return st;
+    auto mark = [&]() -> hipError_t {   // events accumulate over calls until SetStageTiming resets them
+        if (!d->timing) return hipSuccess;
+        if (d->ev_used == d->ev.size()) {
+            hipEvent_t e;
+            hipError_t err = hipEventCreate(&e);
+            if (err != hipSuccess) return err;
+            d->ev.push_back(e);
+        }
+        return hipEventRecord(d->ev[d->ev_used++], stream);
+    };
     for (uint64_t c0 = 0; c0 < n_clips; c0 += chunk) {
         const uint64_t nc = (n_clips - c0) < chunk ? (n_clips - c0) : chunk;
+        LBAD_HIP(mark());
         LBAD_HIP(stage1(d_pcm + c0 * spc, nc, d->d_frames));
+        LBAD_HIP(mark());
         LBAD_HIP(stage2(d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
                         d_haar ? d_haar + c0 * per * frame_floats : nullptr));
+        LBAD_HIP(mark());
     }
     return noErr;
 }
@@ -146,6 +159,7 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective == NULL) return kLBAudioDetectiveArgumentInvalid;
     lbad::free_plan(inDetective->plan);
     if (inDetective->d_frames) (void)hipFree(inDetective->d_frames);
+    for (hipEvent_t e : inDetective->ev) (void)hipEventDestroy(e);
     delete inDetective;
     return noErr;
 }
@@ -198,6 +212,37 @@ OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef d, UInt32 inAnaly
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef d, UInt32 inVariant) {
     if (inVariant > 2) return kLBAudioDetectiveArgumentInvalid;
     d->variant = inVariant;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveSetScratchLimit(LBAudioDetectiveRef d, UInt64 inBytes) {
+    if (!d || inBytes == 0) return kLBAudioDetectiveArgumentInvalid;
+    d->scratch_limit = inBytes;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveSetStageTiming(LBAudioDetectiveRef d, UInt32 inEnabled) {
+    if (!d) return kLBAudioDetectiveArgumentInvalid;
+    d->timing = inEnabled != 0;
+    d->ev_used = 0;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveGetStageTimes(LBAudioDetectiveRef d, Float32* outStage1Ms, Float32* outStage2Ms,
+                                       UInt32* outLaunches) {
+    if (!d || !d->timing || d->ev_used < 3) return kLBAudioDetectiveArgumentInvalid;
+    float s1 = 0.0f, s2 = 0.0f;
+    LBAD_HIP(hipEventSynchronize(d->ev[d->ev_used - 1]));
+    for (size_t i = 0; i + 2 < d->ev_used; i += 3) {
+        float a = 0.0f, b = 0.0f;
+        LBAD_HIP(hipEventElapsedTime(&a, d->ev[i], d->ev[i + 1]));
+        LBAD_HIP(hipEventElapsedTime(&b, d->ev[i + 1], d->ev[i + 2]));
+        s1 += a;
+        s2 += b;
+    }
+    if (outStage1Ms) *outStage1Ms = s1;
+    if (outStage2Ms) *outStage2Ms = s2;
+    if (outLaunches) *outLaunches = (UInt32)(d->ev_used / 3);
     return noErr;
 }
 

@@ -129,8 +129,13 @@ struct LBAudioDetective {
     uint32_t bands;
     uint32_t variant = 0;
     lbad::Plan plan;         // lazily rebuilt when the configuration changes
-    float* d_frames = nullptr;  // scratch for the unfused path
+    float* d_frames = nullptr;  // frame rows between stage 1 and stage 2
     uint64_t d_frames_cap = 0;  // in floats
+    uint64_t scratch_limit = 16ull << 30;   // bytes of HBM the inter-stage buffer may take
+    // optional per-stage timing (hipEvents on the caller's stream)
+    bool timing = false;
+    std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2
+    size_t ev_used = 0;
 };
 
 struct LBAudioDetectiveCorpus {
