@@ -63,6 +63,8 @@ def main() -> None:
     ap.add_argument("--clips", type=int, default=100_000, help="clips resident per GPU")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 unfused kernels, 2 fused kernel")
     ap.add_argument("--corpus", type=int, default=1_000_000, help="entries for the compare-leg side measurement (0 = skip)")
+    ap.add_argument("--corpus-hbm", type=int, default=10_000_000,
+                    help="entries per GPU of the HBM-resident scan (larger than the 256 MiB Infinity Cache; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="clips for the CPU baseline (0 = 250 per thread)")
     args = ap.parse_args()
@@ -261,6 +263,34 @@ def main() -> None:
                 "achieved_GBps_layout": round(sc.local.entry_stride_bytes * n_local / (scan_ms * 1e-3) / 1e9, 2),
                 "hbm_frac_algorithmic": round(25 * per * n_local / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             }
+
+    # HBM-resident scan: the 1 M corpus (128 MB) fits the 256 MiB Infinity Cache, this one does not
+    if args.corpus > 0 and args.corpus_hbm > 0 and world == 1:
+        n_big = args.corpus_hbm
+        big = lb.Corpus(200, per, n_big)
+        for b in range(0, n_big, 1 << 20):
+            big.append_packed_device(lb.synth_corpus_device(CSEED, b, min(1 << 20, n_big - b), per, 200))
+        key = torch.zeros(1, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            big.query_key_device(fq, key)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            big.query_key_device(fq, key)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        idx, sc = lb.Corpus.decode_key(int(key.item()))
+        result["compare_hbm"] = {
+            "workload": f"1 query vs {n_big} fingerprints on one GPU ({big.entry_stride_bytes * n_big / 1e9:.2f} GB, HBM-resident)",
+            "scan_ms": round(ms, 4), "best_index": idx, "best_score": sc,
+            "roofline": {"bound": "hbm", "achieved": round(25 * per * n_big / (ms * 1e-3) / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(25 * per * n_big / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "layout_GBps": round(big.entry_stride_bytes * n_big / (ms * 1e-3) / 1e9, 1)},
+        }
+        big.dispose()
 
     if world > 1:
         dist.barrier()

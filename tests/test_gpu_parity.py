@@ -399,3 +399,91 @@ def test_sharded_on_one_device(lb, gpu, oracle):
     sc = lb.ShardedCorpus(200, 5, n)                        # world size 1: query() without a process group
     sc.append_packed_device(lb.synth_corpus_device(CSEED, 0, n, 5, 200))
     assert sc.query(fq) == got
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json sizes: properties that need no oracle pass over the whole batch
+# ---------------------------------------------------------------------------------------------
+def _free_gib(gpu):
+    free, _ = gpu.cuda.mem_get_info()
+    return free / 2**30
+
+
+def test_full_size_fingerprint_batch(lb, gpu, oracle):
+    """configs[1]: 100 000 one-second 44.1 kHz clips.  (1) the specialised and the generic kernels
+    agree on every sub-fingerprint of the whole batch; (2) identical clips planted at scattered
+    batch positions give identical bits; (3) a sample is bit-exact against the oracle; (4) a batch
+    processed in several launches (small scratch limit) equals the single-launch result."""
+    n = 100_000
+    if _free_gib(gpu) < 60:
+        pytest.skip("needs ~45 GiB of HBM")
+    clips = lb.synth_clips_device(SEED, 0, n, 44100, 44100)
+    twins = [3, 4097, 50_000, 99_999]
+    for t in twins[1:]:
+        clips[t].copy_(clips[twins[0]])
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    det.set_kernel_variant(2)
+    fast = det.fingerprint_clips_device(clips)
+    det.set_kernel_variant(1)
+    slow = det.fingerprint_clips_device(clips)
+    gpu.cuda.synchronize()
+    assert gpu.equal(fast, slow)
+    for t in twins[1:]:
+        assert gpu.equal(fast[t], fast[twins[0]])
+    assert not gpu.equal(fast[0], fast[1])
+    det.set_kernel_variant(0)
+    det.set_scratch_limit(1 << 28)                       # 256 MiB -> many launches
+    chunked = det.fingerprint_clips_device(clips)
+    gpu.cuda.synchronize()
+    assert gpu.equal(chunked, fast)
+    pick = [0, 1, 2, 77_777, 99_998]
+    host = clips[pick].cpu().numpy()
+    want = oracle.fingerprint_batch(host, oracle.Config(44100, 1024), nthreads=4)
+    got = lb.unpack_packed(fast[pick].cpu().numpy(), 200).reshape(len(pick), 5, 200)
+    assert np.array_equal(got, want)
+    # every sub-fingerprint carries exactly 100 sign pairs with at most one Boolean set per pair
+    words = fast.view(gpu.int32).reshape(-1, 8)
+    both = words & (words >> 1) & 0x55555555
+    assert int(both.abs().sum().item()) == 0
+    assert int((words[:, 6] >> 8).abs().sum().item()) == 0 and int(words[:, 7].abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("n", [1_000_000, 10_000_000])
+def test_full_size_corpus(lb, gpu, oracle, n):
+    """configs[2]/[3]: 1 M and 10 M fingerprints.  The planted near-duplicate is found with the
+    oracle's score; specialised and generic scans return the same key; 8 contiguous shards
+    max-reduced equal the whole-corpus answer (the all-reduce of config 4 on one device)."""
+    from lbaudiodetective_amd import sharded
+    if _free_gib(gpu) < 8:
+        pytest.skip("needs a few GiB of HBM")
+    corpus = lb.Corpus(200, 5, n)
+    step = 1 << 20
+    for b in range(0, n, step):
+        corpus.append_packed_device(lb.synth_corpus_device(CSEED, b, min(step, n - b), 5, 200))
+    planted = 777_777
+    entry = oracle.synth_entry(CSEED, planted, 5, 200)
+    q = _planted_query(oracle, entry, 0.07)
+    fq = lb.Fingerprint.from_bools(q)
+    want_score = np.float32(oracle.compare_fp(q, entry, 200))
+    corpus.set_kernel_variant(2)
+    got = corpus.query(fq)
+    assert got[0] == planted and np.float32(got[1]).view(np.uint32) == want_score.view(np.uint32)
+    assert abs(got[1] - 0.93) < 0.03                      # 7 % of the pairs flipped
+    if n <= 1_000_000:
+        corpus.set_kernel_variant(1)
+        assert corpus.query(fq) == got
+        corpus.set_kernel_variant(0)
+    keys = []
+    for r in range(8):
+        b, e = sharded.shard_range(n, r, 8)
+        shard = lb.Corpus(200, 5, e - b)
+        for c in range(b, e, step):
+            shard.append_packed_device(lb.synth_corpus_device(CSEED, c, min(step, e - c), 5, 200))
+        key = gpu.zeros(1, dtype=gpu.int64, device="cuda")
+        shard.query_key_device(fq, key, 0, index_base=b)
+        keys.append(int(key.item()))
+        shard.dispose()
+    assert sharded.decode_key(max(keys)) == got
+    # scores elsewhere sit at chance level (essay p.43): sample the score vector
+    scores = corpus.scores_device(fq, 200)[:: max(1, n // 4096)].cpu().numpy()
+    assert 0.45 < float(np.median(scores)) < 0.55
