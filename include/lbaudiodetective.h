@@ -103,9 +103,10 @@ OSStatus LBAudioDetectiveSetSubfingerprintLength(LBAudioDetectiveRef inDetective
  * leaving the detective unchanged, for anything else. */
 OSStatus LBAudioDetectiveSetWindowSize(LBAudioDetectiveRef inDetective, UInt32 inWindowSize);       /* D.h:184 */
 OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef inDetective, UInt32 inAnalysisStride); /* D.h:194 */
-/* File front end: LPCM CAF / WAV already at the processing sample rate (mono, or
- * multi-channel averaged to mono).  Compressed data or another rate returns
- * kLBAudioDetectiveUnsupportedFile (Apple's decoder/resampler is out of scope). */
+/* File front end replacing ExtAudioFile: CAF ('lpcm' or Apple 'ima4') and RIFF/WAVE (PCM, IEEE
+ * float), channels averaged to mono, converted to the processing sample rate by a documented
+ * windowed-sinc resampler (Apple's converter is closed source), then fingerprinted on the GPU.
+ * Other payloads return kLBAudioDetectiveUnsupportedFile, a missing file -43 (fnfErr). */
 OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint); /* D.h:218 */
 OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL1,
@@ -136,6 +137,14 @@ Float32 LBAudioDetectiveFingerprintCompareSubfingerprints(LBAudioDetectiveFinger
                                                           Boolean* inSubfingerprint1, Boolean* inSubfingerprint2,
                                                           UInt32 inRange);                            /* Fp.h:147 */
 
+/* Wire format of a fingerprint: '0'/'1' per Boolean, sub-fingerprints joined by '+' (the string the
+ * upstream test helper builds, LBAudioDetectiveTests.m:22-37).  GetString writes a NUL-terminated
+ * string when inCapacity suffices and always returns the length needed (without the NUL);
+ * NewFromString returns NULL for malformed input. */
+UInt64 LBAudioDetectiveFingerprintGetStringLength(LBAudioDetectiveFingerprintRef inFingerprint);
+UInt64 LBAudioDetectiveFingerprintGetString(LBAudioDetectiveFingerprintRef inFingerprint, char* outString, UInt64 inCapacity);
+LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNewFromString(const char* inString);
+
 /* ======================================================================================
  * Part 1c -- frame (Fr.h; "internal" upstream but used by its Haar test)
  * ==================================================================================== */
@@ -157,6 +166,18 @@ Boolean LBAudioDetectiveFrameEqualToFrame(LBAudioDetectiveFrameRef inFrame1, LBA
 /* ======================================================================================
  * Part 2 -- additions
  * ==================================================================================== */
+
+/* How the file entry points hop between windows when the file's rate differs from the processing
+ * rate.  0 (default): analysisStride samples at the PROCESSING rate, like the PCM entry points.
+ * 1: what upstream actually does -- its seek offsets and its length are in FILE
+ * frames, so the hop is analysisStride * processingRate / fileRate processing-rate samples (rounded,
+ * at least 1) and the window count is (fileFrames - windowSize) / analysisStride. */
+OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef inDetective, UInt32 inMode);
+/* Decode a file to mono float32, optionally converted to inSampleRate (0 = keep the file's rate).
+ * The buffer is owned by the caller and released with LBAudioDetectiveFreeSamples. */
+OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
+                                      UInt64* outCount, Float64* outSampleRate);
+void LBAudioDetectiveFreeSamples(Float32* inSamples);
 
 /* Number of sub-fingerprints a buffer of inNumberOfSamples yields with the detective's
  * window/stride (framing of LBAudioDetective.m:250-255; 0 when shorter than a window). */
@@ -249,7 +270,11 @@ void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* ou
 /* Per-entry scores (debug / parity): device pointer to count float32. */
 OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                             UInt32 inRange, Float32* outScores, void* inStream);
-/* Kernel selection: 0 = automatic, 1 = generic slot-layout kernel, 2 = specialised plane kernel. */
+/* Binary corpus file ("LBADCRP1" header + the stored entries' planes); Load reserves
+ * max(inCapacity, stored count) entries. */
+OSStatus LBAudioDetectiveCorpusSave(LBAudioDetectiveCorpusRef inCorpus, const char* inPath);
+LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 inCapacity);
+/* Kernel selection: 0 = automatic, 1 = generic kernel, 2 = specialised plane kernel. */
 OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef inCorpus, UInt32 inVariant);
 
 /* ---- synthetic inputs generated on the device (bench / tests) -------------------------- */

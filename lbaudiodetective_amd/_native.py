@@ -74,6 +74,9 @@ _SIGNATURES = {
     "LBAudioDetectiveFingerprintEqualToFingerprint": (Boolean, [Ref, Ref]),
     "LBAudioDetectiveFingerprintCompareToFingerprint": (Float32, [Ref, Ref, UInt32]),
     "LBAudioDetectiveFingerprintCompareSubfingerprints": (Float32, [Ref, C.c_void_p, C.c_void_p, UInt32]),
+    "LBAudioDetectiveFingerprintGetStringLength": (UInt64, [Ref]),
+    "LBAudioDetectiveFingerprintGetString": (UInt64, [Ref, C.c_char_p, UInt64]),
+    "LBAudioDetectiveFingerprintNewFromString": (Ref, [C.c_char_p]),
     # ---- frame (Fr.h) ----
     "LBAudioDetectiveFrameNew": (Ref, [UInt32]),
     "LBAudioDetectiveFrameDispose": (None, [Ref]),
@@ -89,6 +92,9 @@ _SIGNATURES = {
     "LBAudioDetectiveFrameExtractFingerprint": (None, [Ref, UInt32, C.c_void_p]),
     "LBAudioDetectiveFrameEqualToFrame": (Boolean, [Ref, Ref]),
     # ---- additions ----
+    "LBAudioDetectiveSetFileHopMode": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveReadAudioURL": (OSStatus, [C.c_char_p, Float64, _P(_P(Float32)), _P(UInt64), _P(Float64)]),
+    "LBAudioDetectiveFreeSamples": (None, [_P(Float32)]),
     "LBAudioDetectiveGetSubfingerprintCount": (UInt64, [Ref, UInt64]),
     "LBAudioDetectiveProcessPCM": (OSStatus, [Ref, C.c_void_p, UInt64, _P(Ref)]),
     "LBAudioDetectiveComparePCM": (OSStatus, [Ref, C.c_void_p, UInt64, C.c_void_p, UInt64, UInt32, _P(Float32)]),
@@ -113,6 +119,8 @@ _SIGNATURES = {
     "LBAudioDetectiveCorpusDecodeKey": (None, [UInt64, _P(SInt64), _P(Float32)]),
     "LBAudioDetectiveCorpusScoresDevice": (OSStatus, [Ref, Ref, UInt32, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveCorpusSetKernelVariant": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveCorpusSave": (OSStatus, [Ref, C.c_char_p]),
+    "LBAudioDetectiveCorpusLoad": (Ref, [C.c_char_p, UInt64]),
     "LBAudioDetectiveSynthClipsDevice": (OSStatus, [UInt32, UInt64, UInt64, UInt32, UInt32, UInt32, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveSynthCorpusDevice": (OSStatus, [UInt32, UInt64, UInt64, UInt32, UInt32, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveDeviceCount": (SInt32, []),

@@ -148,7 +148,17 @@ class Fingerprint:
 
     def to_string(self) -> str:
         """'0'/'1' per Boolean, sub-fingerprints joined by '+' (LBAudioDetectiveTests.m:22-37)."""
-        return "+".join("".join(str(int(v)) for v in row) for row in self.to_bools())
+        n = int(self._L.LBAudioDetectiveFingerprintGetStringLength(self._ref))
+        buf = C.create_string_buffer(n + 1)
+        self._L.LBAudioDetectiveFingerprintGetString(self._ref, buf, n + 1)
+        return buf.value.decode()
+
+    @classmethod
+    def from_string(cls, text: str) -> "Fingerprint":
+        ref = N.lib().LBAudioDetectiveFingerprintNewFromString(text.encode())
+        if not ref:
+            raise ValueError("malformed fingerprint string")
+        return cls(_ref=ref)
 
 
 class Frame:
@@ -277,6 +287,10 @@ class Detective:
     def subfingerprint_count(self, n_samples: int) -> int:
         return int(self._L.LBAudioDetectiveGetSubfingerprintCount(self._ref, n_samples))
 
+    def set_file_hop_mode(self, mode: int):
+        """0: hop in processing-rate samples; 1: upstream's file-frame hop."""
+        _check(self._L.LBAudioDetectiveSetFileHopMode(self._ref, mode), "SetFileHopMode")
+
     # file entry points (D.h:218,235)
     def process_audio_url(self, path: str) -> Fingerprint:
         out = N.Ref()
@@ -341,9 +355,10 @@ class Detective:
 class Corpus:
     """LBAudioDetectiveCorpusRef: device-resident reference fingerprints with a top-1 query."""
 
-    def __init__(self, subfingerprint_length: int, subfingerprints_per_entry: int, capacity: int):
+    def __init__(self, subfingerprint_length: int, subfingerprints_per_entry: int, capacity: int, _ref=None):
         self._L = N.lib()
-        self._ref = self._L.LBAudioDetectiveCorpusNew(subfingerprint_length, subfingerprints_per_entry, capacity)
+        self._ref = _ref if _ref is not None else self._L.LBAudioDetectiveCorpusNew(
+            subfingerprint_length, subfingerprints_per_entry, capacity)
         if not self._ref:
             raise LBAudioDetectiveError(1, "CorpusNew (unsupported shape, zero capacity or no HIP device)")
         self.subfingerprint_length = subfingerprint_length
@@ -363,6 +378,17 @@ class Corpus:
 
     def __len__(self) -> int:
         return int(self._L.LBAudioDetectiveCorpusGetCount(self._ref))
+
+    def save(self, path: str):
+        _check(self._L.LBAudioDetectiveCorpusSave(self._ref, path.encode()), "CorpusSave")
+
+    @classmethod
+    def load(cls, path: str, subfingerprint_length: int, subfingerprints_per_entry: int, capacity: int = 0) -> "Corpus":
+        ref = N.lib().LBAudioDetectiveCorpusLoad(path.encode(), capacity)
+        if not ref:
+            raise LBAudioDetectiveError(1, "CorpusLoad (missing/malformed file or no HIP device)")
+        c = cls(subfingerprint_length, subfingerprints_per_entry, capacity, _ref=ref)
+        return c
 
     @property
     def entry_stride_bytes(self) -> int:
@@ -404,6 +430,18 @@ class Corpus:
         idx, score = N.SInt64(-1), N.Float32(0.0)
         N.lib().LBAudioDetectiveCorpusDecodeKey(key & 0xFFFFFFFFFFFFFFFF, C.byref(idx), C.byref(score))
         return int(idx.value), float(score.value)
+
+
+def read_audio_url(path: str, sample_rate: float = 0.0):
+    """Decode a CAF/WAV file to mono float32 (numpy), optionally resampled; returns (samples, rate)."""
+    buf, n, rate = C.POINTER(N.Float32)(), N.UInt64(0), N.Float64(0.0)
+    _check(N.lib().LBAudioDetectiveReadAudioURL(path.encode(), float(sample_rate), C.byref(buf), C.byref(n),
+                                                C.byref(rate)), "ReadAudioURL")
+    try:
+        out = np.ctypeslib.as_array(buf, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+    finally:
+        N.lib().LBAudioDetectiveFreeSamples(buf)
+    return out, float(rate.value)
 
 
 def synth_clips_device(seed: int, first: int, n_clips: int, sample_rate_hz: int, n_samples: int,

@@ -142,6 +142,58 @@ OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef c, LBAudio
     return lbad::run_query(c, inQuery, inRange, 0, outScores, c->d_key, static_cast<hipStream_t>(inStream));
 }
 
+// ---- corpus file: header + the planes of the stored entries, plane-major ----------------------------
+namespace {
+struct CorpusFileHeader {
+    char magic[8];            // "LBADCRP1"
+    uint32_t subfp_len, n_sub, n_planes, reserved;
+    uint64_t count;
+};
+}  // namespace
+
+OSStatus LBAudioDetectiveCorpusSave(LBAudioDetectiveCorpusRef c, const char* inPath) {
+    if (!c || !inPath) return kLBAudioDetectiveArgumentInvalid;
+    FILE* f = std::fopen(inPath, "wb");
+    if (!f) return -43;
+    CorpusFileHeader h;
+    std::memcpy(h.magic, "LBADCRP1", 8);
+    h.subfp_len = c->subfp_len; h.n_sub = c->n_sub; h.n_planes = c->n_planes; h.reserved = 0; h.count = c->count;
+    OSStatus st = std::fwrite(&h, sizeof(h), 1, f) == 1 ? noErr : kLBAudioDetectiveDeviceError;
+    std::vector<uint4> host(c->count);
+    for (uint32_t p = 0; p < c->n_planes && st == noErr && c->count; ++p) {
+        st = lbad::hip_status(hipMemcpy(host.data(), c->d_planes + (size_t)p * c->capacity, c->count * sizeof(uint4),
+                                        hipMemcpyDeviceToHost), "corpus plane D2H", __LINE__);
+        if (st == noErr && std::fwrite(host.data(), sizeof(uint4), c->count, f) != c->count) st = kLBAudioDetectiveDeviceError;
+    }
+    std::fclose(f);
+    return st;
+}
+
+LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 inCapacity) {
+    if (!inPath) return NULL;
+    FILE* f = std::fopen(inPath, "rb");
+    if (!f) return NULL;
+    CorpusFileHeader h;
+    LBAudioDetectiveCorpusRef c = NULL;
+    if (std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "LBADCRP1", 8) == 0 &&
+        h.n_planes == lbad::planes_per_entry(h.subfp_len, h.n_sub)) {
+        const uint64_t cap = inCapacity > h.count ? inCapacity : (h.count ? h.count : 1);
+        c = LBAudioDetectiveCorpusNew(h.subfp_len, h.n_sub, cap);
+        std::vector<uint4> host(h.count);
+        for (uint32_t p = 0; c && p < h.n_planes && h.count; ++p) {
+            if (std::fread(host.data(), sizeof(uint4), h.count, f) != h.count ||
+                lbad::hip_status(hipMemcpy(c->d_planes + (size_t)p * c->capacity, host.data(), h.count * sizeof(uint4),
+                                           hipMemcpyHostToDevice), "corpus plane H2D", __LINE__) != noErr) {
+                LBAudioDetectiveCorpusDispose(c);
+                c = NULL;
+            }
+        }
+        if (c) c->count = h.count;
+    }
+    std::fclose(f);
+    return c;
+}
+
 OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef inQuery, UInt32 inRange,
                                      SInt64* outIndex, Float32* outScore) {
     if (!c) return kLBAudioDetectiveArgumentInvalid;

@@ -4,6 +4,7 @@
 #include "audiofile.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace lbad {
@@ -330,21 +331,81 @@ OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef d, const Float32* inSamp
     return st;
 }
 
-OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL,
-                                         LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
-    if (!inFileURL) return kLBAudioDetectiveArgumentInvalid;  // :211-214
+static OSStatus read_url(LBAudioDetectiveURLRef inFileURL, std::vector<float>& mono, double& rate) {
 #ifdef __OBJC__
     const char* path = [[inFileURL path] fileSystemRepresentation];
 #else
     const char* path = inFileURL;
 #endif
-    std::vector<float> mono;
-    double rate = 0.0;
     const lbad::AudioFileStatus fs = lbad::read_audio_file(path, mono, rate);
     if (fs == lbad::AudioFileStatus::NotFound) return -43;  // fnfErr, what ExtAudioFileOpenURL reports
     if (fs != lbad::AudioFileStatus::Ok) return kLBAudioDetectiveUnsupportedFile;
-    if (std::fabs(rate - d->format.mSampleRate) > 1e-6 * rate) return kLBAudioDetectiveUnsupportedFile;  // no resampler yet
-    return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef d, UInt32 inMode) {
+    if (!d || inMode > 1) return kLBAudioDetectiveArgumentInvalid;
+    d->hop_mode = inMode;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
+                                      UInt64* outCount, Float64* outSampleRate) {
+    if (!inFileURL || !outSamples || !outCount) return kLBAudioDetectiveArgumentInvalid;
+    std::vector<float> mono, conv;
+    double rate = 0.0;
+    OSStatus st = read_url(inFileURL, mono, rate);
+    if (st != noErr) return st;
+    const std::vector<float>* src = &mono;
+    if (inSampleRate > 0.0 && std::fabs(inSampleRate - rate) > 1e-9 * rate) {
+        lbad::resample(mono, rate, inSampleRate, conv);
+        src = &conv;
+        rate = inSampleRate;
+    }
+    Float32* buf = static_cast<Float32*>(std::malloc(sizeof(Float32) * (src->size() ? src->size() : 1)));
+    if (!buf) return kLBAudioDetectiveArgumentInvalid;
+    std::memcpy(buf, src->data(), sizeof(Float32) * src->size());
+    *outSamples = buf;
+    *outCount = src->size();
+    if (outSampleRate) *outSampleRate = rate;
+    return noErr;
+}
+
+void LBAudioDetectiveFreeSamples(Float32* inSamples) { std::free(inSamples); }
+
+OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL,
+                                         LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
+    if (!inFileURL) return kLBAudioDetectiveArgumentInvalid;  // :211-214
+    std::vector<float> file, mono;
+    double file_rate = 0.0;
+    OSStatus st = read_url(inFileURL, file, file_rate);
+    if (st != noErr) return st;
+    const double rate = d->format.mSampleRate;
+    if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
+    // ExtAudioFile converts to the client format (:229); here: decode on the host, then resample
+    lbad::resample(file, file_rate, rate, mono);
+    if (d->hop_mode == 0 || std::fabs(file_rate - rate) <= 1e-9 * rate)
+        return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
+
+    // hop_mode 1 -- what upstream actually does with a file whose rate differs from the processing
+    // rate: the length (:236) and the seek offsets (:287-288) are in FILE frames while each
+    // read returns windowSize CLIENT frames, so the hop is analysisStride file frames =
+    // analysisStride * rate / file_rate client samples and the window count comes from the file length.
+    const uint64_t file_frames = file.size();
+    if (d->stride == 0 || file_frames < d->window) return LBAudioDetectiveProcessPCM(d, mono.data(), 0, outFingerprint);
+    const uint64_t image_width = (file_frames - d->window) / d->stride;                    // :250
+    const uint64_t frames = image_width / lbad::kRowsPerFrame;                              // :255
+    uint32_t hop = (uint32_t)std::llround((double)d->stride * rate / file_rate);
+    if (hop < 1) hop = 1;
+    // windows that start near the end of the file read short upstream and keep stale buffer contents;
+    // here the stream is zero-padded instead
+    const uint64_t need = frames * lbad::kRowsPerFrame * hop + d->window;
+    mono.resize(need > mono.size() ? need : mono.size(), 0.0f);
+    const uint32_t saved = d->stride;
+    d->stride = hop;
+    st = LBAudioDetectiveProcessPCM(d, mono.data(), need, outFingerprint);
+    d->stride = saved;
+    return st;
 }
 
 OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL1,

@@ -79,6 +79,49 @@ Boolean LBAudioDetectiveFingerprintEqualToFingerprint(LBAudioDetectiveFingerprin
     return std::memcmp(a->data.data(), b->data.data(), a->data.size()) == 0 ? 1 : 0;
 }
 
+// ---- wire format: '0'/'1' per Boolean, sub-fingerprints joined by '+' (the string the upstream test
+//      helper builds, LBAudioDetectiveTests.m:22-37, and the essay's client posts to its server) --------
+UInt64 LBAudioDetectiveFingerprintGetStringLength(LBAudioDetectiveFingerprintRef fp) {
+    if (!fp || fp->count == 0) return 0;
+    return (UInt64)fp->count * fp->length + (fp->count - 1);
+}
+
+UInt64 LBAudioDetectiveFingerprintGetString(LBAudioDetectiveFingerprintRef fp, char* outString, UInt64 inCapacity) {
+    const UInt64 need = LBAudioDetectiveFingerprintGetStringLength(fp);
+    if (!outString || inCapacity < need + 1) return need;
+    UInt64 at = 0;
+    for (uint32_t s = 0; s < fp->count; ++s) {
+        if (s) outString[at++] = '+';
+        for (uint32_t b = 0; b < fp->length; ++b)
+            outString[at++] = fp->data[(size_t)s * fp->length + b] ? '1' : '0';
+    }
+    outString[at] = 0;
+    return need;
+}
+
+LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNewFromString(const char* inString) {
+    if (!inString) return NULL;
+    LBAudioDetectiveFingerprint* fp = new LBAudioDetectiveFingerprint();
+    std::vector<Boolean> row;
+    auto flush = [&]() -> bool {
+        if (fp->count == 0) fp->length = (uint32_t)row.size();
+        if (row.size() != fp->length || row.empty()) return false;
+        fp->data.insert(fp->data.end(), row.begin(), row.end());
+        fp->count++;
+        row.clear();
+        return true;
+    };
+    if (*inString == 0) return fp;   // empty fingerprint
+    for (const char* c = inString;; ++c) {
+        if (*c == '0' || *c == '1') row.push_back(*c == '1');
+        else if (*c == '+' || *c == 0) {
+            if (!flush()) { delete fp; return NULL; }
+            if (*c == 0) break;
+        } else { delete fp; return NULL; }
+    }
+    return fp;
+}
+
 }  // extern "C"
 
 namespace lbad {

@@ -1,9 +1,10 @@
-// audiofile.cpp -- minimal file front end standing in for ExtAudioFile (LBAudioDetective.m:224-237):
-// uncompressed CAF ('lpcm') and RIFF/WAVE (PCM / IEEE float) -> mono float32 at the file's rate.
-// Compressed CAF payloads (the upstream bird fixtures are IMA4) and sample-rate conversion are
-// not implemented yet; callers get kLBAudioDetectiveUnsupportedFile.
+// audiofile.cpp -- file front end standing in for ExtAudioFile (LBAudioDetective.m:224-237): CAF with
+// 'lpcm' or 'ima4' (Apple IMA ADPCM, what the upstream bird fixtures use) payloads and RIFF/WAVE
+// (PCM / IEEE float) -> mono float32 at the file's rate; resample() converts to the processing
+// rate.  Host code, like the decoder it replaces; the fingerprint arithmetic stays on the GPU.
 #include "audiofile.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -62,6 +63,56 @@ bool decode_pcm(const uint8_t* data, size_t n_bytes, uint32_t channels, uint32_t
     return true;
 }
 
+// ---- Apple IMA4: 34-byte packets = 2-byte big-endian header (9-bit predictor, 7-bit step index) +
+//      64 4-bit codes, low nibble first (the published IMA/DVI ADPCM recurrence) ----------------------
+const int kImaIndex[16] = {-1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8};
+const int kImaStep[89] = {7,     8,     9,     10,    11,    12,    13,    14,    16,    17,    19,    21,    23,
+                          25,    28,    31,    34,    37,    41,    45,    50,    55,    60,    66,    73,    80,
+                          88,    97,    107,   118,   130,   143,   157,   173,   190,   209,   230,   253,   279,
+                          307,   337,   371,   408,   449,   494,   544,   598,   658,   724,   796,   876,   963,
+                          1060,  1166,  1282,  1411,  1552,  1707,  1878,  2066,  2272,  2499,  2749,  3024,  3327,
+                          3660,  4026,  4428,  4871,  5358,  5894,  6484,  7132,  7845,  8630,  9493,  10442, 11487,
+                          12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767};
+
+bool decode_ima4(const uint8_t* data, size_t n_bytes, uint32_t channels, int64_t valid_frames, int32_t priming,
+                 std::vector<float>& out) {
+    if (channels == 0) return false;
+    const size_t packets = n_bytes / (34 * (size_t)channels);   // packets are interleaved per channel
+    std::vector<float> acc(packets * 64, 0.0f);
+    for (size_t p = 0; p < packets; ++p) {
+        for (uint32_t c = 0; c < channels; ++c) {
+            const uint8_t* pk = data + (p * channels + c) * 34;
+            const int header = (pk[0] << 8) | pk[1];
+            int predictor = (int16_t)(header & 0xFF80);
+            int index = header & 0x7F;
+            if (index > 88) index = 88;
+            for (int i = 0; i < 64; ++i) {
+                const int nib = (i & 1) ? (pk[2 + (i >> 1)] >> 4) : (pk[2 + (i >> 1)] & 0x0F);
+                const int step = kImaStep[index];
+                int diff = step >> 3;
+                if (nib & 4) diff += step;
+                if (nib & 2) diff += step >> 1;
+                if (nib & 1) diff += step >> 2;
+                predictor += (nib & 8) ? -diff : diff;
+                if (predictor > 32767) predictor = 32767;
+                if (predictor < -32768) predictor = -32768;
+                index += kImaIndex[nib];
+                if (index < 0) index = 0;
+                if (index > 88) index = 88;
+                acc[p * 64 + i] += (float)predictor / 32768.0f;
+            }
+        }
+    }
+    if (channels > 1)
+        for (float& v : acc) v /= (float)channels;
+    size_t first = priming > 0 ? (size_t)priming : 0;
+    if (first > acc.size()) first = acc.size();
+    size_t count = acc.size() - first;
+    if (valid_frames > 0 && (size_t)valid_frames < count) count = (size_t)valid_frames;   // 'pakt' trims the tail
+    out.assign(acc.begin() + first, acc.begin() + first + count);
+    return true;
+}
+
 }  // namespace
 
 AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, double& sample_rate) {
@@ -81,8 +132,10 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
 
     if (std::memcmp(p, "caff", 4) == 0) {
         size_t at = 8;
-        bool have_desc = false, is_float = false, little = false;
+        bool have_desc = false, is_float = false, little = false, ima4 = false;
         uint32_t channels = 0, bits = 0;
+        int64_t valid_frames = -1;
+        int32_t priming = 0;
         while (at + 12 <= n) {
             const uint8_t* ch = p + at;
             const int64_t csz = (int64_t)be64(ch + 4);
@@ -91,15 +144,24 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
             if (body + len > n) len = n - body;
             if (std::memcmp(ch, "desc", 4) == 0 && len >= 32) {
                 sample_rate = be_f64(p + body);
-                if (std::memcmp(p + body + 8, "lpcm", 4) != 0) return AudioFileStatus::Unsupported;
+                ima4 = std::memcmp(p + body + 8, "ima4", 4) == 0;
+                if (!ima4 && std::memcmp(p + body + 8, "lpcm", 4) != 0) return AudioFileStatus::Unsupported;
+                if (ima4 && (be32(p + body + 20) != 64 || be32(p + body + 16) != 34u * be32(p + body + 24)))
+                    return AudioFileStatus::Unsupported;
                 const uint32_t flags = be32(p + body + 12);
                 is_float = flags & 1u;
                 little = flags & 2u;
                 channels = be32(p + body + 24);
                 bits = be32(p + body + 28);
                 have_desc = true;
+            } else if (std::memcmp(ch, "pakt", 4) == 0 && len >= 24) {
+                valid_frames = (int64_t)be64(p + body + 8);     // mNumberValidFrames
+                priming = (int32_t)be32(p + body + 16);          // mPrimingFrames
             } else if (std::memcmp(ch, "data", 4) == 0) {
                 if (!have_desc || len < 4) return AudioFileStatus::Unsupported;
+                if (ima4)
+                    return decode_ima4(p + body + 4, len - 4, channels, valid_frames, priming, mono)
+                               ? AudioFileStatus::Ok : AudioFileStatus::Unsupported;
                 return decode_pcm(p + body + 4, len - 4, channels, bits, is_float, little, mono)
                            ? AudioFileStatus::Ok : AudioFileStatus::Unsupported;
             }
@@ -147,6 +209,62 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
         return AudioFileStatus::Unsupported;
     }
     return AudioFileStatus::Unsupported;
+}
+
+
+// ---- sample-rate conversion -------------------------------------------------------------------------
+// Apple's converter is closed source; this is a documented stand-in: band-limited interpolation with
+// a Kaiser-windowed sinc (beta 9, 24 zero crossings each side at the lower of the two rates, cut-off
+// 0.92 of the lower Nyquist), evaluated in double precision at position n * rate_in / rate_out for
+// output sample n and normalised to unit DC gain per output sample.
+namespace {
+double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-17 * sum) break;
+    }
+    return sum;
+}
+}  // namespace
+
+void resample(const std::vector<float>& in, double rate_in, double rate_out, std::vector<float>& out) {
+    if (in.empty() || !(rate_in > 0.0) || !(rate_out > 0.0)) { out.clear(); return; }
+    if (rate_in == rate_out) { out = in; return; }
+    const double ratio = rate_in / rate_out;                 // input samples per output sample
+    const double scale = ratio > 1.0 ? ratio : 1.0;          // kernel is stretched when decimating
+    const double cutoff = 0.92;
+    const int zero_crossings = 24;
+    const double beta = 9.0, i0b = bessel_i0(beta);
+    // kernel sampled 2048 times per unit of t in [0, zero_crossings], read with linear interpolation
+    const int res = 2048;
+    std::vector<double> table((size_t)zero_crossings * res + 2);
+    for (size_t i = 0; i < table.size(); ++i) {
+        const double t = (double)i / res;
+        const double u = t / zero_crossings;
+        const double win = u < 1.0 ? bessel_i0(beta * std::sqrt(1.0 - u * u)) / i0b : 0.0;
+        const double a = M_PI * cutoff * t;
+        table[i] = cutoff * (a < 1e-12 ? 1.0 : std::sin(a) / a) * win;
+    }
+    const double half = zero_crossings * scale;              // kernel half-width in input samples
+    const uint64_t n_out = (uint64_t)((double)in.size() / ratio);
+    out.resize(n_out);
+    for (uint64_t n = 0; n < n_out; ++n) {
+        const double pos = (double)n * ratio;
+        const long k0 = (long)std::ceil(pos - half), k1 = (long)std::floor(pos + half);
+        double acc = 0.0, wsum = 0.0;
+        for (long k = k0; k <= k1; ++k) {
+            const double t = std::fabs(((double)k - pos) / scale) * res;   // table coordinate
+            const size_t i = (size_t)t;
+            if (i + 1 >= table.size()) continue;
+            const double w = table[i] + (table[i + 1] - table[i]) * (t - (double)i);
+            wsum += w;
+            if (k >= 0 && (size_t)k < in.size()) acc += w * (double)in[(size_t)k];
+        }
+        out[n] = (float)(wsum != 0.0 ? acc / wsum : 0.0);
+    }
 }
 
 }  // namespace lbad

@@ -128,6 +128,7 @@ struct LBAudioDetective {
     uint32_t stride;
     uint32_t bands;
     uint32_t variant = 0;
+    uint32_t hop_mode = 0;   // file entry points: 0 = hop in processing-rate samples, 1 = upstream's file-frame hop
     lbad::Plan plan;         // lazily rebuilt when the configuration changes
     float* d_frames = nullptr;  // frame rows between stage 1 and stage 2
     uint64_t d_frames_cap = 0;  // in floats

@@ -1,0 +1,135 @@
+"""CPU tests of the file front end (decode + resample run on the host, like the ExtAudioFile code they
+replace) and of the fingerprint wire format."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+BIRDS = os.path.join(os.path.dirname(__file__), "golden", "birds")
+
+_STEP = [7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45, 50, 55, 60, 66, 73, 80, 88, 97,
+         107, 118, 130, 143, 157, 173, 190, 209, 230, 253, 279, 307, 337, 371, 408, 449, 494, 544, 598, 658, 724, 796,
+         876, 963, 1060, 1166, 1282, 1411, 1552, 1707, 1878, 2066, 2272, 2499, 2749, 3024, 3327, 3660, 4026, 4428, 4871,
+         5358, 5894, 6484, 7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623,
+         27086, 29794, 32767]
+_IDX = [-1, -1, -1, -1, 2, 4, 6, 8] * 2
+
+
+def _caf_chunks(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"caff"
+    at, out = 8, {}
+    while at + 12 <= len(b):
+        size = struct.unpack(">q", b[at + 4:at + 12])[0]
+        body = at + 12
+        ln = len(b) - body if size < 0 else size
+        out[b[at:at + 4]] = b[body:body + ln]
+        at = body + ln
+    return out
+
+
+def _ima4_python(path, limit_packets=400):
+    """Independent decoder of the published IMA ADPCM recurrence (first packets only: it is a slow loop)."""
+    ch = _caf_chunks(path)
+    data = ch[b"data"][4:]
+    out = []
+    for p in range(min(limit_packets, len(data) // 34)):
+        pk = data[34 * p:34 * p + 34]
+        head = (pk[0] << 8) | pk[1]
+        pred = head & 0xFF80
+        pred = pred - 65536 if pred >= 32768 else pred
+        idx = min(head & 0x7F, 88)
+        for i in range(64):
+            byte = pk[2 + i // 2]
+            nib = (byte >> 4) if i & 1 else (byte & 15)
+            step = _STEP[idx]
+            diff = step >> 3
+            if nib & 4: diff += step
+            if nib & 2: diff += step >> 1
+            if nib & 1: diff += step >> 2
+            pred = max(-32768, min(32767, pred - diff if nib & 8 else pred + diff))
+            idx = max(0, min(88, idx + _IDX[nib]))
+            out.append(pred)
+    return np.array(out, np.float32) / np.float32(32768)
+
+
+def test_ima4_decode_matches_independent_decoder(lb):
+    path = os.path.join(BIRDS, "BlackBird.caf")
+    got, rate = lb.read_audio_url(path)
+    assert rate == 44100.0
+    desc = struct.unpack(">d4sIIIII", _caf_chunks(path)[b"desc"])
+    assert desc[1] == b"ima4" and desc[3:5] == (34, 64)
+    valid = struct.unpack(">qqii", _caf_chunks(path)[b"pakt"])[1]
+    assert got.size == valid == 397046                     # 397 046 valid frames
+    want = _ima4_python(path)
+    assert np.array_equal(got[:want.size], want)
+    assert 0.05 < float(np.sqrt(np.mean(got ** 2))) < 0.3 and float(np.abs(got).max()) < 1.0
+    assert lb.read_audio_url(os.path.join(BIRDS, "BlackBird_eql.caf"))[0].size == 177455
+
+
+def test_lpcm_containers(lb, tmp_path):
+    rng = np.random.default_rng(4)
+    x = rng.integers(-2**31, 2**31 - 1, 1000, dtype=np.int64).astype(np.int32)
+
+    def caf_int32_le(path):                                 # layout of the upstream *_rec.caf fixtures
+        desc = struct.pack(">d4sIIIII", 44100.0, b"lpcm", 2, 4, 1, 1, 32)
+        data = struct.pack(">I", 0) + x.astype("<i4").tobytes()
+        with open(path, "wb") as f:
+            f.write(b"caff" + struct.pack(">HH", 1, 0) + b"desc" + struct.pack(">q", len(desc)) + desc)
+            f.write(b"free" + struct.pack(">q", 16) + bytes(16) + b"data" + struct.pack(">q", -1) + data)
+
+    p = str(tmp_path / "rec.caf")
+    caf_int32_le(p)
+    got, rate = lb.read_audio_url(p)
+    assert rate == 44100.0 and np.array_equal(got, (x.astype(np.float64) / 2**31).astype(np.float32))
+
+    stereo = np.stack([np.arange(100), -np.arange(100)], axis=1).astype("<i2")        # L + R cancel
+    pcm = stereo.tobytes()
+    w = str(tmp_path / "st.wav")
+    with open(w, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 8000, 32000, 4, 16))
+        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+    got, rate = lb.read_audio_url(w)
+    assert rate == 8000.0 and got.size == 100 and not got.any()                       # channels averaged to mono
+
+
+def test_resampler(lb, tmp_path):
+    def wav_f32(path, x, rate):
+        pcm = x.astype("<f4").tobytes()
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 3, 1, rate, rate * 4, 4, 32))
+            f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+    n, fs, fo = 44100, 44100, 5512
+    t = np.arange(n) / fs
+    p = str(tmp_path / "tone.wav")
+    wav_f32(p, 0.5 * np.sin(2 * np.pi * 440 * t), fs)
+    y, rate = lb.read_audio_url(p, fo)
+    assert rate == fo and y.size == int(n * fo / fs)
+    k = np.arange(y.size)
+    want = 0.5 * np.sin(2 * np.pi * 440 * k / fo)
+    core = slice(200, y.size - 200)                          # away from the zero-padded edges
+    assert np.abs(y[core] - want[core]).max() < 2e-4        # pass band: band-limited interpolation is exact
+    wav_f32(p, 0.5 * np.sin(2 * np.pi * 4000 * t), fs)       # above the new Nyquist (2756 Hz)
+    y, _ = lb.read_audio_url(p, fo)
+    assert np.abs(y[core]).max() < 0.5 * 10 ** (-70 / 20)    # > 70 dB down: no audible alias
+    wav_f32(p, np.full(n, 0.25), fs)
+    y, _ = lb.read_audio_url(p, fo)
+    assert np.abs(y[core] - 0.25).max() < 1e-6               # unit DC gain
+    y, rate = lb.read_audio_url(p, fs)
+    assert rate == fs and np.array_equal(y, np.full(n, 0.25, np.float32))   # same rate: untouched
+
+
+def test_fingerprint_string_round_trip(lb):
+    rng = np.random.default_rng(8)
+    rows = rng.integers(0, 2, (4, 200)).astype(np.uint8)
+    fp = lb.Fingerprint.from_bools(rows)
+    text = fp.to_string()
+    assert text == "+".join("".join(map(str, r)) for r in rows)          # LBAudioDetectiveTests.m:22-37
+    back = lb.Fingerprint.from_string(text)
+    assert back.equal_to_fingerprint(fp)
+    assert lb.Fingerprint(0).to_string() == "" and lb.Fingerprint.from_string("").number_of_subfingerprints == 0
+    for bad in ("01+0", "01a", "+01", "01++10"):
+        with pytest.raises(ValueError):
+            lb.Fingerprint.from_string(bad)

@@ -487,3 +487,57 @@ def test_full_size_corpus(lb, gpu, oracle, n):
     # scores elsewhere sit at chance level (essay p.43): sample the score vector
     scores = corpus.scores_device(fq, 200)[:: max(1, n // 4096)].cpu().numpy()
     assert 0.45 < float(np.median(scores)) < 0.55
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE configs[0]: bundled bird fixtures through LBAudioDetectiveCompareAudioURLs
+# ---------------------------------------------------------------------------------------------
+BIRDS = os.path.join(os.path.dirname(__file__), "golden", "birds")
+
+
+@pytest.mark.parametrize("hop_mode", [0, 1])
+def test_bird_fixtures_compare_audio_urls(lb, gpu, oracle, hop_mode):
+    """Upstream Test 1 in miniature (LBAudioDetectiveTests.m:95-97): the 4 s crop of the blackbird
+    must match its 9 s original far better than another bird does.  Defaults (5512 Hz / 2048 / 64).
+    The GPU result equals the oracle run on the same decoded + resampled PCM."""
+    det = lb.Detective()
+    det.set_file_hop_mode(hop_mode)
+    orig = os.path.join(BIRDS, "BlackBird.caf")
+    same = os.path.join(BIRDS, "BlackBird_eql.caf")
+    other = os.path.join(BIRDS, "Sparrow_eql.caf")
+    f_orig, f_same = det.process_audio_url(orig), det.process_audio_url(same)
+    if hop_mode == 1:
+        # SURVEY Q17: 397 046 file frames -> 6171 windows -> 48 sub-fingerprints; 177 455 -> 2740 -> 21
+        assert (f_orig.number_of_subfingerprints, f_same.number_of_subfingerprints) == (48, 21)
+    else:
+        assert (f_orig.number_of_subfingerprints, f_same.number_of_subfingerprints) == (5, 2)
+    m_same = det.compare_audio_urls(orig, same, 0)
+    m_other = det.compare_audio_urls(orig, other, 0)
+    assert m_same > m_other + 0.1 and m_same > 0.6 and 0.4 < m_other < 0.62      # chance level ~0.5 (essay p.43)
+    # parity of the whole file path against the oracle on identical PCM
+    cfg = oracle.Config()
+    pcm, rate = lb.read_audio_url(orig, 5512)
+    if hop_mode == 0:
+        want = oracle.fingerprint_pcm(pcm, cfg)
+    else:
+        cfg.stride = 8                                    # 64 file frames = 64 * 5512 / 44100 ~ 8 samples
+        need = 48 * 128 * 8 + 2048
+        want = oracle.fingerprint_pcm(np.concatenate([pcm, np.zeros(max(0, need - pcm.size), np.float32)])[:need], cfg)
+    assert np.array_equal(f_orig.to_bools(), want)
+    assert det.analysis_stride == 64                       # the emulation does not leak into the settings
+
+
+def test_corpus_save_load(lb, gpu, oracle, tmp_path):
+    n = 5000
+    corpus = lb.Corpus(200, 5, n + 100)
+    corpus.append_packed_device(lb.synth_corpus_device(CSEED, 0, n, 5, 200))
+    path = str(tmp_path / "birds.lbadcorpus")
+    corpus.save(path)
+    assert os.path.getsize(path) == 32 + n * 128
+    again = lb.Corpus.load(path, 200, 5)
+    assert len(again) == n
+    q = lb.Fingerprint.from_bools(_planted_query(oracle, oracle.synth_entry(CSEED, 4321, 5, 200), 0.05))
+    assert again.query(q) == corpus.query(q) and corpus.query(q)[0] == 4321
+    assert gpu.equal(again.scores_device(q), corpus.scores_device(q))
+    with pytest.raises(lb.LBAudioDetectiveError):
+        lb.Corpus.load(str(tmp_path / "missing"), 200, 5)
