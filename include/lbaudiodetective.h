@@ -206,6 +206,12 @@ OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef inDetective, const Float
 OSStatus LBAudioDetectiveFingerprintClipsDevice(LBAudioDetectiveRef inDetective, const Float32* inClips,
                                                 UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
                                                 void* outPacked, void* inStream);
+/* Same with integer PCM: inSampleFormat 0 = float32, 1 = int16 (sample / 32768), 2 = int32
+ * (sample / 2^31).  The conversion LBAudioDetectiveConvertToFormat (LBAudioDetective.m:413-437) hands
+ * to AudioConverter is fused into the kernels' PCM load; int16 input halves the HBM read traffic. */
+OSStatus LBAudioDetectiveFingerprintClipsDeviceFormat(LBAudioDetectiveRef inDetective, const void* inClips,
+                                                      UInt32 inSampleFormat, UInt64 inNumberOfClips,
+                                                      UInt64 inSamplesPerClip, void* outPacked, void* inStream);
 /* Same, host buffers in and unpacked Booleans out (count x subfingerprintLength per clip). */
 OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef inDetective, const Float32* inClips,
                                           UInt64 inNumberOfClips, UInt64 inSamplesPerClip, Boolean* outBooleans);
@@ -229,6 +235,18 @@ OSStatus LBAudioDetectiveFingerprintClipsDeviceTaps(LBAudioDetectiveRef inDetect
                                                     UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
                                                     void* outPacked, Float32* outFramesRaw, Float32* outFramesHaar,
                                                     void* inStream);
+
+/* Streaming (the essay's live-recording use): PCM arrives in chunks of any size; whenever the
+ * buffered samples complete one or more frames they are fingerprinted and appended, and the partial
+ * frame is carried to the next call.  After pushing L samples in total the fingerprint equals
+ * LBAudioDetectiveProcessPCM on those L samples.  The detective's settings must not change while a
+ * stream is open. */
+typedef struct LBAudioDetectiveStream* LBAudioDetectiveStreamRef;
+LBAudioDetectiveStreamRef LBAudioDetectiveStreamNew(LBAudioDetectiveRef inDetective);
+void LBAudioDetectiveStreamDispose(LBAudioDetectiveStreamRef inStream);
+OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef inStream, const Float32* inSamples,
+                                    UInt64 inNumberOfSamples, UInt32* outNewSubfingerprints);
+LBAudioDetectiveFingerprintRef LBAudioDetectiveStreamCopyFingerprint(LBAudioDetectiveStreamRef inStream);
 
 /* Boolean <-> packed conversion on the host (no arithmetic). */
 void LBAudioDetectivePackSubfingerprint(const Boolean* inBooleans, UInt32 inLength, UInt32* outWords);

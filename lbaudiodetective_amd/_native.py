@@ -99,6 +99,11 @@ _SIGNATURES = {
     "LBAudioDetectiveProcessPCM": (OSStatus, [Ref, C.c_void_p, UInt64, _P(Ref)]),
     "LBAudioDetectiveComparePCM": (OSStatus, [Ref, C.c_void_p, UInt64, C.c_void_p, UInt64, UInt32, _P(Float32)]),
     "LBAudioDetectiveFingerprintClipsDevice": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, C.c_void_p, C.c_void_p]),
+    "LBAudioDetectiveFingerprintClipsDeviceFormat": (OSStatus, [Ref, C.c_void_p, UInt32, UInt64, UInt64, C.c_void_p, C.c_void_p]),
+    "LBAudioDetectiveStreamNew": (Ref, [Ref]),
+    "LBAudioDetectiveStreamDispose": (None, [Ref]),
+    "LBAudioDetectiveStreamPush": (OSStatus, [Ref, C.c_void_p, UInt64, _P(UInt32)]),
+    "LBAudioDetectiveStreamCopyFingerprint": (Ref, [Ref]),
     "LBAudioDetectiveFingerprintClips": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, C.c_void_p]),
     "LBAudioDetectiveSetKernelVariant": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveSetScratchLimit": (OSStatus, [Ref, UInt64]),

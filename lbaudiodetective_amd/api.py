@@ -333,15 +333,17 @@ class Detective:
         Asynchronous on the given (default: current) torch stream.  With taps=True also returns the
         128 x bands frames before and after the Haar (unfused kernels only)."""
         import torch
-        assert clips.is_cuda and clips.dtype == torch.float32 and clips.is_contiguous()
+        assert clips.is_cuda and clips.is_contiguous() and clips.dtype in (torch.float32, torch.int16, torch.int32)
+        assert not taps or clips.dtype == torch.float32
         n, spc = clips.shape
         per = self.subfingerprint_count(spc)
         if out is None:
             out = torch.empty((n, per, N.PACKED_BYTES), dtype=torch.uint8, device=clips.device)
         sp = _stream_ptr(stream)
         if not taps:
-            _check(self._L.LBAudioDetectiveFingerprintClipsDevice(self._ref, clips.data_ptr(), n, spc, out.data_ptr(), sp),
-                   "FingerprintClipsDevice")
+            fmt = {torch.float32: 0, torch.int16: 1, torch.int32: 2}[clips.dtype]
+            _check(self._L.LBAudioDetectiveFingerprintClipsDeviceFormat(self._ref, clips.data_ptr(), fmt, n, spc,
+                                                                       out.data_ptr(), sp), "FingerprintClipsDevice")
             return out
         bands = self.number_of_pitch_steps
         raw = torch.empty((n, per, N.ROWS_PER_FRAME, bands), dtype=torch.float32, device=clips.device)
@@ -350,6 +352,35 @@ class Detective:
                                                                  raw.data_ptr(), haar.data_ptr(), sp),
                "FingerprintClipsDeviceTaps")
         return out, raw, haar
+
+
+class Stream:
+    """LBAudioDetectiveStreamRef: chunked PCM in, partial frame carried across calls."""
+
+    def __init__(self, detective: Detective):
+        self._L = N.lib()
+        self._det = detective            # keep the detective alive
+        self._ref = self._L.LBAudioDetectiveStreamNew(detective._ref)
+
+    def dispose(self):
+        if self._ref:
+            self._L.LBAudioDetectiveStreamDispose(self._ref)
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
+
+    def push(self, samples) -> int:
+        x = _f32(samples).reshape(-1)
+        new = N.UInt32(0)
+        _check(self._L.LBAudioDetectiveStreamPush(self._ref, x.ctypes.data, x.size, C.byref(new)), "StreamPush")
+        return int(new.value)
+
+    def fingerprint(self) -> Fingerprint:
+        return Fingerprint(_ref=self._L.LBAudioDetectiveStreamCopyFingerprint(self._ref))
 
 
 class Corpus:

@@ -85,8 +85,11 @@ static OSStatus ensure_scratch(LBAudioDetective* d, uint64_t floats) {
 }
 
 // The batch hot path: every clip -> frames_per_clip packed sub-fingerprints.
-OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint64_t n_clips, uint64_t spc,
-                                  uint32_t* d_packed, float* d_raw, float* d_haar, hipStream_t stream) {
+OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, uint32_t fmt, uint64_t n_clips,
+                                  uint64_t spc, uint32_t* d_packed, float* d_raw, float* d_haar, hipStream_t stream) {
+    if (fmt > 2) return kLBAudioDetectiveArgumentInvalid;
+    const size_t elem = fmt == 1 ? 2 : 4;
+    const char* d_pcm = static_cast<const char*>(d_pcm_raw);
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
     const Plan& p = d->plan;
@@ -97,9 +100,9 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
     bool special = p.pruned_ok;
     if (d->variant == 1) special = false;
     if (d->variant == 2 && !special) return kLBAudioDetectiveArgumentInvalid;
-    auto stage1 = [&](const float* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
-        return special ? launch_rows_pruned(p, p.d_bin_const, pcm_in, nc, spc, (uint32_t)per, frames_out, stream)
-                       : launch_fft_bands(p, pcm_in, nc, spc, (uint32_t)per, frames_out, stream);
+    auto stage1 = [&](const void* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
+        return special ? launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream)
+                       : launch_fft_bands(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
     };
     const bool special2 = d->variant != 1 && haar_select32_supported(p);
     auto stage2 = [&](float* frames_in, uint64_t nf, uint32_t* packed_out, float* haar_out) -> hipError_t {
@@ -131,7 +134,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const float* d_pcm, uint6
     for (uint64_t c0 = 0; c0 < n_clips; c0 += chunk) {
         const uint64_t nc = (n_clips - c0) < chunk ? (n_clips - c0) : chunk;
         LBAD_HIP(mark());
-        LBAD_HIP(stage1(d_pcm + c0 * spc, nc, d->d_frames));
+        LBAD_HIP(stage1(d_pcm + c0 * spc * elem, nc, d->d_frames));
         LBAD_HIP(mark());
         LBAD_HIP(stage2(d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
                         d_haar ? d_haar + c0 * per * frame_floats : nullptr));
@@ -255,8 +258,17 @@ OSStatus LBAudioDetectiveFingerprintClipsDeviceTaps(LBAudioDetectiveRef d, const
                                                     UInt64 inSamplesPerClip, void* outPacked, Float32* outFramesRaw,
                                                     Float32* outFramesHaar, void* inStream) {
     if (!d || (!inClips && inNumberOfClips) || (!outPacked && inNumberOfClips)) return kLBAudioDetectiveArgumentInvalid;
-    return lbad::fingerprint_clips_device(d, inClips, inNumberOfClips, inSamplesPerClip,
+    return lbad::fingerprint_clips_device(d, inClips, 0, inNumberOfClips, inSamplesPerClip,
                                           static_cast<uint32_t*>(outPacked), outFramesRaw, outFramesHaar,
+                                          static_cast<hipStream_t>(inStream));
+}
+
+OSStatus LBAudioDetectiveFingerprintClipsDeviceFormat(LBAudioDetectiveRef d, const void* inClips, UInt32 inSampleFormat,
+                                                      UInt64 inNumberOfClips, UInt64 inSamplesPerClip, void* outPacked,
+                                                      void* inStream) {
+    if (!d || (!inClips && inNumberOfClips) || (!outPacked && inNumberOfClips)) return kLBAudioDetectiveArgumentInvalid;
+    return lbad::fingerprint_clips_device(d, inClips, inSampleFormat, inNumberOfClips, inSamplesPerClip,
+                                          static_cast<uint32_t*>(outPacked), nullptr, nullptr,
                                           static_cast<hipStream_t>(inStream));
 }
 
@@ -282,7 +294,7 @@ OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef d, const Float32* 
     std::vector<uint32_t> packed(n_sub * LBAD_PACKED_WORDS);
     if (st == noErr) st = lbad::hip_status(hipMemcpy(d_pcm, inClips, pcm_bytes, hipMemcpyHostToDevice), "copy pcm", __LINE__);
     if (st == noErr)
-        st = lbad::fingerprint_clips_device(d, d_pcm, inNumberOfClips, inSamplesPerClip, d_packed, nullptr, nullptr, nullptr);
+        st = lbad::fingerprint_clips_device(d, d_pcm, 0, inNumberOfClips, inSamplesPerClip, d_packed, nullptr, nullptr, nullptr);
     if (st == noErr)
         st = lbad::hip_status(hipMemcpy(packed.data(), d_packed, n_sub * LBAD_PACKED_BYTES, hipMemcpyDeviceToHost),
                               "copy packed", __LINE__);
@@ -420,6 +432,57 @@ OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, LBAudioDetectiv
     LBAudioDetectiveFingerprintDispose(fp1);
     LBAudioDetectiveFingerprintDispose(fp2);
     return st;
+}
+
+// ---- streaming: chunked PCM in, the partial frame is carried across calls -----------------------------
+struct LBAudioDetectiveStream {
+    LBAudioDetectiveRef detective;
+    std::vector<Float32> pending;          // starts at a frame boundary of the stream
+    LBAudioDetectiveFingerprintRef fingerprint;
+};
+
+LBAudioDetectiveStreamRef LBAudioDetectiveStreamNew(LBAudioDetectiveRef inDetective) {
+    if (!inDetective) return NULL;
+    LBAudioDetectiveStream* s = new LBAudioDetectiveStream();
+    s->detective = inDetective;
+    s->fingerprint = LBAudioDetectiveFingerprintNew(0);
+    return s;
+}
+
+void LBAudioDetectiveStreamDispose(LBAudioDetectiveStreamRef inStream) {
+    if (!inStream) return;
+    LBAudioDetectiveFingerprintDispose(inStream->fingerprint);
+    delete inStream;
+}
+
+OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef s, const Float32* inSamples, UInt64 inNumberOfSamples,
+                                    UInt32* outNewSubfingerprints) {
+    if (outNewSubfingerprints) *outNewSubfingerprints = 0;
+    if (!s || (!inSamples && inNumberOfSamples)) return kLBAudioDetectiveArgumentInvalid;
+    LBAudioDetective* d = s->detective;
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    s->pending.insert(s->pending.end(), inSamples, inSamples + inNumberOfSamples);
+    // same rule as the whole-buffer path (:250-255): frame f exists once (L - W) / stride >= 128 (f + 1)
+    const uint64_t ready = lbad::subfingerprint_count(s->pending.size(), d->window, d->stride);
+    if (ready == 0) return noErr;
+    const uint64_t hop = (uint64_t)lbad::kRowsPerFrame * d->stride;
+    const uint64_t use = (uint64_t)d->window + ready * hop;            // yields exactly `ready` frames
+    std::vector<Boolean> bools((size_t)ready * d->subfp_len);
+    st = LBAudioDetectiveFingerprintClips(d, s->pending.data(), 1, use, bools.data());
+    if (st != noErr) return st;
+    for (uint64_t f = 0; f < ready; ++f) {
+        UInt32 len = d->subfp_len;
+        LBAudioDetectiveFingerprintSetSubfingerprintLength(s->fingerprint, &len);
+        LBAudioDetectiveFingerprintAddSubfingerprint(s->fingerprint, bools.data() + (size_t)f * d->subfp_len);
+    }
+    s->pending.erase(s->pending.begin(), s->pending.begin() + (size_t)(ready * hop));
+    if (outNewSubfingerprints) *outNewSubfingerprints = (UInt32)ready;
+    return noErr;
+}
+
+LBAudioDetectiveFingerprintRef LBAudioDetectiveStreamCopyFingerprint(LBAudioDetectiveStreamRef s) {
+    return s ? LBAudioDetectiveFingerprintCopy(s->fingerprint) : NULL;
 }
 
 // ---- synthetic inputs and device plumbing ------------------------------------------------------

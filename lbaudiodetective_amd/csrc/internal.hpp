@@ -54,16 +54,17 @@ struct Plan {
 
 // ---- kernel launchers (k_*.hip) -------------------------------------------------------------
 // windows -> frame rows.  frames: [n_clips * frames_per_clip][128][bands]
-hipError_t launch_fft_bands(const Plan& plan, const float* d_pcm, uint64_t n_clips, uint64_t samples_per_clip,
-                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
+// fmt: 0 float32, 1 int16, 2 int32 samples
+hipError_t launch_fft_bands(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
+                            uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
 // frame rows -> packed sub-fingerprints.  d_haar (optional) receives the decomposed frames.
 hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_frames, uint32_t* d_packed,
                               float* d_haar_out, hipStream_t stream);
 // specialised stage 1 (k_rows_pruned.hip): 1024-sample windows whose bands read only bins 0..21
 bool rows_pruned_supported(const Plan& plan);
 void rows_pruned_constants(std::vector<float>& out);
-hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const float* d_pcm, uint64_t n_clips,
-                              uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
+hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint32_t fmt,
+                              uint64_t n_clips, uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
                               hipStream_t stream);
 
 // specialised stage 2 (k_haar_select32.hip): 128 x 32 frames, keep <= 128

@@ -6,7 +6,7 @@
 // (positive-only normalisation, divisor = edge difference).  One wave owns one window; the W/2
 // complex points live in LDS in natural order (the decimation-in-time network is walked with
 // bit-reversed index arithmetic instead of a bit-reversed load, so bin k ends at address
-// brev(k)).  Generic over window size; the headline configuration uses k_fused.hip instead.
+// brev(k)).  Generic over window size; the headline configuration uses k_rows_pruned.hip instead.
 #include "internal.hpp"
 
 namespace lbad {
@@ -24,8 +24,8 @@ __device__ __forceinline__ float2 bfly_mul_add(float wr, float wi, float2 u, flo
 
 template <int LOG2W, int WPB>
 __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
-    const float* __restrict__ pcm, uint64_t samples_per_clip, uint32_t stride, uint32_t windows_per_clip,
-    const float* __restrict__ tw, const uint32_t* __restrict__ band_tbl, uint32_t nbands, uint32_t kmin,
+    const void* __restrict__ pcm_raw, uint32_t fmt, uint64_t samples_per_clip, uint32_t stride,
+    uint32_t windows_per_clip, const float* __restrict__ tw, const uint32_t* __restrict__ band_tbl, uint32_t nbands, uint32_t kmin,
     uint32_t kmax, float* __restrict__ frames) {
     constexpr int W = 1 << LOG2W;
     constexpr int N = W / 2;
@@ -41,9 +41,19 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
     const uint64_t win = (uint64_t)blockIdx.x * WPB + wave;
     const uint64_t clip = win / windows_per_clip;
     const uint32_t wi = (uint32_t)(win % windows_per_clip);
-    const float* src = pcm + clip * samples_per_clip + (uint64_t)wi * stride;
-
-    for (int i = lane; i < W; i += 64) zf[i] = src[i];
+    const uint64_t first = clip * samples_per_clip + (uint64_t)wi * stride;
+    // sample formats: 0 float32, 1 int16 / 32768, 2 int32 / 2^31 (what LBAudioDetectiveConvertToFormat,
+    // LBAudioDetective.m:413-437, asks AudioConverter to do for integer PCM)
+    if (fmt == 0) {
+        const float* src = static_cast<const float*>(pcm_raw) + first;
+        for (int i = lane; i < W; i += 64) zf[i] = src[i];
+    } else if (fmt == 1) {
+        const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
+        for (int i = lane; i < W; i += 64) zf[i] = (float)src[i] * (1.0f / 32768.0f);
+    } else {
+        const int32_t* src = static_cast<const int32_t*>(pcm_raw) + first;
+        for (int i = lane; i < W; i += 64) zf[i] = (float)src[i] * (1.0f / 2147483648.0f);
+    }
     __syncthreads();
 
     const float* twr = tw;
@@ -112,7 +122,7 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
 }
 
 template <int LOG2W>
-hipError_t launch_one(const Plan& plan, const float* d_pcm, uint64_t n_clips, uint64_t samples_per_clip,
+hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
                       uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     constexpr int W = 1 << LOG2W;
     constexpr int WPB = (W <= 4096) ? 4 : 2;
@@ -128,7 +138,7 @@ hipError_t launch_one(const Plan& plan, const float* d_pcm, uint64_t n_clips, ui
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(WPB * 64), lds, stream, d_pcm, samples_per_clip,
+    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(WPB * 64), lds, stream, d_pcm, fmt, samples_per_clip,
                        plan.stride, windows_per_clip, plan.d_tw, plan.d_bands, plan.bands, plan.table.kmin,
                        plan.table.kmax, d_frames);
     return hipGetLastError();
@@ -136,19 +146,19 @@ hipError_t launch_one(const Plan& plan, const float* d_pcm, uint64_t n_clips, ui
 
 }  // namespace
 
-hipError_t launch_fft_bands(const Plan& plan, const float* d_pcm, uint64_t n_clips, uint64_t samples_per_clip,
-                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+hipError_t launch_fft_bands(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
+                            uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     switch (plan.log2w) {
-        case 4: return launch_one<4>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 5: return launch_one<5>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 6: return launch_one<6>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 7: return launch_one<7>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 8: return launch_one<8>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 9: return launch_one<9>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 10: return launch_one<10>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 11: return launch_one<11>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 12: return launch_one<12>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 13: return launch_one<13>(plan, d_pcm, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 4: return launch_one<4>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 5: return launch_one<5>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 6: return launch_one<6>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 7: return launch_one<7>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 8: return launch_one<8>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 9: return launch_one<9>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 10: return launch_one<10>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 11: return launch_one<11>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 12: return launch_one<12>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 13: return launch_one<13>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
         default: return hipErrorInvalidValue;
     }
 }

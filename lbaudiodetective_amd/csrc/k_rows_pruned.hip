@@ -168,7 +168,9 @@ __device__ __forceinline__ cplx tree(const float* row, const float* tw) {
 
 // per-bin constants (kBinConst floats, padded to kConstStride): [0..5] twiddles of the "+" tree (stages 7, 8,
 // 9), [6..11] of the mirror tree, [12..13] split-pass twiddle W_1024^k
-__global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const float* __restrict__ pcm,
+// FMT: 0 float32, 1 int16 / 32768, 2 int32 / 2^31 -- the conversion is fused into the span load
+template <int FMT>
+__global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const void* __restrict__ pcm_raw,
                                                                          uint64_t samples_per_clip,
                                                                          uint32_t frames_per_clip,
                                                                          const float* __restrict__ bin_const,
@@ -187,13 +189,13 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const fl
     const uint32_t quarter = (uint32_t)(unit & 3);
     const uint64_t clip = frame / frames_per_clip;
     const uint32_t fi = (uint32_t)(frame % frames_per_clip);
-    const float* src = pcm + clip * samples_per_clip + ((uint64_t)fi * 128 + quarter * kUnitWindows) * kStride;
+    const uint64_t first = clip * samples_per_clip + ((uint64_t)fi * 128 + quarter * kUnitWindows) * kStride;
 
     // ---- A: PCM span -> LDS, skewed by 16 dwords per 64 samples so that the 4 windows of a 32-lane
     //         group hit disjoint bank quarters in phase B1.  All loads are issued before the first
     //         LDS store: one HBM round trip is exposed, and the co-resident workgroup covers it. ----
-    if (aligned16) {
-        const float4* s4 = reinterpret_cast<const float4*>(src);
+    if (FMT == 0 && aligned16) {
+        const float4* s4 = reinterpret_cast<const float4*>(static_cast<const float*>(pcm_raw) + first);
         constexpr int kIter = (kSpan / 4 + kThreads - 1) / kThreads;
         float4 v[kIter];
 #pragma unroll
@@ -212,7 +214,18 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const fl
     } else {
         for (int i = threadIdx.x; i < kBins * kBinConst; i += kThreads)
             cbuf[(i / kBinConst) * kConstStride + (i % kBinConst)] = bin_const[i];
-        for (int s = threadIdx.x; s < kSpan; s += kThreads) span[s + 16 * (s >> 6)] = src[s];
+        if (FMT == 0) {
+            const float* src = static_cast<const float*>(pcm_raw) + first;
+            for (int s = threadIdx.x; s < kSpan; s += kThreads) span[s + 16 * (s >> 6)] = src[s];
+        } else if (FMT == 1) {
+            const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
+            for (int s = threadIdx.x; s < kSpan; s += kThreads)
+                span[s + 16 * (s >> 6)] = (float)src[s] * (1.0f / 32768.0f);
+        } else {
+            const int32_t* src = static_cast<const int32_t*>(pcm_raw) + first;
+            for (int s = threadIdx.x; s < kSpan; s += kThreads)
+                span[s + 16 * (s >> 6)] = (float)src[s] * (1.0f / 2147483648.0f);
+        }
     }
     const int band = lane & 31;
     const uint32_t b_lo = band_tbl[band], b_hi = band_tbl[kBands + band];
@@ -326,24 +339,37 @@ void rows_pruned_constants(std::vector<float>& out) {
     }
 }
 
-hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const float* d_pcm, uint64_t n_clips,
-                              uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
-                              hipStream_t stream) {
-    const uint64_t n_frames = n_clips * frames_per_clip;
-    if (n_frames == 0) return hipSuccess;
-    if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+template <int FMT>
+static hipError_t launch_rows_fmt(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint64_t n_frames,
+                                  uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
+                                  hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_rows_pruned_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_rows_pruned_kernel<FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_pcm) & 15) == 0 && (samples_per_clip & 3) == 0) ? 1 : 0;
-    if (n_frames * 4 > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(frame_rows_pruned_kernel, dim3((uint32_t)(n_frames * 4)), dim3(kThreads), kLdsBytes, stream, d_pcm,
-                       samples_per_clip, frames_per_clip, d_bin_const, plan.d_bands, d_frames, aligned16);
+    hipLaunchKernelGGL(frame_rows_pruned_kernel<FMT>, dim3((uint32_t)(n_frames * 4)), dim3(kThreads), kLdsBytes,
+                       stream, d_pcm, samples_per_clip, frames_per_clip, d_bin_const, plan.d_bands, d_frames,
+                       aligned16);
     return hipGetLastError();
+}
+
+hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint32_t fmt,
+                              uint64_t n_clips, uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
+                              hipStream_t stream) {
+    const uint64_t n_frames = n_clips * frames_per_clip;
+    if (n_frames == 0) return hipSuccess;
+    if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+    if (n_frames * 4 > 0x7fffffffull) return hipErrorInvalidValue;
+    switch (fmt) {
+        case 0: return launch_rows_fmt<0>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 1: return launch_rows_fmt<1>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 2: return launch_rows_fmt<2>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace lbad

@@ -283,10 +283,11 @@ def test_file_entry_points(lb, gpu, oracle, tmp_path):
     assert np.array_equal(det.process_audio_url(pa).to_bools(), oracle.fingerprint_pcm(a, cfg))
     want = np.float32(oracle.compare_fp(oracle.fingerprint_pcm(a, cfg), oracle.fingerprint_pcm(b, cfg), 200))
     assert np.float32(det.compare_audio_urls(pa, pb, 0)).view(np.uint32) == want.view(np.uint32)
-    det.processing_sample_rate = 44100                    # file is 5512 Hz: no resampler yet
-    with pytest.raises(lb.LBAudioDetectiveError) as e:
-        det.process_audio_url(pa)
-    assert e.value.status == lb.constant("kLBAudioDetectiveUnsupportedFile")
+    # a file at another rate goes through the resampler first (upstream: ExtAudioFile's converter)
+    det.configure(sample_rate=11025, window=512)
+    pcm, rate = lb.read_audio_url(pa, 11025)
+    assert rate == 11025 and pcm.size == a.size * 11025 // 5512
+    assert np.array_equal(det.process_audio_url(pa).to_bools(), oracle.fingerprint_pcm(pcm, oracle.Config(11025, 512)))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -541,3 +542,46 @@ def test_corpus_save_load(lb, gpu, oracle, tmp_path):
     assert gpu.equal(again.scores_device(q), corpus.scores_device(q))
     with pytest.raises(lb.LBAudioDetectiveError):
         lb.Corpus.load(str(tmp_path / "missing"), 200, 5)
+
+
+# ---------------------------------------------------------------------------------------------
+# integer PCM (conversion fused into the PCM load) and streaming
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["B_44k_1024", "A_default"])
+def test_integer_pcm_matches_float_path(lb, gpu, oracle, name):
+    """LBAudioDetectiveConvertToFormat's job (D.m:413-437) done on the device: int16 / int32 clips give
+    the bits of the float clips they convert to (sample / 32768, sample / 2^31)."""
+    cfg = oracle.Config(**CONFIGS[name])
+    n = cfg.window + cfg.stride * 128 * 2
+    pcm = oracle.synth_clips(SEED, 300, 4, int(cfg.sample_rate), n)            # exact multiples of 1 / 32768
+    want = oracle.fingerprint_batch(pcm, cfg)
+    i16 = gpu.from_numpy(np.round(pcm * 32768).astype(np.int16)).cuda()
+    rng = np.random.default_rng(2)
+    raw32 = rng.integers(-2**31, 2**31 - 1, pcm.shape, dtype=np.int64).astype(np.int32)
+    f32_of_i32 = (raw32.astype(np.float64) / 2**31).astype(np.float32)
+    want32 = oracle.fingerprint_batch(f32_of_i32, cfg)
+    for variant in ((0, 1) if name == "B_44k_1024" else (1,)):
+        det = lb.Detective().configure(**CONFIGS[name])
+        det.set_kernel_variant(variant)
+        got = _bits(lb, det.fingerprint_clips_device(i16), cfg.subfp_len)
+        assert np.array_equal(got, want), (name, variant, "int16")
+        got = _bits(lb, det.fingerprint_clips_device(gpu.from_numpy(raw32).cuda()), cfg.subfp_len)
+        assert np.array_equal(got, want32), (name, variant, "int32")
+
+
+@pytest.mark.parametrize("chunks", [[1] * 7 + [5000, 1, 1], [4096] * 30, [100_000], [8191, 8193, 1024, 63, 64, 65] * 4])
+def test_streaming_equals_whole_buffer(lb, gpu, oracle, chunks):
+    """Chunked PCM with the partial frame carried across calls == ProcessPCM on the concatenation."""
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    total = sum(chunks)
+    pcm = oracle.synth_clip(SEED, 55, 44100, total)
+    st = lb.Stream(det)
+    at, emitted = 0, 0
+    for c in chunks:
+        emitted += st.push(pcm[at:at + c])
+        at += c
+        assert emitted == oracle.subfingerprint_count(at, 1024, 64)           # frames appear as soon as they are complete
+    whole = det.process_pcm(pcm)
+    assert st.fingerprint().equal_to_fingerprint(whole) or (whole.number_of_subfingerprints == 0 and emitted == 0)
+    if emitted:
+        assert np.array_equal(st.fingerprint().to_bools(), oracle.fingerprint_pcm(pcm, oracle.Config(44100, 1024)))
