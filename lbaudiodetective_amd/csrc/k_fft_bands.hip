@@ -6,20 +6,77 @@
 // (positive-only normalisation, divisor = edge difference).  One wave owns one window; the W/2
 // complex points live in LDS in natural order (the decimation-in-time network is walked with
 // bit-reversed index arithmetic instead of a bit-reversed load, so bin k ends at address
-// brev(k)).  Generic over window size; the headline configuration uses k_rows_pruned.hip instead.
+// brev(k)); three stages share one trip through LDS.  Generic over window size; the headline configuration uses k_rows_pruned.hip instead.
 #include "internal.hpp"
 
 namespace lbad {
 namespace {
 
-__device__ __forceinline__ float2 bfly_mul_add(float wr, float wi, float2 u, float2 v, float2& lo) {
-    // out0 = u + w v, out1 = u - w v; nested fma, identical to the oracle's bfly_general
-    float2 hi;
-    hi.x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
-    hi.y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
-    lo.x = __fmaf_rn(-wr, v.x, __fmaf_rn(wi, v.y, u.x));
-    lo.y = __fmaf_rn(-wr, v.y, __fmaf_rn(-wi, v.x, u.y));
-    return hi;
+// Waves own disjoint LDS regions and never exchange data, so a workgroup barrier would only make
+// them wait for each other.  LDS operations of one wave execute in order; the fences just stop the
+// compiler from moving a lane's loads above other lanes' stores.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// complex point n lives at slot n + (n >> 5): one pad slot per 32 points keeps the strided gathers of
+// the last passes (8 or 64 points between consecutive lanes) off a single bank group
+__device__ __forceinline__ int zslot(int n) { return n + (n >> 5); }
+
+// DIT stages S0 .. S0+NS-1 (NS <= 3) in one trip through LDS: a lane gathers the 2^NS points that
+// these stages connect, runs the butterflies in registers and scatters the results back.  Points are
+// stored in natural order; the stage-s partner of point n is n +- (N >> s) and its twiddle index is
+// the bit-reversed value of n's top s-1 bits.  Every butterfly uses the general nested-fma form: for
+// the twiddles 1 and -i this equals the oracle's multiplication-free form up to the sign of zeros.
+template <int LOG2W, int S0, int NS>
+__device__ __forceinline__ void dit_pass(float2* z, const float* __restrict__ twr, const float* __restrict__ twi,
+                                         int lane) {
+    constexpr int LOGN = LOG2W - 1;
+    constexpr int N = 1 << LOGN;
+    constexpr int G = 1 << NS;
+    constexpr int low_bits = LOGN - S0 - NS + 1;        // bits of n below the NS varying ones
+    constexpr int step = 1 << low_bits;                  // distance handled by the last stage of the pass
+    for (int g = lane; g < N / G; g += 64) {
+        const int n0 = ((g >> low_bits) << (low_bits + NS)) | (g & (step - 1));
+        float2 x[G];
+#pragma unroll
+        for (int e = 0; e < G; ++e) x[e] = z[zslot(n0 + e * step)];
+#pragma unroll
+        for (int t = 0; t < NS; ++t) {
+            const int s = S0 + t;                        // global stage, partner distance N >> s
+            const int half = G >> (t + 1);               // ... = `half` register slots
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                if (e & half) continue;
+                const uint32_t n = (uint32_t)(n0 + e * step);
+                const uint32_t j = s > 1 ? (__brev(n >> (LOGN - s + 1)) >> (32 - (s - 1))) : 0u;
+                const uint32_t ti = j << (LOG2W - s);
+                const float wr = twr[ti], wi = twi[ti];
+                const float2 u = x[e], v = x[e + half];
+                x[e].x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
+                x[e].y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
+                x[e + half].x = __fmaf_rn(-wr, v.x, __fmaf_rn(wi, v.y, u.x));
+                x[e + half].y = __fmaf_rn(-wr, v.y, __fmaf_rn(-wi, v.x, u.y));
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < G; ++e) z[zslot(n0 + e * step)] = x[e];
+    }
+    wave_sync();
+}
+
+template <int LOG2W, int S0>
+__device__ __forceinline__ void dit_all(float2* z, const float* __restrict__ twr, const float* __restrict__ twi,
+                                        int lane) {
+    constexpr int LOGN = LOG2W - 1;
+    if constexpr (S0 <= LOGN) {
+        constexpr int left = LOGN - S0 + 1;
+        constexpr int NS = left >= 3 ? 3 : left;
+        dit_pass<LOG2W, S0, NS>(z, twr, twi, lane);
+        dit_all<LOG2W, S0 + NS>(z, twr, twi, lane);
+    }
 }
 
 template <int LOG2W, int WPB>
@@ -34,9 +91,11 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    float* zf = smem + (size_t)wave * (W + N);
+    // per wave: N (+ skew) complex points, then N floats of power terms
+    constexpr int kZf = 2 * (N + (N >> 5));
+    float* zf = smem + (size_t)wave * (kZf + N);
     float2* z = reinterpret_cast<float2*>(zf);
-    float* vbuf = zf + W;
+    float* vbuf = zf + kZf;
 
     const uint64_t win = (uint64_t)blockIdx.x * WPB + wave;
     const uint64_t clip = win / windows_per_clip;
@@ -46,57 +105,32 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
     // LBAudioDetective.m:413-437, asks AudioConverter to do for integer PCM)
     if (fmt == 0) {
         const float* src = static_cast<const float*>(pcm_raw) + first;
-        for (int i = lane; i < W; i += 64) zf[i] = src[i];
+        for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = src[i];
     } else if (fmt == 1) {
         const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
-        for (int i = lane; i < W; i += 64) zf[i] = (float)src[i] * (1.0f / 32768.0f);
+        for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)src[i] * (1.0f / 32768.0f);
     } else {
         const int32_t* src = static_cast<const int32_t*>(pcm_raw) + first;
-        for (int i = lane; i < W; i += 64) zf[i] = (float)src[i] * (1.0f / 2147483648.0f);
+        for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)src[i] * (1.0f / 2147483648.0f);
     }
-    __syncthreads();
+    wave_sync();
 
-    const float* twr = tw;
+    const float* twr = tw;   // gathered by bit-reversed index; L1/L2 resident
     const float* twi = tw + N;
-
-#pragma unroll
-    for (int s = 1; s <= LOGN; ++s) {
-        const int logD = LOGN - s;
-        const int D = 1 << logD;
-        for (int b = lane; b < N / 2; b += 64) {
-            const int n0 = ((b >> logD) << (logD + 1)) | (b & (D - 1));
-            const int n1 = n0 + D;
-            const uint32_t j = (s > 1) ? (__brev((uint32_t)(n0 >> (logD + 1))) >> (32 - (s - 1))) : 0u;
-            const float2 u = z[n0], v = z[n1];
-            float2 o0, o1;
-            if (j == 0) {
-                o0 = make_float2(u.x + v.x, u.y + v.y);
-                o1 = make_float2(u.x - v.x, u.y - v.y);
-            } else if ((j << 2) == (1u << s)) {  // w = -i
-                o0 = make_float2(u.x + v.y, u.y - v.x);
-                o1 = make_float2(u.x - v.y, u.y + v.x);
-            } else {
-                const uint32_t t = j << (LOG2W - s);
-                o0 = bfly_mul_add(twr[t], twi[t], u, v, o1);
-            }
-            z[n0] = o0;
-            z[n1] = o1;
-        }
-        __syncthreads();
-    }
+    dit_all<LOG2W, 1>(z, twr, twi, lane);
 
     // split pass for the bins the bands read, then the reference's per-bin power term
     const float inv_norm = 1.0f / (float)(W / 4);  // (Float32)(width/2), width = W/2; exact power of two
     for (uint32_t k = kmin + lane; k < kmax; k += 64) {
         float re, im;
         if (k == 0) {
-            const float2 z0 = z[0];
+            const float2 z0 = z[0];   // zslot(0) == 0
             const float sm = z0.x + z0.y, df = z0.x - z0.y;
             re = sm + sm;
             im = df + df;
         } else {
-            const float2 a = z[__brev(k) >> (32 - LOGN)];
-            const float2 b = z[__brev((uint32_t)N - k) >> (32 - LOGN)];
+            const float2 a = z[zslot((int)(__brev(k) >> (32 - LOGN)))];
+            const float2 b = z[zslot((int)(__brev((uint32_t)N - k) >> (32 - LOGN)))];
             const float sr = a.x + b.x, si = a.y - b.y;
             const float dr = a.x - b.x, di = a.y + b.y;
             const float wr = twr[k], wi2 = twi[k];
@@ -107,15 +141,21 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
         if (im > 0.0f) im = __fmul_rn(im, inv_norm);
         vbuf[k - kmin] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
     }
-    __syncthreads();
+    wave_sync();
 
     for (uint32_t b = lane; b < nbands; b += 64) {
         const uint32_t lo = band_tbl[b], hi = band_tbl[nbands + b];
         const float div = __uint_as_float(band_tbl[2 * nbands + b]);
+        // the sum must run in bin order (float32 addition is not associative); the loads are issued in
+        // batches of 8 so that their LDS latency overlaps instead of serialising with the adds
         float p = 0.0f;
-        for (uint32_t k = lo; k < hi; ++k) {
-            const float x = vbuf[k - kmin];
-            if (x == x && fabsf(x) != INFINITY) p = __fadd_rn(p, x);
+        for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
+            float x[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) x[q] = (k0 + q < hi) ? vbuf[k0 + q - kmin] : 0.0f;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q)
+                if (k0 + q < hi && x[q] == x[q] && fabsf(x[q]) != INFINITY) p = __fadd_rn(p, x[q]);
         }
         frames[win * nbands + b] = __fdiv_rn(p, div);
     }
@@ -131,7 +171,7 @@ hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_
     if (n_windows == 0) return hipSuccess;
     const uint64_t blocks = n_windows / WPB;  // windows come in multiples of 128
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)WPB * (W + W / 2) * sizeof(float);
+    const size_t lds = (size_t)WPB * (2 * (W / 2 + W / 64) + W / 2) * sizeof(float);
     auto kern = fft_bands_kernel<LOG2W, WPB>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Throughput of the batch path at the three processing configurations of BASELINE.json, plus the
+host-buffer (PCIe-inclusive) rate of configuration B.  Prints one JSON object."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import lbaudiodetective_amd as lb
+
+out = {}
+for name, rate, window, samples, n, stereo in [("A_5512_2048", 5512, 2048, 5512 * 9, 20000, False),
+                                                ("B_44100_1024", 44100, 1024, 44100, 100000, False),
+                                                ("C_48000_4096_stereo", 48000, 4096, 48000, 10000, True)]:
+    det = lb.Detective().configure(sample_rate=rate, window=window)
+    clips = lb.synth_clips_device(0x4C424144, 0, n, rate, samples, stereo)
+    packed = det.fingerprint_clips_device(clips)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    reps = 3
+    for _ in range(reps):
+        det.fingerprint_clips_device(clips, out=packed)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    out[name] = {"clips": n, "seconds_per_clip": samples / rate, "subfingerprints_per_clip": int(packed.shape[1]),
+                 "ms": round(ms, 3), "audio_seconds_per_s": round(n * samples / rate / (ms * 1e-3), 1),
+                 "windows_per_s": round(n * packed.shape[1] * 128 / (ms * 1e-3), 1)}
+    del clips, packed
+    torch.cuda.empty_cache()
+
+# host buffers in, Booleans out (H2D of the PCM and D2H of the packed bits inside the timed region)
+det = lb.Detective().configure(sample_rate=44100, window=1024)
+host = lb.synth_clips_device(0x4C424144, 0, 4000, 44100, 44100).cpu().numpy()
+det.fingerprint_clips(host[:100])
+t0 = time.perf_counter()
+det.fingerprint_clips(host)
+dt = time.perf_counter() - t0
+out["B_host_buffers_pageable"] = {"clips": 4000, "s": round(dt, 4), "audio_seconds_per_s": round(4000 / dt, 1)}
+pinned = torch.from_numpy(host).pin_memory()
+dev = torch.empty((4000, 44100), dtype=torch.float32, device="cuda")
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+dev.copy_(pinned, non_blocking=True)
+p = det.fingerprint_clips_device(dev)
+res = p.cpu()
+dt = time.perf_counter() - t0
+out["B_host_buffers_pinned"] = {"clips": 4000, "s": round(dt, 4), "audio_seconds_per_s": round(4000 / dt, 1),
+                                "h2d_GBps": round(host.nbytes / dt / 1e9, 2)}
+print(json.dumps(out))
