@@ -172,7 +172,8 @@ __device__ __forceinline__ cplx tree(const float* row, const float* tw) {
 template <int FMT>
 __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const void* __restrict__ pcm_raw,
                                                                          uint64_t samples_per_clip,
-                                                                         uint32_t frames_per_clip,
+                                                                         uint32_t frames_per_clip, uint64_t n_units,
+                                                                         uint64_t units_per_xcd,
                                                                          const float* __restrict__ bin_const,
                                                                          const uint32_t* __restrict__ band_tbl,
                                                                          float* __restrict__ frames, int aligned16) {
@@ -184,7 +185,11 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const vo
     float* vbuf = tbuf;                       // power terms reuse the wave's transpose area after the trees
     float* cbuf = smem + kSpanDw + kTDw;
 
-    const uint64_t unit = blockIdx.x;         // quarter frame
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; used for speed only).  Giving every XCD a
+    // contiguous range of quarter frames makes neighbouring units -- whose PCM spans overlap by a third
+    // -- share one L2 instead of fetching the overlap from HBM once per XCD.
+    const uint64_t unit = (uint64_t)(blockIdx.x & 7) * units_per_xcd + (blockIdx.x >> 3);   // quarter frame
+    if (unit >= n_units) return;
     const uint64_t frame = unit >> 2;
     const uint32_t quarter = (uint32_t)(unit & 3);
     const uint64_t clip = frame / frames_per_clip;
@@ -351,9 +356,10 @@ static hipError_t launch_rows_fmt(const Plan& plan, const float* d_bin_const, co
         attr_set = true;
     }
     const int aligned16 = ((reinterpret_cast<uintptr_t>(d_pcm) & 15) == 0 && (samples_per_clip & 3) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(frame_rows_pruned_kernel<FMT>, dim3((uint32_t)(n_frames * 4)), dim3(kThreads), kLdsBytes,
-                       stream, d_pcm, samples_per_clip, frames_per_clip, d_bin_const, plan.d_bands, d_frames,
-                       aligned16);
+    const uint64_t n_units = n_frames * 4, units_per_xcd = (n_units + 7) / 8;
+    hipLaunchKernelGGL(frame_rows_pruned_kernel<FMT>, dim3((uint32_t)(units_per_xcd * 8)), dim3(kThreads), kLdsBytes,
+                       stream, d_pcm, samples_per_clip, frames_per_clip, n_units, units_per_xcd, d_bin_const,
+                       plan.d_bands, d_frames, aligned16);
     return hipGetLastError();
 }
 
@@ -363,7 +369,7 @@ hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const 
     const uint64_t n_frames = n_clips * frames_per_clip;
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-    if (n_frames * 4 > 0x7fffffffull) return hipErrorInvalidValue;
+    if (n_frames * 4 + 8 > 0x7fffffffull) return hipErrorInvalidValue;
     switch (fmt) {
         case 0: return launch_rows_fmt<0>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
         case 1: return launch_rows_fmt<1>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
