@@ -585,3 +585,46 @@ def test_streaming_equals_whole_buffer(lb, gpu, oracle, chunks):
     assert st.fingerprint().equal_to_fingerprint(whole) or (whole.number_of_subfingerprints == 0 and emitted == 0)
     if emitted:
         assert np.array_equal(st.fingerprint().to_bools(), oracle.fingerprint_pcm(pcm, oracle.Config(44100, 1024)))
+
+
+# ---------------------------------------------------------------------------------------------
+# randomized sweep: configurations and shapes nobody picked by hand
+# ---------------------------------------------------------------------------------------------
+def test_random_configurations_bit_exact(lb, gpu, oracle):
+    rng = np.random.default_rng(20260101)
+    for trial in range(40):
+        window = int(2 ** rng.integers(4, 13))                     # 16 .. 4096
+        stride = int(rng.choice([1, 3, 7, 16, 31, 64, 100, 257]))
+        bands = int(rng.choice([1, 2, 5, 16, 31, 32, 33, 64]))
+        subfp_len = int(min(rng.choice([1, 2, 9, 64, 199, 200, 201, 256]), 128 * bands))
+        rate = float(rng.choice([4000, 5512, 8000, 11025, 22050, 44100, 48000, 96000]))
+        frames = int(rng.integers(1, 3))
+        extra = int(rng.integers(0, 128 * stride))                  # ragged tail, odd lengths, odd alignment
+        n = window + stride * 128 * frames + extra
+        n_clips = int(rng.integers(1, 4))
+        cfg = oracle.Config(rate, window, stride, bands, subfp_len)
+        pcm = oracle.synth_clips(SEED + trial, 0, n_clips, 44100, n)
+        if trial % 5 == 0:
+            pcm[:, : n // 2] = 0.0                                   # half silence: ties and empty bands
+        want = oracle.fingerprint_batch(pcm, cfg)
+        assert want.shape[1] == frames
+        got = _fingerprint_device(lb, gpu, pcm, cfg)
+        assert np.array_equal(got, want), (trial, window, stride, bands, subfp_len, rate, n)
+
+
+def test_random_compare_shapes(lb, gpu, oracle):
+    rng = np.random.default_rng(77)
+    for trial in range(60):
+        L = int(rng.choice([1, 2, 3, 31, 32, 33, 64, 65, 199, 200, 255, 256]))
+        n1, n2 = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+        a = oracle.synth_corpus(trial, 0, 1, n1, L)[0]
+        b = oracle.synth_corpus(trial, 1, 1, n2, L)[0]
+        if trial % 3 == 0:                                          # make part of b a copy of a (a real match)
+            m = min(n1, n2)
+            b[:m] = a[n1 - m:]
+        if trial % 7 == 0:
+            a[rng.integers(0, n1)] = 0                              # a sub-fingerprint with no possible hits
+        rg = int(rng.choice([1, 2, L // 2 + 1, L, L + 5, 1000]))
+        want = np.float32(oracle.compare_fp(a, b, rg))
+        got = np.float32(lb.Fingerprint.from_bools(a).compare_to_fingerprint(lb.Fingerprint.from_bools(b), rg))
+        assert got.view(np.uint32) == want.view(np.uint32), (trial, L, n1, n2, rg)
