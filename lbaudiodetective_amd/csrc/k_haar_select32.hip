@@ -24,11 +24,36 @@ constexpr int kCols = 32;
 constexpr uint32_t kCand = 128;     // candidates ranked exhaustively
 constexpr int kChunkDw = 20;        // 16 floats + 4 pad: conflict-free ds_read_b128 across lanes
 
-#ifndef LBAD_EXACT_CONST_DIV
-#define LBAD_EXACT_CONST_DIV 0
-#endif
-
 __device__ __forceinline__ float div_root(float x, float root) { return __fdiv_rn(x, root); }
+
+// x / d for the Haar's three constant divisors without the ~11-instruction IEEE division sequence:
+//     q0 = x * r;  e = fma(-d, q0, x);  q = fma(e, r, q0)        with r = RN(1 / d).
+// tools/verify_const_div.c checks ALL 2^32 inputs for d = sqrtf(2), sqrtf(32), sqrtf(128): q equals the
+// correctly rounded quotient bit for bit whenever 2^-105 <= |x| < inf (and for +0; -0 gives +0, which
+// no later step can tell apart).  Inputs outside [2^-100, FLT_MAX] other than zero are only recorded
+// here (min over |x| - 1 ulp, max over |x|, as integers); the caller redoes the whole line with true
+// divisions when a lane saw one.
+constexpr uint32_t kFastDivLo = 0x0D800000u;   // 2^-100
+constexpr uint32_t kFastDivHi = 0x7F7FFFFFu;   // FLT_MAX
+
+struct DivGuard {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    __device__ __forceinline__ bool bad() const { return lo < kFastDivLo - 1u || hi > kFastDivHi; }
+};
+
+template <bool FAST>
+__device__ __forceinline__ float div_c(float x, float d, float r, DivGuard& g) {
+    if constexpr (FAST) {
+        const uint32_t u = __float_as_uint(x) & 0x7fffffffu;
+        g.lo = min(g.lo, u - 1u);          // zero wraps to 0xFFFFFFFF and never trips the guard
+        g.hi = max(g.hi, u);
+        const float q0 = __fmul_rn(x, r);
+        const float e = __fmaf_rn(-d, q0, x);
+        return __fmaf_rn(e, r, q0);
+    } else {
+        return __fdiv_rn(x, d);
+    }
+}
 
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red, int parity) {
 #pragma unroll
@@ -42,27 +67,37 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red, int p
 // levels 1..4 of a 16-value line held in registers.  On return d[0..7] = level-1 details,
 // d[8..11] = level 2, d[12..13] = level 3, d[14] = level 4 and the return value is the level-4
 // average that continues into the cross-lane levels.
-__device__ __forceinline__ float haar16(float (&a)[16], float (&d)[15], float root, float root2) {
+template <bool FAST>
+__device__ __forceinline__ float haar16_impl(const float (&in)[16], float (&d)[15], float root, float r_root,
+                                             float root2, float r_root2, DivGuard& g) {
+    float a[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = div_root(a[i], root);
+    for (int i = 0; i < 16; ++i) a[i] = div_c<FAST>(in[i], root, r_root, g);
     float s1[8], s2[4], s3[2];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        s1[i] = div_root(__fadd_rn(a[2 * i], a[2 * i + 1]), root2);
-        d[i] = div_root(__fsub_rn(a[2 * i], a[2 * i + 1]), root2);
+        s1[i] = div_c<FAST>(__fadd_rn(a[2 * i], a[2 * i + 1]), root2, r_root2, g);
+        d[i] = div_c<FAST>(__fsub_rn(a[2 * i], a[2 * i + 1]), root2, r_root2, g);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        s2[i] = div_root(__fadd_rn(s1[2 * i], s1[2 * i + 1]), root2);
-        d[8 + i] = div_root(__fsub_rn(s1[2 * i], s1[2 * i + 1]), root2);
+        s2[i] = div_c<FAST>(__fadd_rn(s1[2 * i], s1[2 * i + 1]), root2, r_root2, g);
+        d[8 + i] = div_c<FAST>(__fsub_rn(s1[2 * i], s1[2 * i + 1]), root2, r_root2, g);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        s3[i] = div_root(__fadd_rn(s2[2 * i], s2[2 * i + 1]), root2);
-        d[12 + i] = div_root(__fsub_rn(s2[2 * i], s2[2 * i + 1]), root2);
+        s3[i] = div_c<FAST>(__fadd_rn(s2[2 * i], s2[2 * i + 1]), root2, r_root2, g);
+        d[12 + i] = div_c<FAST>(__fsub_rn(s2[2 * i], s2[2 * i + 1]), root2, r_root2, g);
     }
-    d[14] = div_root(__fsub_rn(s3[0], s3[1]), root2);
-    return div_root(__fadd_rn(s3[0], s3[1]), root2);
+    d[14] = div_c<FAST>(__fsub_rn(s3[0], s3[1]), root2, r_root2, g);
+    return div_c<FAST>(__fadd_rn(s3[0], s3[1]), root2, r_root2, g);
+}
+
+__device__ __forceinline__ float haar16(const float (&in)[16], float (&d)[15], float root, float root2) {
+    DivGuard g;
+    float s4 = haar16_impl<true>(in, d, root, __fdiv_rn(1.0f, root), root2, __fdiv_rn(1.0f, root2), g);
+    if (__any(g.bad())) s4 = haar16_impl<false>(in, d, root, 0.0f, root2, 0.0f, g);   // rare: tiny / inf / NaN
+    return s4;
 }
 
 __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
