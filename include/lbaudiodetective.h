@@ -248,6 +248,14 @@ OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef inStream, const Fl
                                     UInt64 inNumberOfSamples, UInt32* outNewSubfingerprints);
 LBAudioDetectiveFingerprintRef LBAudioDetectiveStreamCopyFingerprint(LBAudioDetectiveStreamRef inStream);
 
+/* Stage 2 alone: inFrames = device pointer to inNumberOfFrames x 128 x bands float32 frame rows (what
+ * LBAudioDetectiveFrameSetRow collects upstream) -> packed sub-fingerprints; outFramesHaar (optional)
+ * receives the decomposed frames.  Replaces LBAudioDetectiveSynthesizeFingerprint
+ * (LBAudioDetective.m:315-331) for a batch of full frames. */
+OSStatus LBAudioDetectiveFramesToSubfingerprintsDevice(LBAudioDetectiveRef inDetective, const Float32* inFrames,
+                                                       UInt64 inNumberOfFrames, void* outPacked, Float32* outFramesHaar,
+                                                       void* inStream);
+
 /* Boolean <-> packed conversion on the host (no arithmetic). */
 void LBAudioDetectivePackSubfingerprint(const Boolean* inBooleans, UInt32 inLength, UInt32* outWords);
 void LBAudioDetectiveUnpackSubfingerprint(const UInt32* inWords, UInt32 inLength, Boolean* outBooleans);

@@ -354,6 +354,19 @@ class Detective:
         return out, raw, haar
 
 
+def frames_to_subfingerprints_device(det: "Detective", frames, want_haar: bool = False, stream=None):
+    """Stage 2 alone on torch frames [n, 128, bands] float32 (cuda) -> packed uint8 [n, 32] (and the Haar frames)."""
+    import torch
+    assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous()
+    n = frames.shape[0]
+    out = torch.empty((n, N.PACKED_BYTES), dtype=torch.uint8, device=frames.device)
+    haar = torch.empty_like(frames) if want_haar else None
+    _check(N.lib().LBAudioDetectiveFramesToSubfingerprintsDevice(det._ref, frames.data_ptr(), n, out.data_ptr(),
+                                                                 haar.data_ptr() if want_haar else None, _stream_ptr(stream)),
+           "FramesToSubfingerprintsDevice")
+    return (out, haar) if want_haar else out
+
+
 class Stream:
     """LBAudioDetectiveStreamRef: chunked PCM in, partial frame carried across calls."""
 

@@ -20,34 +20,31 @@ OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint*
     bool fast = planes_fast_supported(c->subfp_len, c->n_sub, q->count);
     if (c->variant == 1) fast = false;
     if (c->variant == 2 && !fast) return kLBAudioDetectiveArgumentInvalid;
-    std::vector<uint32_t> block;
-    const std::vector<uint32_t>* up = &slots;
+    LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
     if (fast) {
+        // the specialised scan takes its 300-byte query block as a kernel argument: nothing to stage
+        std::vector<uint32_t> block;
         build_plane_query(slots.data(), c->n_sub, range, block);
-        up = &block;
+        LBAD_HIP(launch_compare_planes_fast(c->d_planes, c->capacity, c->count, c->n_sub, block.data(), index_base,
+                                            d_scores, key_dst, stream));
+        return noErr;
     }
-    if (c->query_cap < up->size()) {
+    if (c->query_cap < slots.size()) {
         if (c->d_query) (void)hipFree(c->d_query);
         if (c->h_query) (void)hipHostFree(c->h_query);
         c->d_query = nullptr;
         c->h_query = nullptr;
         c->query_cap = 0;
-        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_query), up->size() * sizeof(uint32_t)));
-        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_query), up->size() * sizeof(uint32_t), hipHostMallocDefault));
-        c->query_cap = (uint32_t)up->size();
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_query), slots.size() * sizeof(uint32_t)));
+        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_query), slots.size() * sizeof(uint32_t), hipHostMallocDefault));
+        c->query_cap = (uint32_t)slots.size();
     }
     // the pinned staging block is reused by every query: wait for the previous one's copy
     LBAD_HIP(hipStreamSynchronize(stream));
-    std::memcpy(c->h_query, up->data(), up->size() * sizeof(uint32_t));
-    LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, up->size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
-    if (fast) {
-        LBAD_HIP(launch_compare_planes_fast(c->d_planes, c->capacity, c->count, c->n_sub, c->d_query, index_base,
-                                            d_scores, key_dst, stream));
-    } else {
-        LBAD_HIP(launch_compare_planes_generic(c->d_planes, c->capacity, c->count, c->n_sub, c->subfp_len,
-                                               c->d_query, q->count, range, index_base, d_scores, key_dst, stream));
-    }
+    std::memcpy(c->h_query, slots.data(), slots.size() * sizeof(uint32_t));
+    LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    LBAD_HIP(launch_compare_planes_generic(c->d_planes, c->capacity, c->count, c->n_sub, c->subfp_len, c->d_query,
+                                           q->count, range, index_base, d_scores, key_dst, stream));
     return noErr;
 }
 

@@ -263,6 +263,23 @@ OSStatus LBAudioDetectiveFingerprintClipsDeviceTaps(LBAudioDetectiveRef d, const
                                           static_cast<hipStream_t>(inStream));
 }
 
+OSStatus LBAudioDetectiveFramesToSubfingerprintsDevice(LBAudioDetectiveRef d, const Float32* inFrames, UInt64 inNumberOfFrames,
+                                                       void* outPacked, Float32* outFramesHaar, void* inStream) {
+    if (!d || (!inFrames && inNumberOfFrames) || (!outPacked && inNumberOfFrames)) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    const lbad::Plan& p = d->plan;
+    hipStream_t stream = static_cast<hipStream_t>(inStream);
+    float* frames = const_cast<float*>(inFrames);   // the kernels only read them
+    if (d->variant != 1 && lbad::haar_select32_supported(p)) {
+        LBAD_HIP(lbad::launch_haar_select32(p, frames, inNumberOfFrames, static_cast<uint32_t*>(outPacked), outFramesHaar, stream));
+    } else {
+        if (d->variant == 2) return kLBAudioDetectiveArgumentInvalid;
+        LBAD_HIP(lbad::launch_haar_select(p, frames, inNumberOfFrames, static_cast<uint32_t*>(outPacked), outFramesHaar, stream));
+    }
+    return noErr;
+}
+
 OSStatus LBAudioDetectiveFingerprintClipsDeviceFormat(LBAudioDetectiveRef d, const void* inClips, UInt32 inSampleFormat,
                                                       UInt64 inNumberOfClips, UInt64 inSamplesPerClip, void* outPacked,
                                                       void* inStream) {

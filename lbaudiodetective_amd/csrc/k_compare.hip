@@ -196,6 +196,8 @@ __global__ __launch_bounds__(kThreads) void pack_planes_kernel(const uint32_t* _
 constexpr uint32_t kLp = 200;
 constexpr uint32_t kSubSpan = 7;  // a 200-bit field at an even multiple-of-8 bit offset touches <= 7 words
 
+constexpr uint32_t kPlaneQueryWords = 8 * 4 * 2 + 8 * kSubSpan + 8;   // room for NSUB = 8 (13 planes)
+
 template <int NSUB>
 struct PlaneShape {
     static constexpr uint32_t bits = NSUB * kLp;
@@ -207,17 +209,18 @@ struct PlaneShape {
     static constexpr uint32_t total = off_possible + NSUB;
 };
 
+// The query block travels in the kernel-argument segment: every lane reads the same words, so the
+// compiler keeps them in SGPRs (scalar loads) -- no staging copy, no LDS reads in the scan loop.
+struct PlaneQueryArg {
+    uint32_t w[kPlaneQueryWords];
+};
+
 template <int NSUB>
 __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* __restrict__ planes, uint64_t stride,
-                                                                  uint64_t n_entries,
-                                                                  const uint32_t* __restrict__ qc,
+                                                                  uint64_t n_entries, const PlaneQueryArg qc,
                                                                   uint64_t index_base, float* __restrict__ scores,
                                                                   unsigned long long* __restrict__ key_out) {
     using S = PlaneShape<NSUB>;
-    __shared__ uint32_t s_c[S::total];
-    for (uint32_t i = threadIdx.x; i < S::total; i += kThreads) s_c[i] = qc[i];
-    __syncthreads();
-
     unsigned long long best = 0ull;
     for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
          e += (uint64_t)gridDim.x * kThreads) {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* _
         }
 #pragma unroll
         for (uint32_t w = 0; w < S::planes * 4; ++w) {
-            const uint32_t x = y[w] ^ s_c[w];
+            const uint32_t x = y[w] ^ qc.w[w];
             y[w] = ~(x | (x >> 1));
         }
         float sum = 0.0f;
@@ -239,9 +242,9 @@ __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* _
             uint32_t hits = 0;
 #pragma unroll
             for (uint32_t j = 0; j < kSubSpan; ++j) {
-                if (w0 + j < S::planes * 4) hits += __popc(y[w0 + j] & s_c[S::off_mask + s * kSubSpan + j]);
+                if (w0 + j < S::planes * 4) hits += __popc(y[w0 + j] & qc.w[S::off_mask + s * kSubSpan + j]);
             }
-            const float possible = __uint_as_float(s_c[S::off_possible + s]);
+            const float possible = __uint_as_float(qc.w[S::off_possible + s]);
             const float ratio = possible > 0.0f ? __fdiv_rn((float)hits, possible) : 0.0f;
             sum = __fadd_rn(sum, ratio);
         }
@@ -261,10 +264,14 @@ uint32_t grid_for(uint64_t n_entries) {
 }
 
 template <int NSUB>
-hipError_t launch_planes_n(const uint4* d_planes, uint64_t stride, uint64_t n_entries, const uint32_t* d_qc,
+hipError_t launch_planes_n(const uint4* d_planes, uint64_t stride, uint64_t n_entries, const uint32_t* h_qc,
                            uint64_t index_base, float* d_scores, unsigned long long* d_key, hipStream_t stream) {
+    static_assert(PlaneShape<NSUB>::total <= kPlaneQueryWords, "query block does not fit the kernel argument");
+    PlaneQueryArg arg;
+    std::memset(&arg, 0, sizeof(arg));
+    std::memcpy(arg.w, h_qc, PlaneShape<NSUB>::total * sizeof(uint32_t));
     hipLaunchKernelGGL(compare_planes_kernel<NSUB>, dim3(grid_for(n_entries)), dim3(kThreads), 0, stream, d_planes,
-                       stride, n_entries, d_qc, index_base, d_scores, d_key);
+                       stride, n_entries, arg, index_base, d_scores, d_key);
     return hipGetLastError();
 }
 
@@ -364,6 +371,7 @@ void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, 
     }
 }
 
+// h_qc: HOST pointer to the block built by build_plane_query (it is passed as a kernel argument)
 hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
                                       uint32_t n_sub, const uint32_t* d_qc, uint64_t index_base, float* d_scores,
                                       unsigned long long* d_key, hipStream_t stream) {

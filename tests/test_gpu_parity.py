@@ -628,3 +628,46 @@ def test_random_compare_shapes(lb, gpu, oracle):
         want = np.float32(oracle.compare_fp(a, b, rg))
         got = np.float32(lb.Fingerprint.from_bools(a).compare_to_fingerprint(lb.Fingerprint.from_bools(b), rg))
         assert got.view(np.uint32) == want.view(np.uint32), (trial, L, n1, n2, rg)
+
+
+# ---------------------------------------------------------------------------------------------
+# stage 2 alone, on frames built to hit the corners of the Haar / select arithmetic
+# ---------------------------------------------------------------------------------------------
+def _frames_cases(rng):
+    base = np.abs(rng.standard_normal((128, 32)).astype(np.float32)) * 100
+    cases = {"typical": base.copy()}
+    for name, scale in [("near_fast_division_limit", 2.0 ** -98), ("below_limit", 2.0 ** -104), ("denormal", 2.0 ** -130),
+                        ("near_overflow", 2.0 ** 120)]:
+        with np.errstate(over="ignore"):
+            cases[name] = (base * np.float32(scale)).astype(np.float32)     # the last one overflows to inf in places
+    mixed = base.copy()
+    mixed[::3] *= np.float32(2.0 ** -110)                  # tiny and ordinary magnitudes in one frame
+    mixed[5, 7] = np.float32(2.0 ** -127)
+    cases["mixed_magnitudes"] = mixed
+    inf = base.copy(); inf[10, 3] = np.inf
+    cases["one_inf"] = inf
+    sparse = np.zeros((128, 32), np.float32); sparse[:, 13] = base[:, 13]; sparse[:, 16] = base[:, 16]
+    cases["mostly_empty_bands"] = sparse                   # what 44.1 kHz / 1024 produces (17 empty bands)
+    cases["cancellation"] = np.tile(np.array([1.0, -1.0], np.float32), (128, 16)) * np.float32(3.0)
+    cases["all_equal"] = np.full((128, 32), np.float32(7.5))
+    cases["zeros"] = np.zeros((128, 32), np.float32)
+    neg = -base; cases["negative"] = neg.astype(np.float32)
+    return cases
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_stage2_corner_frames(lb, gpu, oracle, variant):
+    cases = _frames_cases(np.random.default_rng(3))
+    frames = np.stack(list(cases.values()))
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    det.set_kernel_variant(variant)
+    packed, haar = lb.frames_to_subfingerprints_device(det, gpu.from_numpy(frames).cuda(), want_haar=True)
+    gpu.cuda.synchronize()
+    got_bits = lb.unpack_packed(packed.cpu().numpy(), 200)
+    got_haar = haar.cpu().numpy()
+    for i, name in enumerate(cases):
+        want_haar = oracle.haar_2d(frames[i])
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(got_haar[i], want_haar, equal_nan=True), f"{name}: Haar differs (variant {variant})"
+        if not np.isnan(want_haar).any():                   # NaN payloads/signs are not comparable across CPU and GPU
+            assert np.array_equal(got_bits[i], oracle.extract(want_haar, 200)[:200]), f"{name}: bits differ"
