@@ -44,10 +44,20 @@ constexpr int kConstDw = kBins * kConstStride;
 constexpr int kLdsBytes = (kSpanDw + kTDw + kConstDw) * 4;   // 75 840 B: two workgroups per CU
 static_assert(2 * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
-struct cplx {
-    float x, y;
-};
+// A complex value is one even-aligned VGPR pair (.x = re, .y = im).  Butterflies are written on the
+// pair so that they compile to v_pk_fma_f32 / v_pk_add_f32 with op_sel swizzles and SGPR twiddle
+// pairs (two IEEE operations per instruction, no register shuffling); each half is the same
+// correctly rounded fma / add the oracle performs.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef f32x2 cplx;
+
+__device__ __forceinline__ cplx fma2(cplx a, cplx b, cplx c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cplx mk(float x, float y) {
+    cplx r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
 typedef __attribute__((address_space(3))) volatile f32x2 lds_vf32x2;   // LDS, not mergeable into ds_*2_b64
 
 __device__ __forceinline__ constexpr int brev6(int v) {
@@ -57,21 +67,20 @@ __device__ __forceinline__ constexpr int brev6(int v) {
 // full butterfly on registers, twiddle index t into the W_64 table (compile time)
 template <int T>
 __device__ __forceinline__ void bfly(cplx& u, cplx& v) {
+    const cplx a = u, b = v;
     if constexpr (T == 0) {
-        const cplx a = u, b = v;
-        u.x = a.x + b.x; u.y = a.y + b.y;
-        v.x = a.x - b.x; v.y = a.y - b.y;
-    } else if constexpr (T == 16) {  // w = -i
-        const cplx a = u, b = v;
-        u.x = a.x + b.y; u.y = a.y - b.x;
-        v.x = a.x - b.y; v.y = a.y + b.x;
+        u = a + b;
+        v = a - b;
+    } else if constexpr (T == 16) {  // w = -i: w b = (b.y, -b.x)
+        const cplx t = mk(b.y, -b.x);
+        u = a + t;
+        v = a - t;
     } else {
         constexpr float wr = kTw64Re[T], wi = kTw64Im[T];
-        const cplx a = u, b = v;
-        u.x = __fmaf_rn(wr, b.x, __fmaf_rn(-wi, b.y, a.x));
-        u.y = __fmaf_rn(wr, b.y, __fmaf_rn(wi, b.x, a.y));
-        v.x = __fmaf_rn(-wr, b.x, __fmaf_rn(wi, b.y, a.x));
-        v.y = __fmaf_rn(-wr, b.y, __fmaf_rn(-wi, b.x, a.y));
+        const cplx bs = b.yx;
+        // u.x = fma(wr, b.x, fma(-wi, b.y, a.x)), u.y = fma(wr, b.y, fma(wi, b.x, a.y)); v likewise negated
+        u = fma2(mk(wr, wr), b, fma2(mk(-wi, wi), bs, a));
+        v = fma2(mk(-wr, -wr), b, fma2(mk(wi, -wi), bs, a));
     }
 }
 
@@ -92,12 +101,9 @@ __device__ __forceinline__ void stage_blocks(cplx (&x)[64]) {
     }
 }
 
-// u + w v with a run-time twiddle (tree stages and the split pass use per-lane tables)
+// u + w v with a run-time twiddle (tree stages use per-lane tables)
 __device__ __forceinline__ cplx madd(cplx u, float wr, float wi, cplx v) {
-    cplx o;
-    o.x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
-    o.y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
-    return o;
+    return fma2(mk(wr, wr), v, fma2(mk(-wi, wi), v.yx, u));
 }
 
 // stage-6 outputs: row i < 22 is k64 = i ("+" output of pair j = i); row i >= 22 is k64 = i + 21
@@ -107,23 +113,16 @@ __device__ __forceinline__ cplx stage6_row(const cplx (&x)[64]) {
     constexpr int j = I < 22 ? I : I - 11;
     constexpr bool plus = I < 22;
     const cplx u = x[j], v = x[j + 32];
-    cplx o;
     if constexpr (j == 0) {
-        o.x = u.x + v.x; o.y = u.y + v.y;   // only the "+" output of pair 0 is needed
+        return u + v;   // only the "+" output of pair 0 is needed
     } else if constexpr (j == 16) {
-        if constexpr (plus) { o.x = u.x + v.y; o.y = u.y - v.x; }
-        else { o.x = u.x - v.y; o.y = u.y + v.x; }
+        const cplx t = mk(v.y, -v.x);
+        return plus ? u + t : u - t;
     } else {
         constexpr float wr = kTw64Re[j], wi = kTw64Im[j];
-        if constexpr (plus) {
-            o.x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
-            o.y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
-        } else {
-            o.x = __fmaf_rn(-wr, v.x, __fmaf_rn(wi, v.y, u.x));
-            o.y = __fmaf_rn(-wr, v.y, __fmaf_rn(-wi, v.x, u.y));
-        }
+        if constexpr (plus) return fma2(mk(wr, wr), v, fma2(mk(-wi, wi), v.yx, u));
+        else return fma2(mk(-wr, -wr), v, fma2(mk(wi, -wi), v.yx, u));
     }
-    return o;
 }
 
 // rows [I, END) of stage 6 -> transpose buffer rows [I - FIRST, ...).  volatile keeps the compiler
@@ -132,11 +131,7 @@ __device__ __forceinline__ cplx stage6_row(const cplx (&x)[64]) {
 template <int I, int END, int FIRST>
 __device__ __forceinline__ void store_rows(const cplx (&x)[64], float* trow) {
     if constexpr (I < END) {
-        const cplx o = stage6_row<I>(x);
-        f32x2 ov;
-        ov.x = o.x;
-        ov.y = o.y;
-        *(lds_vf32x2*)(trow + (I - FIRST) * kRowDw) = ov;
+        *(lds_vf32x2*)(trow + (I - FIRST) * kRowDw) = stage6_row<I>(x);
         store_rows<I + 1, END, FIRST>(x, trow);
     }
 }
@@ -145,9 +140,7 @@ template <int M>
 __device__ __forceinline__ void load_points(cplx (&x)[64], const float* src) {
     if constexpr (M < 64) {
         // sample 2r + 16 M of the window sits (M & 3) * 16 + (M >> 2) * 80 dwords after the lane base
-        const f32x2 v = *(const lds_vf32x2*)(src + (M & 3) * 16 + (M >> 2) * 80);
-        x[brev6(M)].x = v.x;
-        x[brev6(M)].y = v.y;
+        x[brev6(M)] = *(const lds_vf32x2*)(src + (M & 3) * 16 + (M >> 2) * 80);
         load_points<M + 1>(x, src);
     }
 }
@@ -158,8 +151,8 @@ __device__ __forceinline__ cplx tree(const float* row, const float* tw) {
     const float4 q1 = *reinterpret_cast<const float4*>(row + 4);
     const float4 q2 = *reinterpret_cast<const float4*>(row + 8);
     const float4 q3 = *reinterpret_cast<const float4*>(row + 12);
-    const cplx x0{q0.x, q0.y}, x1{q0.z, q0.w}, x2{q1.x, q1.y}, x3{q1.z, q1.w};
-    const cplx x4{q2.x, q2.y}, x5{q2.z, q2.w}, x6{q3.x, q3.y}, x7{q3.z, q3.w};
+    const cplx x0 = mk(q0.x, q0.y), x1 = mk(q0.z, q0.w), x2 = mk(q1.x, q1.y), x3 = mk(q1.z, q1.w);
+    const cplx x4 = mk(q2.x, q2.y), x5 = mk(q2.z, q2.w), x6 = mk(q3.x, q3.y), x7 = mk(q3.z, q3.w);
     const cplx y0 = madd(x0, tw[0], tw[1], x4), y1 = madd(x1, tw[0], tw[1], x5);
     const cplx y2 = madd(x2, tw[0], tw[1], x6), y3 = madd(x3, tw[0], tw[1], x7);
     const cplx z0 = madd(y0, tw[2], tw[3], y2), z1 = madd(y1, tw[2], tw[3], y3);
