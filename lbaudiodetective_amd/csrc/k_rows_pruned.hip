@@ -71,10 +71,9 @@ __device__ __forceinline__ void bfly(cplx& u, cplx& v) {
     if constexpr (T == 0) {
         u = a + b;
         v = a - b;
-    } else if constexpr (T == 16) {  // w = -i: w b = (b.y, -b.x)
-        const cplx t = mk(b.y, -b.x);
-        u = a + t;
-        v = a - t;
+    } else if constexpr (T == 16) {  // w = -i: w b = (b.y, -b.x); 1 * x + y rounds exactly like x + y
+        u = fma2(mk(1.0f, -1.0f), b.yx, a);
+        v = fma2(mk(-1.0f, 1.0f), b.yx, a);
     } else {
         constexpr float wr = kTw64Re[T], wi = kTw64Im[T];
         const cplx bs = b.yx;
@@ -116,8 +115,7 @@ __device__ __forceinline__ cplx stage6_row(const cplx (&x)[64]) {
     if constexpr (j == 0) {
         return u + v;   // only the "+" output of pair 0 is needed
     } else if constexpr (j == 16) {
-        const cplx t = mk(v.y, -v.x);
-        return plus ? u + t : u - t;
+        return plus ? fma2(mk(1.0f, -1.0f), v.yx, u) : fma2(mk(-1.0f, 1.0f), v.yx, u);
     } else {
         constexpr float wr = kTw64Re[j], wi = kTw64Im[j];
         if constexpr (plus) return fma2(mk(wr, wr), v, fma2(mk(-wi, wi), v.yx, u));
