@@ -13,6 +13,17 @@
 namespace lbad {
 namespace {
 
+// complex value = one even-aligned VGPR pair; butterflies on the pair compile to v_pk_fma_f32 with
+// op_sel swizzles (each half is the same correctly rounded fma the oracle performs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 mk2(float x, float y) {
+    f32x2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+
 // Waves own disjoint LDS regions and never exchange data, so a workgroup barrier would only make
 // them wait for each other.  LDS operations of one wave execute in order; the fences just stop the
 // compiler from moving a lane's loads above other lanes' stores.
@@ -116,9 +127,12 @@ __device__ __forceinline__ void dit_pass(float2* z, const float2* cache, const f
                         w[(1 << t) - 1 + h] = make_float2(tw[ti], tw[N + ti]);
                     }
             }
-            float2 x[G];
+            f32x2 x[G];
 #pragma unroll
-            for (int e = 0; e < G; ++e) x[e] = z[zslot(n0 + e * step)];
+            for (int e = 0; e < G; ++e) {
+                const float2 t = z[zslot(n0 + e * step)];
+                x[e] = mk2(t.x, t.y);
+            }
 #pragma unroll
             for (int t = 0; t < NS; ++t) {
                 const int half = G >> (t + 1);               // partner distance in register slots
@@ -127,15 +141,13 @@ __device__ __forceinline__ void dit_pass(float2* z, const float2* cache, const f
                     if (e & half) continue;
                     const float2 wt = w[(1 << t) - 1 + (e >> (NS - t))];
                     const float wr = wt.x, wi = wt.y;
-                    const float2 u = x[e], v = x[e + half];
-                    x[e].x = __fmaf_rn(wr, v.x, __fmaf_rn(-wi, v.y, u.x));
-                    x[e].y = __fmaf_rn(wr, v.y, __fmaf_rn(wi, v.x, u.y));
-                    x[e + half].x = __fmaf_rn(-wr, v.x, __fmaf_rn(wi, v.y, u.x));
-                    x[e + half].y = __fmaf_rn(-wr, v.y, __fmaf_rn(-wi, v.x, u.y));
+                    const f32x2 u = x[e], v = x[e + half], vs = v.yx;
+                    x[e] = fma2(mk2(wr, wr), v, fma2(mk2(-wi, wi), vs, u));
+                    x[e + half] = fma2(mk2(-wr, -wr), v, fma2(mk2(wi, -wi), vs, u));
                 }
             }
 #pragma unroll
-            for (int e = 0; e < G; ++e) z[zslot(n0 + e * step)] = x[e];
+            for (int e = 0; e < G; ++e) z[zslot(n0 + e * step)] = make_float2(x[e].x, x[e].y);
         }
     }
     wave_sync();
