@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Long randomized GPU-vs-oracle sweep (not part of the test suite): tools/fuzz_parity.py [trials] [seed]."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import lbaudiodetective_amd as lb
+from oracle import oracle as O
+
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+t0 = time.time()
+for t in range(trials):
+    kind = rng.integers(0, 4)
+    if kind == 0:      # config B shape through the specialised kernels, odd clip counts / lengths / content
+        cfg = O.Config(44100, 1024)
+        n = 1024 + 64 * 128 * int(rng.integers(1, 4)) + int(rng.integers(0, 8192))
+        clips = int(rng.integers(1, 9))
+    else:
+        cfg = O.Config(float(rng.choice([5512, 8000, 16000, 22050, 44100, 48000])), int(2 ** rng.integers(4, 13)),
+                       int(rng.integers(1, 300)), int(rng.integers(1, 65)), 1)
+        cfg.subfp_len = int(rng.integers(1, min(256, 128 * cfg.bands) + 1))
+        n = cfg.window + cfg.stride * 128 * int(rng.integers(1, 3)) + int(rng.integers(0, 128 * cfg.stride))
+        clips = int(rng.integers(1, 4))
+    pcm = O.synth_clips(int(rng.integers(0, 2**31)), int(rng.integers(0, 1000)), clips, 44100, n)
+    mode = rng.integers(0, 6)
+    if mode == 0: pcm *= np.float32(1e-3)
+    if mode == 1: pcm[:, ::2] = 0
+    if mode == 2: pcm[:, : n // 3] = pcm[:, n // 3: 2 * (n // 3)]      # repeated content: many equal coefficients
+    if mode == 3: pcm = np.sign(pcm).astype(np.float32)
+    want = O.fingerprint_batch(pcm, cfg, nthreads=8)
+    det = lb.Detective().configure(sample_rate=cfg.sample_rate, window=cfg.window, stride=cfg.stride, bands=cfg.bands,
+                                   subfp_len=cfg.subfp_len)
+    packed = det.fingerprint_clips_device(torch.from_numpy(pcm).cuda())
+    got = lb.unpack_packed(packed.cpu().numpy(), cfg.subfp_len).reshape(want.shape)
+    if not np.array_equal(got, want):
+        bad += 1
+        print("MISMATCH", t, kind, mode, cfg.sample_rate, cfg.window, cfg.stride, cfg.bands, cfg.subfp_len, n, clips, flush=True)
+    # compare leg on the fresh fingerprints
+    if want.shape[1] >= 1 and clips >= 2:
+        a, b = want[0], want[1]
+        rg = int(rng.integers(1, cfg.subfp_len + 3))
+        g = np.float32(lb.Fingerprint.from_bools(a).compare_to_fingerprint(lb.Fingerprint.from_bools(b), rg))
+        w = np.float32(O.compare_fp(a, b, rg))
+        if g.view(np.uint32) != w.view(np.uint32):
+            bad += 1
+            print("COMPARE MISMATCH", t, rg, g, w, flush=True)
+print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
