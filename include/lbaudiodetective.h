@@ -293,6 +293,14 @@ OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef inCorpus, LBAudio
 OSStatus LBAudioDetectiveCorpusQueryKeyDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                               UInt32 inRange, UInt64 inIndexBase, void* outKey, void* inStream);
 void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* outScore);
+/* Several queries against one pass over the corpus (the scan is HBM-bound: up to 8 queries share each
+ * read of an entry).  Results are those of inCount separate LBAudioDetectiveCorpusQuery calls.  The
+ * KeysDevice form writes inCount keys to the device pointer outKeys for a sharded max-reduction. */
+OSStatus LBAudioDetectiveCorpusQueryBatch(LBAudioDetectiveCorpusRef inCorpus, const LBAudioDetectiveFingerprintRef* inQueries,
+                                          UInt32 inCount, UInt32 inRange, SInt64* outIndices, Float32* outScores);
+OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef inCorpus,
+                                                    const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
+                                                    UInt32 inRange, UInt64 inIndexBase, void* outKeys, void* inStream);
 /* Per-entry scores (debug / parity): device pointer to count float32. */
 OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                             UInt32 inRange, Float32* outScores, void* inStream);

@@ -123,6 +123,8 @@ _SIGNATURES = {
     "LBAudioDetectiveCorpusQuery": (OSStatus, [Ref, Ref, UInt32, _P(SInt64), _P(Float32)]),
     "LBAudioDetectiveCorpusQueryKeyDevice": (OSStatus, [Ref, Ref, UInt32, UInt64, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveCorpusDecodeKey": (None, [UInt64, _P(SInt64), _P(Float32)]),
+    "LBAudioDetectiveCorpusQueryBatch": (OSStatus, [Ref, _P(Ref), UInt32, UInt32, _P(SInt64), _P(Float32)]),
+    "LBAudioDetectiveCorpusQueryBatchKeysDevice": (OSStatus, [Ref, _P(Ref), UInt32, UInt32, UInt64, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveCorpusScoresDevice": (OSStatus, [Ref, Ref, UInt32, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveCorpusSetKernelVariant": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveCorpusSave": (OSStatus, [Ref, C.c_char_p]),

@@ -456,6 +456,23 @@ class Corpus:
         _check(self._L.LBAudioDetectiveCorpusQuery(self._ref, fp._ref, range_, C.byref(idx), C.byref(score)), "CorpusQuery")
         return int(idx.value), float(score.value)
 
+    def query_batch(self, fps, range_: int = 0):
+        """Several queries in one pass over the corpus -> list of (index, score)."""
+        n = len(fps)
+        refs = (N.Ref * n)(*[f._ref for f in fps])
+        idx, sc = (N.SInt64 * n)(), (N.Float32 * n)()
+        _check(self._L.LBAudioDetectiveCorpusQueryBatch(self._ref, refs, n, range_, idx, sc), "CorpusQueryBatch")
+        return [(int(idx[i]), float(sc[i])) for i in range(n)]
+
+    def query_batch_keys_device(self, fps, keys_out, range_: int = 0, index_base: int = 0, stream=None):
+        """Writes len(fps) 64-bit keys into keys_out (torch int64 on the device), asynchronously."""
+        n = len(fps)
+        refs = (N.Ref * n)(*[f._ref for f in fps])
+        _check(self._L.LBAudioDetectiveCorpusQueryBatchKeysDevice(self._ref, refs, n, range_, index_base,
+                                                                 keys_out.data_ptr(), _stream_ptr(stream)),
+               "CorpusQueryBatchKeysDevice")
+        return keys_out
+
     def query_key_device(self, fp: Fingerprint, key_out, range_: int = 0, index_base: int = 0, stream=None):
         """Writes the 64-bit (score, ~index) key into key_out (torch int64[1] on the device), async."""
         _check(self._L.LBAudioDetectiveCorpusQueryKeyDevice(self._ref, fp._ref, range_, index_base, key_out.data_ptr(),

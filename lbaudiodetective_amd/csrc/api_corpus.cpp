@@ -139,6 +139,70 @@ OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef c, LBAudio
     return lbad::run_query(c, inQuery, inRange, 0, outScores, c->d_key, static_cast<hipStream_t>(inStream));
 }
 
+// Several queries in one pass over the corpus.  outKeys is a device pointer to inCount 64-bit keys.
+OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef c, const LBAudioDetectiveFingerprintRef* inQueries,
+                                                    UInt32 inCount, UInt32 inRange, UInt64 inIndexBase, void* outKeys,
+                                                    void* inStream) {
+    if (!c || !inQueries || !outKeys || inCount == 0) return kLBAudioDetectiveArgumentInvalid;
+    if (inIndexBase + c->count > 0x100000000ull) return kLBAudioDetectiveArgumentInvalid;
+    hipStream_t stream = static_cast<hipStream_t>(inStream);
+    unsigned long long* keys = static_cast<unsigned long long*>(outKeys);
+    bool all_fast = c->variant != 1;
+    for (UInt32 i = 0; i < inCount && all_fast; ++i)
+        all_fast = inQueries[i] && lbad::planes_fast_supported(c->subfp_len, c->n_sub, inQueries[i]->count) &&
+                   inQueries[i]->length == c->subfp_len;
+    if (!all_fast) {   // shapes without the specialised scan: one pass per query
+        for (UInt32 i = 0; i < inCount; ++i) {
+            OSStatus st = lbad::run_query(c, inQueries[i], inRange, inIndexBase, nullptr, keys + i, stream);
+            if (st != noErr) return st;
+        }
+        return noErr;
+    }
+    const uint32_t range = inRange ? inRange : c->subfp_len;
+    const uint32_t kw = lbad::plane_query_words();
+    const size_t words = (size_t)inCount * kw;
+    if (c->query_cap < words) {
+        if (c->d_query) (void)hipFree(c->d_query);
+        if (c->h_query) (void)hipHostFree(c->h_query);
+        c->d_query = nullptr;
+        c->h_query = nullptr;
+        c->query_cap = 0;
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_query), words * sizeof(uint32_t)));
+        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_query), words * sizeof(uint32_t), hipHostMallocDefault));
+        c->query_cap = (uint32_t)words;
+    }
+    LBAD_HIP(hipStreamSynchronize(stream));   // the pinned staging block is reused by every call
+    std::memset(c->h_query, 0, words * sizeof(uint32_t));
+    std::vector<uint32_t> slots, block;
+    for (UInt32 i = 0; i < inCount; ++i) {
+        lbad::pack_fingerprint(inQueries[i], slots);
+        lbad::build_plane_query(slots.data(), c->n_sub, range, block);
+        std::memcpy(c->h_query + (size_t)i * kw, block.data(), block.size() * sizeof(uint32_t));
+    }
+    LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    LBAD_HIP(hipMemsetAsync(keys, 0, (size_t)inCount * sizeof(unsigned long long), stream));
+    LBAD_HIP(lbad::launch_compare_planes_batch(c->d_planes, c->capacity, c->count, c->n_sub, c->d_query, inCount,
+                                               inIndexBase, keys, stream));
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveCorpusQueryBatch(LBAudioDetectiveCorpusRef c, const LBAudioDetectiveFingerprintRef* inQueries,
+                                          UInt32 inCount, UInt32 inRange, SInt64* outIndices, Float32* outScores) {
+    if (!c || inCount == 0) return kLBAudioDetectiveArgumentInvalid;
+    unsigned long long* d_keys = nullptr;
+    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d_keys), (size_t)inCount * sizeof(unsigned long long)));
+    OSStatus st = LBAudioDetectiveCorpusQueryBatchKeysDevice(c, inQueries, inCount, inRange, 0, d_keys, NULL);
+    std::vector<unsigned long long> keys(inCount);
+    if (st == noErr)
+        st = lbad::hip_status(hipMemcpy(keys.data(), d_keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost),
+                              "copy keys", __LINE__);
+    (void)hipFree(d_keys);
+    if (st != noErr) return st;
+    for (UInt32 i = 0; i < inCount; ++i)
+        LBAudioDetectiveCorpusDecodeKey(keys[i], outIndices ? outIndices + i : NULL, outScores ? outScores + i : NULL);
+    return noErr;
+}
+
 // ---- corpus file: header + the planes of the stored entries, plane-major ----------------------------
 namespace {
 struct CorpusFileHeader {

@@ -98,6 +98,10 @@ void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, 
 hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
                                       uint32_t n_sub, const uint32_t* d_qc, uint64_t index_base, float* d_scores,
                                       unsigned long long* d_key, hipStream_t stream);
+uint32_t plane_query_words();
+hipError_t launch_compare_planes_batch(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries, uint32_t n_sub,
+                                       const uint32_t* d_qblocks, uint32_t n_queries, uint64_t index_base,
+                                       unsigned long long* d_keys, hipStream_t stream);
 void pack_fingerprint(const struct ::LBAudioDetectiveFingerprint* fp, std::vector<uint32_t>& out);
 
 // synthetic data

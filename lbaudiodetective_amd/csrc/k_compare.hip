@@ -257,6 +257,63 @@ __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* _
     block_max_key(best, key_out);
 }
 
+// Batch form: up to QB queries share one pass over the corpus (the scan is HBM-bound, so a handful of
+// extra popcount rounds per entry are free).  Query blocks (kPlaneQueryWords each) sit in global memory and
+// are read with wave-uniform indices, i.e. through the scalar cache.
+constexpr int kQueryBatch = 8;
+
+template <int NSUB>
+__global__ __launch_bounds__(kThreads) void compare_planes_batch_kernel(const uint4* __restrict__ planes,
+                                                                        uint64_t stride, uint64_t n_entries,
+                                                                        const uint32_t* __restrict__ qblocks,
+                                                                        uint32_t n_queries, uint64_t index_base,
+                                                                        unsigned long long* __restrict__ keys_out) {
+    using S = PlaneShape<NSUB>;
+    unsigned long long best[kQueryBatch];
+#pragma unroll
+    for (int q = 0; q < kQueryBatch; ++q) best[q] = 0ull;
+    for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
+         e += (uint64_t)gridDim.x * kThreads) {
+        uint32_t b[S::planes * 4];
+#pragma unroll
+        for (uint32_t p = 0; p < S::planes; ++p) {
+            const uint4 v = planes[(uint64_t)p * stride + e];
+            b[4 * p + 0] = v.x; b[4 * p + 1] = v.y; b[4 * p + 2] = v.z; b[4 * p + 3] = v.w;
+        }
+#pragma unroll
+        for (int q = 0; q < kQueryBatch; ++q) {
+            if ((uint32_t)q < n_queries) {
+                const uint32_t* qc = qblocks + (size_t)q * kPlaneQueryWords;
+                float sum = 0.0f;
+#pragma unroll
+                for (uint32_t s = 0; s < (uint32_t)NSUB; ++s) {
+                    const uint32_t w0 = (s * kLp) >> 5;
+                    uint32_t hits = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < kSubSpan; ++j) {
+                        if (w0 + j < S::planes * 4) {
+                            const uint32_t x = b[w0 + j] ^ qc[w0 + j];
+                            hits += __popc(~(x | (x >> 1)) & qc[S::off_mask + s * kSubSpan + j]);
+                        }
+                    }
+                    const float possible = __uint_as_float(qc[S::off_possible + s]);
+                    const float ratio = possible > 0.0f ? __fdiv_rn((float)hits, possible) : 0.0f;
+                    sum = __fadd_rn(sum, ratio);
+                }
+                const float cand = __fdiv_rn(sum, (float)NSUB);
+                const float match = (0.0f < cand) ? cand : 0.0f;
+                const unsigned long long k = make_key(match, index_base + e);
+                best[q] = k > best[q] ? k : best[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kQueryBatch; ++q) {
+        if ((uint32_t)q < n_queries) block_max_key(best[q], keys_out + q);
+        __syncthreads();   // block_max_key reuses one LDS scratch array
+    }
+}
+
 uint32_t grid_for(uint64_t n_entries) {
     const uint64_t blocks = (n_entries + kThreads - 1) / kThreads;
     const uint64_t cap = 256ull * 8ull;  // 8 workgroups per CU, grid-stride the rest
@@ -385,6 +442,40 @@ hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stri
         case 6: return launch_planes_n<6>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
         case 7: return launch_planes_n<7>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
         case 8: return launch_planes_n<8>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        default: return hipErrorNotSupported;
+    }
+}
+
+
+template <int NSUB>
+static hipError_t launch_batch_n(const uint4* d_planes, uint64_t stride, uint64_t n_entries, const uint32_t* d_qblocks,
+                                 uint32_t n_queries, uint64_t index_base, unsigned long long* d_keys,
+                                 hipStream_t stream) {
+    for (uint32_t q0 = 0; q0 < n_queries; q0 += kQueryBatch) {
+        const uint32_t nq = n_queries - q0 < (uint32_t)kQueryBatch ? n_queries - q0 : (uint32_t)kQueryBatch;
+        hipLaunchKernelGGL(compare_planes_batch_kernel<NSUB>, dim3(grid_for(n_entries)), dim3(kThreads), 0, stream,
+                           d_planes, stride, n_entries, d_qblocks + (size_t)q0 * kPlaneQueryWords, nq, index_base,
+                           d_keys + q0);
+    }
+    return hipGetLastError();
+}
+
+uint32_t plane_query_words() { return kPlaneQueryWords; }
+
+// d_qblocks: n_queries blocks of plane_query_words() words each (build_plane_query output, zero padded)
+hipError_t launch_compare_planes_batch(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries, uint32_t n_sub,
+                                       const uint32_t* d_qblocks, uint32_t n_queries, uint64_t index_base,
+                                       unsigned long long* d_keys, hipStream_t stream) {
+    if (n_entries == 0 || n_queries == 0) return hipSuccess;
+    switch (n_sub) {
+        case 1: return launch_batch_n<1>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 2: return launch_batch_n<2>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 3: return launch_batch_n<3>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 4: return launch_batch_n<4>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 5: return launch_batch_n<5>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 6: return launch_batch_n<6>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 7: return launch_batch_n<7>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
+        case 8: return launch_batch_n<8>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
         default: return hipErrorNotSupported;
     }
 }

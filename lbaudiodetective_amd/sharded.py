@@ -54,6 +54,15 @@ class ShardedCorpus:
     def append_packed_device(self, packed, stream=None):
         self.local.append_packed_device(packed, stream)
 
+    def query_batch(self, fps, range_: int = 0, keys_out=None):
+        """Collective: several queries, one pass over every shard, one all-reduce of len(fps) int64 keys."""
+        import torch
+        if keys_out is None:
+            keys_out = torch.zeros(len(fps), dtype=torch.int64, device="cuda")
+        self.local.query_batch_keys_device(fps, keys_out, range_, index_base=self.begin)
+        allreduce_best(keys_out, self.group)
+        return [decode_key(int(k)) for k in keys_out.tolist()]
+
     def query(self, fp, range_: int = 0, key_out=None):
         """Collective: every rank calls it with the same query; returns (global index, score)."""
         import torch

@@ -671,3 +671,38 @@ def test_stage2_corner_frames(lb, gpu, oracle, variant):
             assert np.array_equal(got_haar[i], want_haar, equal_nan=True), f"{name}: Haar differs (variant {variant})"
         if not np.isnan(want_haar).any():                   # NaN payloads/signs are not comparable across CPU and GPU
             assert np.array_equal(got_bits[i], oracle.extract(want_haar, 200)[:200]), f"{name}: bits differ"
+
+
+def test_corpus_batch_queries(lb, gpu, oracle):
+    """Several queries sharing one pass over the corpus == the same queries one at a time."""
+    n = 30000
+    host = oracle.synth_corpus(CSEED + 5, 0, n, 5, 200)
+    corpus = lb.Corpus(200, 5, n)
+    corpus.append_packed_device(lb.synth_corpus_device(CSEED + 5, 0, n, 5, 200))
+    planted = [17, 29999, 12000, 12000, 5, 7777, 123, 20000, 4, 15000, 9, 26000, 1, 2, 3, 11, 13, 19999, 25000]
+    qs = [_planted_query(oracle, host[p], 0.02 * (i % 5), seed=i) for i, p in enumerate(planted)]
+    qs.append(np.zeros((5, 200), np.uint8))                         # no possible hits anywhere -> (-1, 0)
+    fps = [lb.Fingerprint.from_bools(q) for q in qs]
+    for rg in (0, 120):
+        got = corpus.query_batch(fps, rg)
+        assert got == [corpus.query(f, rg) for f in fps]
+        for (idx, sc), q in zip(got[:3], qs[:3]):
+            oi, osc = oracle.corpus_best(q, host, rg if rg else 200, nthreads=8)
+            assert (idx, np.float32(sc).view(np.uint32)) == (oi, np.float32(osc).view(np.uint32))
+    assert got[-1] == (-1, 0.0) and [g[0] for g in got[:-1]] == planted
+    # sharded form: two shards, keys max-reduced per query
+    from lbaudiodetective_amd import sharded
+    keys = []
+    for r in range(2):
+        sc = lb.ShardedCorpus(200, 5, n, rank=r, world_size=2)
+        sc.append_packed_device(lb.synth_corpus_device(CSEED + 5, sc.begin, sc.end - sc.begin, 5, 200))
+        k = gpu.zeros(len(fps), dtype=gpu.int64, device="cuda")
+        sc.local.query_batch_keys_device(fps, k, 0, index_base=sc.begin)
+        keys.append(k)
+    merged = gpu.maximum(keys[0], keys[1]).tolist()
+    assert [sharded.decode_key(int(k)) for k in merged] == corpus.query_batch(fps, 0)
+    # a shape without the specialised scan falls back to one pass per query
+    odd = lb.Corpus(64, 3, 500)
+    odd.append_packed_device(lb.synth_corpus_device(3, 0, 500, 3, 64))
+    ofp = [lb.Fingerprint.from_bools(oracle.synth_entry(3, i, 3, 64)) for i in (7, 400)]
+    assert odd.query_batch(ofp) == [(7, 1.0), (400, 1.0)]
