@@ -40,6 +40,37 @@ def allreduce_best(key_tensor, group=None):
     return key_tensor
 
 
+def broadcast_fingerprint(fp, src: int = 0, group=None, device=None):
+    """Send rank `src`'s query fingerprint to every rank (the 160-byte "query broadcast" of the sharded
+    compare).  `fp` is a Fingerprint on the source rank and may be None elsewhere; returns a Fingerprint
+    on every rank.  Two small collectives: the shape, then the Booleans."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from .api import Fingerprint
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return fp
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    shape = torch.zeros(2, dtype=torch.int64, device=device)
+    if dist.get_rank(group) == src:
+        bools = fp.to_bools()
+        shape[0], shape[1] = bools.shape[0], bools.shape[1]
+    dist.broadcast(shape, src=src, group=group)
+    n, length = int(shape[0]), int(shape[1])
+    data = torch.zeros(max(1, n * length), dtype=torch.uint8, device=device)
+    if dist.get_rank(group) == src and n * length:
+        data[: n * length] = torch.from_numpy(np.ascontiguousarray(bools).reshape(-1)).to(device)
+    dist.broadcast(data, src=src, group=group)
+    if dist.get_rank(group) == src:
+        return fp
+    out = Fingerprint(length)
+    rows = data[: n * length].cpu().numpy().reshape(n, length)
+    for row in rows:
+        out.add_subfingerprint(row)
+    return out
+
+
 class ShardedCorpus:
     """This rank's shard of a global corpus plus the collective top-1 query."""
 

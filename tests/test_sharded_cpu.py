@@ -28,6 +28,10 @@ def _worker(rank, world, port, n_entries, planted, q, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle as O
+    import lbaudiodetective_amd as lb
+    # the query exists on rank 0 only; the broadcast hands every rank an identical fingerprint
+    fq = lb.broadcast_fingerprint(lb.Fingerprint.from_bools(q) if rank == 0 else None, src=0)
+    assert np.array_equal(fq.to_bools(), q)
     begin, end = sharded.shard_range(n_entries, rank, world)
     corpus = O.synth_corpus(77, begin, end - begin, 5, 200)
     for g in planted:                       # identical entries in different shards: lowest index must win
