@@ -10,6 +10,8 @@
 // twiddles in an LDS cache laid out in consumption order.  Generic over window size; the headline configuration uses k_rows_pruned.hip instead.
 #include "internal.hpp"
 
+#include <cstdlib>
+
 namespace lbad {
 namespace {
 
@@ -255,19 +257,14 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
     }
 }
 
-template <int LOG2W>
-hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
-                      uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
-    constexpr int W = 1 << LOG2W;
-    constexpr int WPB = (W <= 4096) ? 4 : 2;
-    // the per-lane twiddle cache must leave room for the waves' own buffers
-    constexpr size_t cache_bytes = (size_t)Passes<LOG2W>::cache_slots * sizeof(float2);
-    constexpr size_t wave_bytes = (size_t)WPB * wave_floats<LOG2W>() * sizeof(float);
-    constexpr bool CACHED = cache_bytes + wave_bytes <= 160 * 1024;
+template <int LOG2W, int WPB, bool CACHED>
+hipError_t launch_variant(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
+                          uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    constexpr size_t cache_bytes = CACHED ? (size_t)Passes<LOG2W>::cache_slots * sizeof(float2) : 0;
+    constexpr size_t lds = cache_bytes + (size_t)WPB * wave_floats<LOG2W>() * sizeof(float);
     const uint32_t windows_per_clip = frames_per_clip * kRowsPerFrame;
     const uint64_t n_windows = n_clips * windows_per_clip;
     if (n_windows == 0) return hipSuccess;
-    const size_t lds = (CACHED ? cache_bytes : 0) + wave_bytes;
     auto kern = fft_bands_kernel<LOG2W, WPB, CACHED>;
     static int resident = 0;
     if (!resident) {
@@ -289,6 +286,35 @@ hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_
                        windows_per_clip, n_windows, plan.d_tw, plan.d_bands, plan.bands, plan.table.kmin,
                        plan.table.kmax, d_frames);
     return hipGetLastError();
+}
+
+// LDS-tile sizing knobs for the sweep of BASELINE configs[4] (tools/sweep_lds_tiles.py): waves per
+// workgroup and the twiddle cache can be overridden through the environment for W = 2048 and 4096.
+inline int env_int(const char* name, int fallback) {
+    const char* v = std::getenv(name);
+    return v && *v ? std::atoi(v) : fallback;
+}
+
+template <int LOG2W>
+hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
+                      uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    constexpr int W = 1 << LOG2W;
+    constexpr int WPB = (W <= 4096) ? 4 : 2;
+    // the per-lane twiddle cache must leave room for the waves' own buffers
+    constexpr size_t cache_bytes = (size_t)Passes<LOG2W>::cache_slots * sizeof(float2);
+    constexpr size_t wave_bytes = (size_t)WPB * wave_floats<LOG2W>() * sizeof(float);
+    constexpr bool CACHED = cache_bytes + wave_bytes <= 160 * 1024;
+    if constexpr (LOG2W == 11 || LOG2W == 12) {
+        const int wpb = env_int("LBAD_FFT_WPB", WPB);
+        const bool cached = env_int("LBAD_FFT_NOCACHE", 0) == 0;
+#define LBAD_V(w, c) return launch_variant<LOG2W, w, c>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream)
+        if (wpb == 1) { if (cached) LBAD_V(1, true); else LBAD_V(1, false); }
+        if (wpb == 2) { if (cached) LBAD_V(2, true); else LBAD_V(2, false); }
+        if (!cached) LBAD_V(4, false);
+#undef LBAD_V
+    }
+    return launch_variant<LOG2W, WPB, CACHED>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames,
+                                              stream);
 }
 
 }  // namespace

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: 48 kHz / 4096-point windows, stereo-summed clips -- LDS-tile sizing sweep of the
+generic stage-1 kernel: waves per workgroup x twiddle cache on/off.  Each point runs in a fresh process
+(the knobs are read when the kernel is first launched).  Prints a markdown table.
+
+    python tools/sweep_lds_tiles.py            # the sweep
+    python tools/sweep_lds_tiles.py --one      # one measurement with the current environment (internal)
+"""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if "--one" in sys.argv:
+    import torch
+    import lbaudiodetective_amd as lb
+    n = 10000
+    det = lb.Detective().configure(sample_rate=48000, window=4096)
+    clips = lb.synth_clips_device(0x4C424144, 0, n, 48000, 48000, True)
+    out = det.fingerprint_clips_device(clips)
+    torch.cuda.synchronize()
+    det.set_stage_timing(True)
+    for _ in range(3):
+        det.fingerprint_clips_device(clips, out=out)
+    s1, s2, launches = det.stage_times()
+    ms = s1 / launches
+    windows = n * out.shape[1] * 128
+    print(json.dumps({"stage1_ms": ms, "stage2_ms": s2 / launches, "windows_per_s": windows / (ms * 1e-3),
+                      "pcm_GBps": n * 48000 * 4 / (ms * 1e-3) / 1e9}))
+    sys.exit(0)
+
+rows = []
+for wpb in (1, 2, 4):
+    for nocache in (0, 1):
+        env = dict(os.environ, LBAD_FFT_WPB=str(wpb), LBAD_FFT_NOCACHE=str(nocache))
+        out = subprocess.run([sys.executable, __file__, "--one"], env=env, capture_output=True, text=True)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        r = json.loads(line[-1]) if line else {"stage1_ms": float("nan"), "windows_per_s": 0, "pcm_GBps": 0}
+        lds_wave = (2 * (2048 + 64) + 2048) * 4
+        lds = wpb * lds_wave + (0 if nocache else 55296)
+        rows.append((wpb, "off" if nocache else "on", lds, r["stage1_ms"], r["windows_per_s"], r["pcm_GBps"]))
+print("| waves / workgroup | twiddle cache | LDS per workgroup (B) | stage-1 ms (10 000 clips) | windows/s | algorithmic PCM GB/s |")
+print("|---|---|---|---|---|---|")
+for wpb, c, lds, ms, wps, gb in rows:
+    print(f"| {wpb} | {c} | {lds} | {ms:.2f} | {wps:.3g} | {gb:.1f} |")
