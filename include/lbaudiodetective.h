@@ -14,6 +14,10 @@
  * device-resident reference-fingerprint corpus with a top-1 query that returns a key a
  * host can all-reduce (max) across GPUs.
  *
+ * Threading: like upstream, nothing here is re-entrant per object -- one call at a time per detective,
+ * fingerprint, frame, stream or corpus; distinct objects are independent.  One process drives one GPU
+ * (the current HIP device at the time of the call).
+ *
  * Plain C, plain pointers and sizes only.  "Device pointer" means memory of the current
  * HIP device (e.g. torch.Tensor.data_ptr()); "stream" is a hipStream_t passed as void*
  * (NULL = the default stream).

@@ -52,6 +52,10 @@ UInt32 LBAudioDetectiveFingerprintGetNumberOfSubfingerprints(LBAudioDetectiveFin
 
 UInt32 LBAudioDetectiveFingerprintGetSubfingerprintAtIndex(LBAudioDetectiveFingerprintRef inFingerprint, UInt32 inIndex,
                                                            Boolean* outSubfingerprint) {  // :72-76 (no bounds check upstream)
+    if (inIndex >= inFingerprint->count) {   // upstream reads past its table here; give zeros instead
+        std::memset(outSubfingerprint, 0, inFingerprint->length);
+        return inFingerprint->length;
+    }
     std::memcpy(outSubfingerprint, inFingerprint->data.data() + (size_t)inIndex * inFingerprint->length,
                 inFingerprint->length);
     return inFingerprint->length;

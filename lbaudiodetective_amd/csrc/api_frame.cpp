@@ -44,6 +44,7 @@ Boolean LBAudioDetectiveFrameFull(LBAudioDetectiveFrameRef inFrame) {  // :79-81
 Boolean LBAudioDetectiveFrameSetRow(LBAudioDetectiveFrameRef inFrame, Float32* inRow, UInt32 inRowIndex,
                                     UInt32 inCount) {  // :86-105
     if (LBAudioDetectiveFrameFull(inFrame)) return 0;
+    if (inRowIndex >= inFrame->max_rows) return 0;   // upstream writes past its row table here
     inFrame->rows[inRowIndex].assign(inRow, inRow + inCount);
     inFrame->row_length = inFrame->row_length == 0 ? inCount : std::min(inFrame->row_length, inCount);
     inFrame->n_rows++;

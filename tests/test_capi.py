@@ -2,6 +2,7 @@
 host-side containers behave like the upstream ones, and compute entry points refuse to run
 (loudly, no fallback) when there is no GPU."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -154,3 +155,35 @@ def test_unsupported_and_missing_files(lb, tmp_path):
     p.write_bytes(b"not audio at all")
     assert lb.lib().LBAudioDetectiveProcessAudioURL(d._ref, str(p).encode(), C.byref(out)) == \
         lb.constant("kLBAudioDetectiveUnsupportedFile")
+
+
+def _build_example(tmp_path, lb):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "compare_urls")
+    libdir = os.path.dirname(lb.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "compare_urls.c"), "-L", libdir, "-llbaudiodetective",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_c_host_builds_against_the_header(lb, tmp_path):
+    """A C99 program written like the upstream README snippet compiles against include/ and links the
+    library: the boundary really is plain C."""
+    import subprocess
+    exe = _build_example(tmp_path, lb)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 2 and "lbaudiodetective-amd" in out.stderr
+    if not _has_gpu():
+        birds = os.path.join(os.path.dirname(__file__), "golden", "birds")
+        out = subprocess.run([exe, os.path.join(birds, "BlackBird.caf"), os.path.join(birds, "BlackBird_eql.caf")],
+                             capture_output=True, text=True)
+        assert out.returncode == 1 and "OSStatus" in out.stderr       # 'nogp': no fallback
+
+
+def test_out_of_range_indices_are_safe(lb):
+    fp = lb.Fingerprint.from_bools(np.ones((2, 8), np.uint8))
+    assert not fp.subfingerprint_at_index(5).any()
+    fr = lb.Frame(2)
+    assert not fr.set_row([1, 2], 7) and fr.number_of_rows == 0

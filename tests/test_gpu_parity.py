@@ -706,3 +706,18 @@ def test_corpus_batch_queries(lb, gpu, oracle):
     odd.append_packed_device(lb.synth_corpus_device(3, 0, 500, 3, 64))
     ofp = [lb.Fingerprint.from_bools(oracle.synth_entry(3, i, 3, 64)) for i in (7, 400)]
     assert odd.query_batch(ofp) == [(7, 1.0), (400, 1.0)]
+
+
+def test_c_host_example_on_bird_fixtures(lb, gpu, tmp_path):
+    """examples/compare_urls.c (the upstream README snippet in C99) run as its own process."""
+    import subprocess
+    from test_capi import _build_example
+    exe = _build_example(tmp_path, lb)
+    a, b = os.path.join(BIRDS, "BlackBird.caf"), os.path.join(BIRDS, "BlackBird_eql.caf")
+    out = subprocess.run([exe, a, b, "upstream-hop"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "48 sub-fingerprints of 200 Booleans" in out.stdout
+    match = float(out.stdout.strip().splitlines()[-1].split()[1])
+    det = lb.Detective()
+    det.set_file_hop_mode(1)
+    assert abs(match - det.compare_audio_urls(a, b)) < 5e-5            # printed with 4 decimals
