@@ -201,10 +201,17 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
     int parity = 0;
     while (cnt_lo > kCand && hi - lo > 1) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
+        // one vector compare per key; the per-wave count is a scalar popcount of the lane mask, so the
+        // adds and the cross-lane reduction run on the scalar unit instead of the VALU
         uint32_t c = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c += key[i] >= mid ? 1u : 0u;
-        c = block_sum(c, s_red, parity);
+        for (int i = 0; i < 16; ++i) c += (uint32_t)__popcll(__ballot(key[i] >= mid));
+        {
+            uint32_t* slot = s_red + 4 * parity;
+            if ((t & 63) == 0) slot[t >> 6] = c;
+            __syncthreads();
+            c = slot[0] + slot[1] + slot[2] + slot[3];
+        }
         parity ^= 1;
         if (c >= keep) { lo = mid; cnt_lo = c; } else { hi = mid; }
     }
