@@ -263,6 +263,31 @@ def main() -> None:
                 "achieved_GBps_layout": round(sc.local.entry_stride_bytes * n_local / (scan_ms * 1e-3) / 1e9, 2),
                 "hbm_frac_algorithmic": round(25 * per * n_local / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             }
+            if world == 1 and not args.no_cpu_baseline:
+                # the same query over the same corpus through the oracle's Boolean-per-byte loop
+                # (the reference's layout: 1000 B per entry), all usable cores; also a full-size parity check
+                from oracle import oracle as O
+                threads = usable_cores()
+                n_cmp = n_local
+                host = np.empty((n_cmp, per, 200), np.uint8)
+                for b in range(0, n_cmp, 1 << 18):
+                    m = min(1 << 18, n_cmp - b)
+                    host[b:b + m] = lb.unpack_packed(
+                        lb.synth_corpus_device(CSEED, b, m, per, 200).cpu().numpy(), 200).reshape(m, per, 200)
+                O.corpus_best(q, host[: 1 << 14], 200, nthreads=threads)
+                t1 = time.perf_counter()
+                ci, cs = O.corpus_best(q, host, 200, nthreads=threads)
+                dt = time.perf_counter() - t1
+                del host
+                result["compare"]["cpu_baseline"] = {
+                    "value": round(n_cmp / dt, 1), "unit": "entries/s", "cores": threads, "kind": "port",
+                    "sample": f"all {n_cmp} entries as {per} x 200 Booleans (the reference's layout) through "
+                              f"oracle/lbad_oracle.c:lbo_corpus_best, {threads} OpenMP threads, {dt * 1e3:.0f} ms",
+                }
+                result["compare"]["parity"] = {
+                    "entries_checked": n_cmp,
+                    "bit_exact": bool(ci == best[0] and np.float32(cs).view(np.uint32) == np.float32(best[1]).view(np.uint32)),
+                }
 
     # HBM-resident scan: the 1 M corpus (128 MB) fits the 256 MiB Infinity Cache, this one does not
     if args.corpus > 0 and args.corpus_hbm > 0 and world == 1:

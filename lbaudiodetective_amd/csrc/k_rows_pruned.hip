@@ -134,27 +134,57 @@ __device__ __forceinline__ void store_rows(const cplx (&x)[64], float* trow) {
     }
 }
 
+template <int I, int END, int FIRST>
+__device__ __forceinline__ void hold_rows(const cplx (&x)[64], cplx (&h)[kRows - kRowsA]) {
+    if constexpr (I < END) {
+        h[I - FIRST] = stage6_row<I>(x);
+        hold_rows<I + 1, END, FIRST>(x, h);
+    }
+}
+template <int I, int N>
+__device__ __forceinline__ void store_held(const cplx (&h)[kRows - kRowsA], float* trow) {
+    if constexpr (I < N) {
+        *(lds_vf32x2*)(trow + I * kRowDw) = h[I];
+        store_held<I + 1, N>(h, trow);
+    }
+}
+
 template <int M>
 __device__ __forceinline__ void load_points(cplx (&x)[64], const float* src) {
     if constexpr (M < 64) {
-        // sample 2r + 16 M of the window sits (M & 3) * 16 + (M >> 2) * 80 dwords after the lane base
-        x[brev6(M)] = *(const lds_vf32x2*)(src + (M & 3) * 16 + (M >> 2) * 80);
+        // register slot I holds point m = brev6(I): sample 2r + 16 m of the window sits
+        // (m & 3) * 16 + (m >> 2) * 80 dwords after the lane base.  Loading in slot order lets the
+        // first butterflies start while the later points are still in flight.
+        constexpr int m = brev6(M);
+        x[M] = *(const lds_vf32x2*)(src + (m & 3) * 16 + (m >> 2) * 80);
         load_points<M + 1>(x, src);
     }
 }
 
-// 7-butterfly reduction over the 8 lanes' values of one stage-6 row (DIT stages 7, 8, 9)
-__device__ __forceinline__ cplx tree(const float* row, const float* tw) {
-    const float4 q0 = *reinterpret_cast<const float4*>(row);
-    const float4 q1 = *reinterpret_cast<const float4*>(row + 4);
-    const float4 q2 = *reinterpret_cast<const float4*>(row + 8);
-    const float4 q3 = *reinterpret_cast<const float4*>(row + 12);
-    const cplx x0 = mk(q0.x, q0.y), x1 = mk(q0.z, q0.w), x2 = mk(q1.x, q1.y), x3 = mk(q1.z, q1.w);
-    const cplx x4 = mk(q2.x, q2.y), x5 = mk(q2.z, q2.w), x6 = mk(q3.x, q3.y), x7 = mk(q3.z, q3.w);
-    const cplx y0 = madd(x0, tw[0], tw[1], x4), y1 = madd(x1, tw[0], tw[1], x5);
-    const cplx y2 = madd(x2, tw[0], tw[1], x6), y3 = madd(x3, tw[0], tw[1], x7);
-    const cplx z0 = madd(y0, tw[2], tw[3], y2), z1 = madd(y1, tw[2], tw[3], y3);
-    return madd(z0, tw[4], tw[5], z1);
+// 7-butterfly reduction over the 8 lanes' values of one stage-6 row (DIT stages 7, 8, 9).  Operands
+// and evaluation are separate so that a pass can have the reads of all its rounds in flight at once.
+struct TreeIn {
+    float4 q0, q1, q2, q3;
+    f32x2 t0, t1, t2;
+};
+__device__ __forceinline__ TreeIn tree_load(const float* row, const float* tw) {
+    TreeIn in;
+    in.q0 = *reinterpret_cast<const float4*>(row);
+    in.q1 = *reinterpret_cast<const float4*>(row + 4);
+    in.q2 = *reinterpret_cast<const float4*>(row + 8);
+    in.q3 = *reinterpret_cast<const float4*>(row + 12);
+    in.t0 = *reinterpret_cast<const f32x2*>(tw);
+    in.t1 = *reinterpret_cast<const f32x2*>(tw + 2);
+    in.t2 = *reinterpret_cast<const f32x2*>(tw + 4);
+    return in;
+}
+__device__ __forceinline__ cplx tree_eval(const TreeIn& in) {
+    const cplx x0 = mk(in.q0.x, in.q0.y), x1 = mk(in.q0.z, in.q0.w), x2 = mk(in.q1.x, in.q1.y), x3 = mk(in.q1.z, in.q1.w);
+    const cplx x4 = mk(in.q2.x, in.q2.y), x5 = mk(in.q2.z, in.q2.w), x6 = mk(in.q3.x, in.q3.y), x7 = mk(in.q3.z, in.q3.w);
+    const cplx y0 = madd(x0, in.t0.x, in.t0.y, x4), y1 = madd(x1, in.t0.x, in.t0.y, x5);
+    const cplx y2 = madd(x2, in.t0.x, in.t0.y, x6), y3 = madd(x3, in.t0.x, in.t0.y, x7);
+    const cplx z0 = madd(y0, in.t1.x, in.t1.y, y2), z1 = madd(y1, in.t1.x, in.t1.y, y3);
+    return madd(z0, in.t2.x, in.t2.y, z1);
 }
 
 // per-bin constants (kBinConst floats, padded to kConstStride): [0..5] twiddles of the "+" tree (stages 7, 8,
@@ -170,6 +200,13 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const vo
                                                                          float* __restrict__ frames, int aligned16) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* span = smem;
+#ifdef LBAD_EXP_TIMELINE
+    long long ts[8];
+    ts[0] = __builtin_readcyclecounter();
+#define STAMP(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define STAMP(i)
+#endif
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
     float* tbuf = smem + kSpanDw + wave * (8 * kWinDw);
@@ -181,6 +218,12 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const vo
     // -- share one L2 instead of fetching the overlap from HBM once per XCD.
     const uint64_t unit = (uint64_t)(blockIdx.x & 7) * units_per_xcd + (blockIdx.x >> 3);   // quarter frame
     if (unit >= n_units) return;
+#ifdef LBAD_EXP_STAGGER
+    if (blockIdx.x >= 256 && blockIdx.x < 512) {
+#pragma unroll
+        for (int i = 0; i < LBAD_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+#endif
     const uint64_t frame = unit >> 2;
     const uint32_t quarter = (uint32_t)(unit & 3);
     const uint64_t clip = frame / frames_per_clip;
@@ -226,7 +269,9 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const vo
     const int band = lane & 31;
     const uint32_t b_lo = band_tbl[band], b_hi = band_tbl[kBands + band];
     const float b_div = __uint_as_float(band_tbl[2 * kBands + band]);
+    STAMP(1);
     __syncthreads();
+    STAMP(2);
 
     const int w8 = lane >> 3, r = lane & 7;
     const float inv_norm = 1.0f / (float)(kW / 4);
@@ -239,65 +284,102 @@ __global__ __launch_bounds__(kThreads, 2) void frame_rows_pruned_kernel(const vo
     stage_blocks<3, 0>(x);
     stage_blocks<4, 0>(x);
     stage_blocks<5, 0>(x);
+    STAMP(3);
 
-    // ---- B3/B4 pass 1: "+" rows through the transpose buffer, tree of Z[k] per bin task -----------
-    // bin tasks: t = lane + 64 * round over 8 windows x 22 bins
+    // ---- B3/B4: stage 6, then the "+" rows through the transpose buffer; the mirror rows wait in
+    //      registers (the 64 points are dead from here on, which leaves room to keep every read of a
+    //      pass in flight).  bin tasks: t = lane + 64 * round over 8 windows x 22 bins ------------------
     store_rows<0, kRowsA, 0>(x, tbuf + w8 * kWinDw + 2 * r);
+    cplx held[kRows - kRowsA];
+    hold_rows<kRowsA, kRows, kRowsA>(x, held);
+    int tw_[3], tk[3];
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+        const int t = lane + 64 * rd;
+        tw_[rd] = t < 8 * kBins ? t / kBins : 0;
+        tk[rd] = t < 8 * kBins ? t % kBins : 0;
+    }
     cplx za[3];
+    {
+        TreeIn in[3];
 #pragma unroll
-    for (int rd = 0; rd < 3; ++rd) {
-        const int t = lane + 64 * rd;
-        const int tw_ = t < 8 * kBins ? t / kBins : 0;
-        const int tk = t < 8 * kBins ? t % kBins : 0;
-        za[rd] = tree(tbuf + tw_ * kWinDw + tk * kRowDw, cbuf + tk * kConstStride);
+        for (int rd = 0; rd < 3; ++rd)
+            in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + tk[rd] * kRowDw, cbuf + tk[rd] * kConstStride);
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) za[rd] = tree_eval(in[rd]);
     }
+    STAMP(4);
     // ---- pass 2: mirror rows reuse the same buffer (in-order LDS: the stores cannot pass the reads) --
-    store_rows<kRowsA, kRows, kRowsA>(x, tbuf + w8 * kWinDw + 2 * r);
+    store_held<0, kRows - kRowsA>(held, tbuf + w8 * kWinDw + 2 * r);
     float pw[3];
+    {
+        TreeIn in[3];
+        f32x2 ws[3];
 #pragma unroll
-    for (int rd = 0; rd < 3; ++rd) {
-        const int t = lane + 64 * rd;
-        const int tw_ = t < 8 * kBins ? t / kBins : 0;
-        const int k = t < 8 * kBins ? t % kBins : 0;
-        const float* c = cbuf + k * kConstStride;
-        // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror)
-        const cplx b = tree(tbuf + tw_ * kWinDw + (k ? 21 - k : 0) * kRowDw, c + 6);
-        const cplx a = za[rd];
-        float re, im;
-        if (k == 0) {
-            const float sm = a.x + a.y, df = a.x - a.y;
-            re = sm + sm;
-            im = df + df;
-        } else {
-            const float sr = a.x + b.x, si = a.y - b.y;
-            const float dr = a.x - b.x, di = a.y + b.y;
-            const float wr = c[12], wi = c[13];
-            re = __fmaf_rn(wr, di, __fmaf_rn(wi, dr, sr));
-            im = __fmaf_rn(-wr, dr, __fmaf_rn(wi, di, si));
+        for (int rd = 0; rd < 3; ++rd) {
+            const int k = tk[rd];
+            const float* c = cbuf + k * kConstStride;
+            // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror)
+            in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + (k ? 21 - k : 0) * kRowDw, c + 6);
+            ws[rd] = *reinterpret_cast<const f32x2*>(c + 12);
         }
-        if (re > 0.0f) re = __fmul_rn(re, inv_norm);
-        if (im > 0.0f) im = __fmul_rn(im, inv_norm);
-        pw[rd] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+#pragma unroll
+        for (int rd = 0; rd < 3; ++rd) {
+            const int k = tk[rd];
+            const cplx b = tree_eval(in[rd]);
+            const cplx a = za[rd];
+            float re, im;
+            if (k == 0) {
+                const float sm = a.x + a.y, df = a.x - a.y;
+                re = sm + sm;
+                im = df + df;
+            } else {
+                const float sr = a.x + b.x, si = a.y - b.y;
+                const float dr = a.x - b.x, di = a.y + b.y;
+                const float wr = ws[rd].x, wi = ws[rd].y;
+                re = __fmaf_rn(wr, di, __fmaf_rn(wi, dr, sr));
+                im = __fmaf_rn(-wr, dr, __fmaf_rn(wi, di, si));
+            }
+            if (re > 0.0f) re = __fmul_rn(re, inv_norm);
+            if (im > 0.0f) im = __fmul_rn(im, inv_norm);
+            pw[rd] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        }
     }
+    STAMP(5);
     // power terms -> LDS only after every tree of the wave has read its rows
 #pragma unroll
     for (int rd = 0; rd < 3; ++rd) {
         const int t = lane + 64 * rd;
-        if (t < 8 * kBins) vbuf[(t / kBins) * 24 + (t % kBins)] = pw[rd];
+        if (t < 8 * kBins) vbuf[tw_[rd] * 24 + tk[rd]] = pw[rd];
     }
 
     // ---- B5: band means, 8 windows x 32 bands per wave ---------------------------------------------
+    // the four windows a lane serves advance together: one LDS round trip per bin instead of four
+    float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* vb = vbuf + (lane >> 5) * 24;
+    for (uint32_t k = b_lo; k < b_hi; ++k) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = vb[q * 48 + k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (v[q] == v[q] && fabsf(v[q]) != INFINITY) p[q] = __fadd_rn(p[q], v[q]);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int ww = 2 * q + (lane >> 5);
-        float p = 0.0f;
-        for (uint32_t k = b_lo; k < b_hi; ++k) {
-            const float v = vbuf[ww * 24 + k];
-            if (v == v && fabsf(v) != INFINITY) p = __fadd_rn(p, v);
-        }
-        const uint32_t row = quarter * kUnitWindows + 8 * wave + ww;
-        frames[(frame * 128 + row) * kBands + band] = __fdiv_rn(p, b_div);
+        const uint32_t row = quarter * kUnitWindows + 8 * wave + 2 * q + (lane >> 5);
+        frames[(frame * 128 + row) * kBands + band] = __fdiv_rn(p[q], b_div);
     }
+#ifdef LBAD_EXP_TIMELINE
+    STAMP(6);
+    if (lane == 0) {
+        float* o = frames + (frame * 128 + quarter * kUnitWindows + 8 * wave) * kBands;
+        for (int i = 1; i < 7; ++i) o[i - 1] = (float)(ts[i] - ts[i - 1]);
+        o[6] = (float)(ts[0] & 0xFFFFFF);
+        o[7] = (float)__builtin_amdgcn_s_getreg(((16 - 1) << 11) | 4);
+        o[8] = (float)(ts[0] >> 24 & 0xFFFFFF);
+    }
+#endif
 }
 
 }  // namespace
