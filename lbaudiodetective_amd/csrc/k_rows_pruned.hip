@@ -206,10 +206,12 @@ __device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, ui
         // `wave` is wave-uniform (an SGPR): chunk c = wave + 4 i, fully unrolled, LDS base through M0
         const float* src = static_cast<const float*>(pcm_raw) + first + lane + 64 * wave;
         float* dst = span + 80 * wave;
+        constexpr int kFull = (kSpan / 64) / kWaves;      // 47 chunks: 11 rounds of 4, then waves 0..2
 #pragma unroll
-        for (int i = 0; i < (kSpan / 64 + kWaves - 1) / kWaves; ++i)
-            if (wave + kWaves * i < kSpan / 64)
-                __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * kWaves * i), (lvoid_t*)(dst + 80 * kWaves * i), 4, 0, 0);
+        for (int i = 0; i < kFull; ++i)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * kWaves * i), (lvoid_t*)(dst + 80 * kWaves * i), 4, 0, 0);
+        if (wave < kSpan / 64 - kFull * kWaves)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * kWaves * kFull), (lvoid_t*)(dst + 80 * kWaves * kFull), 4, 0, 0);
     } else if constexpr (FMT == 1) {
         const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
         for (int s = threadIdx.x; s < kSpan; s += kThreads)
