@@ -167,26 +167,32 @@ __device__ __forceinline__ void load_points(cplx (&x)[64], const float* src) {
 // and evaluation are separate so that a pass can have the reads of all its rounds in flight at once.
 struct TreeIn {
     float4 q0, q1, q2, q3;
+};
+struct TreeTw {     // twiddles of one tree: W_128^k, W_256^k, W_512^k (or their mirror forms)
     f32x2 t0, t1, t2;
 };
-__device__ __forceinline__ TreeIn tree_load(const float* row, const float* tw) {
+__device__ __forceinline__ TreeIn tree_load(const float* row) {
     TreeIn in;
     in.q0 = *reinterpret_cast<const float4*>(row);
     in.q1 = *reinterpret_cast<const float4*>(row + 4);
     in.q2 = *reinterpret_cast<const float4*>(row + 8);
     in.q3 = *reinterpret_cast<const float4*>(row + 12);
-    in.t0 = *reinterpret_cast<const f32x2*>(tw);
-    in.t1 = *reinterpret_cast<const f32x2*>(tw + 2);
-    in.t2 = *reinterpret_cast<const f32x2*>(tw + 4);
     return in;
 }
-__device__ __forceinline__ cplx tree_eval(const TreeIn& in) {
+__device__ __forceinline__ TreeTw tree_twiddles(const float* tw) {
+    TreeTw t;
+    t.t0 = *reinterpret_cast<const f32x2*>(tw);
+    t.t1 = *reinterpret_cast<const f32x2*>(tw + 2);
+    t.t2 = *reinterpret_cast<const f32x2*>(tw + 4);
+    return t;
+}
+__device__ __forceinline__ cplx tree_eval(const TreeIn& in, const TreeTw& t) {
     const cplx x0 = mk(in.q0.x, in.q0.y), x1 = mk(in.q0.z, in.q0.w), x2 = mk(in.q1.x, in.q1.y), x3 = mk(in.q1.z, in.q1.w);
     const cplx x4 = mk(in.q2.x, in.q2.y), x5 = mk(in.q2.z, in.q2.w), x6 = mk(in.q3.x, in.q3.y), x7 = mk(in.q3.z, in.q3.w);
-    const cplx y0 = madd(x0, in.t0.x, in.t0.y, x4), y1 = madd(x1, in.t0.x, in.t0.y, x5);
-    const cplx y2 = madd(x2, in.t0.x, in.t0.y, x6), y3 = madd(x3, in.t0.x, in.t0.y, x7);
-    const cplx z0 = madd(y0, in.t1.x, in.t1.y, y2), z1 = madd(y1, in.t1.x, in.t1.y, y3);
-    return madd(z0, in.t2.x, in.t2.y, z1);
+    const cplx y0 = madd(x0, t.t0.x, t.t0.y, x4), y1 = madd(x1, t.t0.x, t.t0.y, x5);
+    const cplx y2 = madd(x2, t.t0.x, t.t0.y, x6), y3 = madd(x3, t.t0.x, t.t0.y, x7);
+    const cplx z0 = madd(y0, t.t1.x, t.t1.y, y2), z1 = madd(y1, t.t1.x, t.t1.y, y3);
+    return madd(z0, t.t2.x, t.t2.y, z1);
 }
 
 // per-bin constants (kBinConst floats, padded to kConstStride): [0..5] twiddles of the "+" tree (stages 7, 8,
@@ -284,6 +290,18 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         tk[rd] = t < 8 * kBins ? t % kBins : 0;
     }
 
+    // a lane serves the same three (window, bin) tasks in every quarter frame: their twiddles stay in registers
+    __syncthreads();
+    TreeTw twp[3], twm[3];
+    f32x2 ws[3];
+#pragma unroll
+    for (int rd = 0; rd < 3; ++rd) {
+        const float* c = cbuf + tk[rd] * kConstStride;
+        twp[rd] = tree_twiddles(c);
+        twm[rd] = tree_twiddles(c + 6);
+        ws[rd] = *reinterpret_cast<const f32x2*>(c + 12);
+    }
+
     float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // band means of the previous quarter frame, stored one iteration late
     float* out_ptr = nullptr;
 #ifdef LBAD_EXP_TIMELINE
@@ -337,10 +355,9 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         {
             TreeIn in[3];
 #pragma unroll
-            for (int rd = 0; rd < 3; ++rd)
-                in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + tk[rd] * kRowDw, cbuf + tk[rd] * kConstStride);
+            for (int rd = 0; rd < 3; ++rd) in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + tk[rd] * kRowDw);
 #pragma unroll
-            for (int rd = 0; rd < 3; ++rd) za[rd] = tree_eval(in[rd]);
+            for (int rd = 0; rd < 3; ++rd) za[rd] = tree_eval(in[rd], twp[rd]);
         }
         STAMP(4);
         // ---- pass 2: mirror rows reuse the same buffer (in-order LDS: the stores cannot pass the reads)
@@ -348,19 +365,16 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         float pw[3];
         {
             TreeIn in[3];
-            f32x2 ws[3];
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) {
                 const int k = tk[rd];
-                const float* c = cbuf + k * kConstStride;
                 // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror)
-                in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + (k ? 21 - k : 0) * kRowDw, c + 6);
-                ws[rd] = *reinterpret_cast<const f32x2*>(c + 12);
+                in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + (k ? 21 - k : 0) * kRowDw);
             }
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) {
                 const int k = tk[rd];
-                const cplx b = tree_eval(in[rd]);
+                const cplx b = tree_eval(in[rd], twm[rd]);
                 const cplx a = za[rd];
                 float re, im;
                 if (k == 0) {
