@@ -113,6 +113,16 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
     const int t = threadIdx.x;
     const uint64_t frame = blockIdx.x;
     const float root2 = __fsqrt_rn(2.0f);
+#ifdef LBAD_EXP_TIMELINE
+    long long ts[8];
+    int n_steps = 0;
+#define STAMP(i) ts[i] = __builtin_readcyclecounter()
+#define COUNT_STEP() ++n_steps
+#else
+#define STAMP(i)
+#define COUNT_STEP()
+#endif
+    STAMP(0);
 
     if (t < (int)kPackedWords) s_bits[t] = 0;
     if (t < (int)kCand) s_rank[t] = 0;
@@ -145,6 +155,7 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
         base[h * (8 * kChunkDw)] = last;
     }
     __syncthreads();
+    STAMP(1);
 
     // ---- column pass: thread = (column, chunk of 16 rows) -----------------------------------------
     const int col = t >> 3, j = t & 7;
@@ -195,6 +206,7 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < 16; ++i) key[i] = __float_as_uint(v[i]) & 0x7fffffffu;
 
+    STAMP(2);
     // ---- threshold search ---------------------------------------------------------------------------
     uint32_t lo = 0, hi = 0x80000000u, cnt_lo = kRowsPerFrame * kCols;
     uint32_t idx_bound = kRowsPerFrame * kCols;
@@ -213,8 +225,10 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
             c = slot[0] + slot[1] + slot[2] + slot[3];
         }
         parity ^= 1;
+        COUNT_STEP();
         if (c >= keep) { lo = mid; cnt_lo = c; } else { hi = mid; }
     }
+    STAMP(3);
     if (cnt_lo > kCand) {
         // plateau: more than kCand coefficients share the threshold key (e.g. digital silence).  Take
         // every key above it, then the tied ones in ascending flat-index order until `keep` is reached.
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
         }
     }
     __syncthreads();
+    STAMP(4);
     const uint32_t nc = s_ncand;
 
     // ---- rank: 2 threads per candidate, each scans half of the list ----------------------------------
@@ -273,6 +288,15 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
     }
     __syncthreads();
     if (t < (int)kPackedWords) packed[frame * kPackedWords + t] = s_bits[t];
+#ifdef LBAD_EXP_TIMELINE
+    STAMP(5);
+    if (haar_out && t == 0) {
+        float* o = haar_out + frame * (kRowsPerFrame * kCols);
+        for (int i = 1; i < 6; ++i) o[i - 1] = (float)(ts[i] - ts[i - 1]);
+        o[5] = (float)n_steps;
+        o[6] = (float)nc;
+    }
+#endif
 }
 
 }  // namespace
