@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
                                                                  uint32_t subfp_len, uint32_t* __restrict__ packed,
                                                                  float* __restrict__ haar_out) {
     __shared__ __attribute__((aligned(16))) float s_t[kCols * 8 * kChunkDw];   // [col][chunk][20]
-    __shared__ unsigned long long s_cand[kCand];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_cand[kCand];
     __shared__ uint32_t s_rank[kCand];
     __shared__ uint32_t s_red[8];
     __shared__ uint32_t s_ncand;
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
     if (t < (int)kPackedWords) s_bits[t] = 0;
     if (t < (int)kCand) s_rank[t] = 0;
     if (t == 0) s_ncand = 0;
+    reinterpret_cast<uint32_t*>(s_cand)[t] = 0;   // zero keys pad the list to a multiple of 8 for the ranking loop
 
     // ---- row pass: thread = (row, half) ---------------------------------------------------------
     {
@@ -251,13 +252,29 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
     }
 
     // ---- gather candidates: composite = key << 14 | (4095 - idx) << 2 | sign code -------------------
+    // one LDS atomic per wave: the slots of a wave's candidates follow from lane-mask popcounts
+    {
+        bool sel[16];
+        uint32_t wave_total = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t idx = pos[i] * kCols + col;
-        if (key[i] > lo || (key[i] == lo && idx < idx_bound)) {
-            const uint32_t at = atomicAdd(&s_ncand, 1u);
-            const uint32_t sg = v[i] > 0.0f ? 1u : (v[i] < 0.0f ? 2u : 0u);
-            s_cand[at] = ((unsigned long long)key[i] << 14) | ((unsigned long long)(4095u - idx) << 2) | sg;
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t idx = pos[i] * kCols + col;
+            sel[i] = key[i] > lo || (key[i] == lo && idx < idx_bound);
+            wave_total += (uint32_t)__popcll(__ballot(sel[i]));
+        }
+        uint32_t base = 0;
+        if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const unsigned long long m = __ballot(sel[i]);
+            if (sel[i]) {
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t idx = pos[i] * kCols + col;
+                const uint32_t sg = v[i] > 0.0f ? 1u : (v[i] < 0.0f ? 2u : 0u);
+                s_cand[at] = ((unsigned long long)key[i] << 14) | ((unsigned long long)(4095u - idx) << 2) | sg;
+            }
+            base += (uint32_t)__popcll(m);
         }
     }
     __syncthreads();
@@ -269,10 +286,16 @@ __global__ __launch_bounds__(kThreads) void haar_select32_kernel(const float* __
         const uint32_t i = t & 127, part = t >> 7;
         if (i < nc) {
             const unsigned long long mine = s_cand[i];
-            const uint32_t half = (nc + 1) >> 1;
-            const uint32_t j0 = part ? half : 0, j1 = part ? nc : half;
+            // blocks of 8 keys (the tail is zero-padded and never counts); each part takes half the blocks
+            const uint32_t nblk = (nc + 7) >> 3, hblk = (nblk + 1) >> 1;
+            const uint32_t b0 = part ? hblk : 0, b1 = part ? nblk : hblk;
             uint32_t r = 0;
-            for (uint32_t q = j0; q < j1; ++q) r += s_cand[q] > mine ? 1u : 0u;
+            for (uint32_t b = b0; b < b1; ++b) {
+                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_cand + 8 * b);
+                const ulonglong2 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+                r += (c0.x > mine ? 1u : 0u) + (c0.y > mine ? 1u : 0u) + (c1.x > mine ? 1u : 0u) + (c1.y > mine ? 1u : 0u) +
+                     (c2.x > mine ? 1u : 0u) + (c2.y > mine ? 1u : 0u) + (c3.x > mine ? 1u : 0u) + (c3.y > mine ? 1u : 0u);
+            }
             if (r) atomicAdd(&s_rank[i], r);
         }
     }

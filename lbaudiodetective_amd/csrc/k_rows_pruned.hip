@@ -267,7 +267,7 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         const uint32_t frame = (uint32_t)(u >> 2);          // the launcher keeps unit numbers below 2^31
         const uint32_t clip = frame / frames_per_clip;
         const uint32_t fi = frame - clip * frames_per_clip;
-        return (uint64_t)clip * samples_per_clip + (uint64_t)((fi * 128 + (uint32_t)(u & 3) * kUnitWindows) * kStride);
+        return (uint64_t)clip * samples_per_clip + (uint64_t)(fi * 128 + (uint32_t)(u & 3) * kUnitWindows) * kStride;
     };
     uint32_t* my_ctr = claim_ctr + (blockIdx.x & 7);
     const bool claimer = threadIdx.x == 0;
