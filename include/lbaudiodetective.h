@@ -219,6 +219,11 @@ OSStatus LBAudioDetectiveFingerprintClipsDeviceFormat(LBAudioDetectiveRef inDete
 /* Same, host buffers in and unpacked Booleans out (count x subfingerprintLength per clip). */
 OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef inDetective, const Float32* inClips,
                                           UInt64 inNumberOfClips, UInt64 inSamplesPerClip, Boolean* outBooleans);
+/* Same with integer PCM in host memory (inSampleFormat as above): int16 halves the bytes that cross
+ * PCIe, which is what bounds this entry point. */
+OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective, const void* inClips,
+                                                UInt32 inSampleFormat, UInt64 inNumberOfClips,
+                                                UInt64 inSamplesPerClip, Boolean* outBooleans);
 /* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band
  * count), 2 = specialised kernels (pruned 1024-point FFT for bands that read only bins 0..21, register
  * Haar/select for 128 x 32 frames); 2 returns ArgumentInvalid when the configuration has none. */

@@ -106,6 +106,7 @@ _SIGNATURES = {
     "LBAudioDetectiveStreamPush": (OSStatus, [Ref, C.c_void_p, UInt64, _P(UInt32)]),
     "LBAudioDetectiveStreamCopyFingerprint": (Ref, [Ref]),
     "LBAudioDetectiveFingerprintClips": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, C.c_void_p]),
+    "LBAudioDetectiveFingerprintClipsFormat": (OSStatus, [Ref, C.c_void_p, UInt32, UInt64, UInt64, C.c_void_p]),
     "LBAudioDetectiveSetKernelVariant": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveSetScratchLimit": (OSStatus, [Ref, UInt64]),
     "LBAudioDetectiveSetStageTiming": (OSStatus, [Ref, UInt32]),

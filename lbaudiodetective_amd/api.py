@@ -318,12 +318,14 @@ class Detective:
         return float(m.value)
 
     def fingerprint_clips(self, clips) -> np.ndarray:
-        """Host batch: [n_clips, samples] float32 -> [n_clips, count, subfp_len] Booleans."""
-        x = _f32(clips)
+        """Host batch: [n_clips, samples] float32 (or int16 / int32 PCM) -> [n_clips, count, subfp_len] Booleans."""
+        x = np.asarray(clips)
+        fmt = {np.dtype(np.int16): 1, np.dtype(np.int32): 2}.get(x.dtype, 0)
+        x = np.ascontiguousarray(x) if fmt else _f32(x)
         n, spc = x.shape
         per = self.subfingerprint_count(spc)
         out = np.zeros((n, per, self.subfingerprint_length), np.uint8)
-        _check(self._L.LBAudioDetectiveFingerprintClips(self._ref, x.ctypes.data, n, spc, out.ctypes.data),
+        _check(self._L.LBAudioDetectiveFingerprintClipsFormat(self._ref, x.ctypes.data, fmt, n, spc, out.ctypes.data),
                "FingerprintClips")
         return out
 

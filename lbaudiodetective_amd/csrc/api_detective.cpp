@@ -297,21 +297,28 @@ OSStatus LBAudioDetectiveFingerprintClipsDevice(LBAudioDetectiveRef d, const Flo
 
 OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef d, const Float32* inClips, UInt64 inNumberOfClips,
                                           UInt64 inSamplesPerClip, Boolean* outBooleans) {
-    if (!d || !inClips || !outBooleans) return kLBAudioDetectiveArgumentInvalid;
+    return LBAudioDetectiveFingerprintClipsFormat(d, inClips, 0, inNumberOfClips, inSamplesPerClip, outBooleans);
+}
+
+OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef d, const void* inClips, UInt32 inSampleFormat,
+                                                UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
+                                                Boolean* outBooleans) {
+    if (!d || !inClips || !outBooleans || inSampleFormat > 2) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
     const uint64_t per = lbad::subfingerprint_count(inSamplesPerClip, d->window, d->stride);
     if (per == 0 || inNumberOfClips == 0) return noErr;
-    const size_t pcm_bytes = (size_t)inNumberOfClips * inSamplesPerClip * sizeof(float);
+    const size_t pcm_bytes = (size_t)inNumberOfClips * inSamplesPerClip * (inSampleFormat == 1 ? 2 : 4);
     const size_t n_sub = (size_t)inNumberOfClips * per;
-    float* d_pcm = nullptr;
+    void* d_pcm = nullptr;
     uint32_t* d_packed = nullptr;
-    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d_pcm), pcm_bytes));
+    LBAD_HIP(hipMalloc(&d_pcm, pcm_bytes));
     st = lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&d_packed), n_sub * LBAD_PACKED_BYTES), "hipMalloc", __LINE__);
     std::vector<uint32_t> packed(n_sub * LBAD_PACKED_WORDS);
     if (st == noErr) st = lbad::hip_status(hipMemcpy(d_pcm, inClips, pcm_bytes, hipMemcpyHostToDevice), "copy pcm", __LINE__);
     if (st == noErr)
-        st = lbad::fingerprint_clips_device(d, d_pcm, 0, inNumberOfClips, inSamplesPerClip, d_packed, nullptr, nullptr, nullptr);
+        st = lbad::fingerprint_clips_device(d, d_pcm, inSampleFormat, inNumberOfClips, inSamplesPerClip, d_packed, nullptr,
+                                            nullptr, nullptr);
     if (st == noErr)
         st = lbad::hip_status(hipMemcpy(packed.data(), d_packed, n_sub * LBAD_PACKED_BYTES, hipMemcpyDeviceToHost),
                               "copy packed", __LINE__);

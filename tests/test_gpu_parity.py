@@ -567,6 +567,9 @@ def test_integer_pcm_matches_float_path(lb, gpu, oracle, name):
         assert np.array_equal(got, want), (name, variant, "int16")
         got = _bits(lb, det.fingerprint_clips_device(gpu.from_numpy(raw32).cuda()), cfg.subfp_len)
         assert np.array_equal(got, want32), (name, variant, "int32")
+        # host buffers (LBAudioDetectiveFingerprintClipsFormat): same bits, Booleans out
+        assert np.array_equal(det.fingerprint_clips(np.round(pcm * 32768).astype(np.int16)), want), (name, variant, "host int16")
+        assert np.array_equal(det.fingerprint_clips(raw32), want32), (name, variant, "host int32")
 
 
 @pytest.mark.parametrize("chunks", [[1] * 7 + [5000, 1, 1], [4096] * 30, [100_000], [8191, 8193, 1024, 63, 64, 65] * 4])

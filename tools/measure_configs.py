@@ -36,6 +36,11 @@ t0 = time.perf_counter()
 det.fingerprint_clips(host)
 dt = time.perf_counter() - t0
 out["B_host_buffers_pageable"] = {"clips": 4000, "s": round(dt, 4), "audio_seconds_per_s": round(4000 / dt, 1)}
+host16 = np.round(host * 32768).astype(np.int16)
+t0 = time.perf_counter()
+det.fingerprint_clips(host16)
+dt = time.perf_counter() - t0
+out["B_host_buffers_pageable_int16"] = {"clips": 4000, "s": round(dt, 4), "audio_seconds_per_s": round(4000 / dt, 1)}
 pinned = torch.from_numpy(host).pin_memory()
 dev = torch.empty((4000, 44100), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
