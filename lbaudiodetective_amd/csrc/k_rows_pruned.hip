@@ -12,8 +12,10 @@
 //     8 lanes' values of one stage-6 output; the values cross lanes through a per-wave LDS
 //     transpose buffer and one lane evaluates both trees of a bin pair (k, 512-k), the split
 //     pass, the positive-only normalisation and the power term.
-//   * A workgroup owns one frame: the frame's PCM span (127 * 64 + 1024 samples) is read from
-//     HBM once into LDS, so the 16x window overlap costs no extra HBM traffic.
+//   * The work unit is a quarter frame (32 windows): its PCM span (31 * 64 + 1024 samples) goes from
+//     HBM to LDS once, so the 16x window overlap costs no extra HBM traffic.  Persistent workgroups
+//     (two per CU) claim frames from per-XCD counters and refill the span buffer with
+//     global_load_lds behind the arithmetic of the current unit (see frame_rows_pruned_kernel).
 //
 // Executed work per window: ~10.3 k float operations instead of 25.6 k for the full transform;
 // results are bit-identical because every surviving butterfly is evaluated exactly as in the
