@@ -284,13 +284,12 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
 
     const int w8 = lane >> 3, r = lane & 7;
     const float inv_norm = 1.0f / (float)(kW / 4);
-    int tw_[3], tk[3];
+    // bin tasks: the 8 lanes of a window share its 22 bins, lane r taking bins r, r + 8, r + 16 (< 22).
+    // Eight consecutive lanes then read eight consecutive rows of one window: conflict-free b128 reads.
+    int tk[3];
 #pragma unroll
-    for (int rd = 0; rd < 3; ++rd) {
-        const int t = lane + 64 * rd;
-        tw_[rd] = t < 8 * kBins ? t / kBins : 0;
-        tk[rd] = t < 8 * kBins ? t % kBins : 0;
-    }
+    for (int rd = 0; rd < 3; ++rd) tk[rd] = r + 8 * rd < kBins ? r + 8 * rd : kBins - 1;
+    const bool last_valid = r + 16 < kBins;
 
     // a lane serves the same three (window, bin) tasks in every quarter frame: their twiddles stay in registers
     __syncthreads();
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
 
         // ---- B3/B4: stage 6, then the "+" rows through the transpose buffer; the mirror rows wait in
         //      registers (the 64 points are dead from here on, which leaves room to keep every read of a
-        //      pass in flight).  bin tasks: t = lane + 64 * round over 8 windows x 22 bins ---------------
+        //      pass in flight) -----------------------------------------------------------------------------
         store_rows<0, kRowsA, 0>(x, tbuf + w8 * kWinDw + 2 * r);
         cplx held[kRows - kRowsA];
         hold_rows<kRowsA, kRows, kRowsA>(x, held);
@@ -357,7 +356,7 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         {
             TreeIn in[3];
 #pragma unroll
-            for (int rd = 0; rd < 3; ++rd) in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + tk[rd] * kRowDw);
+            for (int rd = 0; rd < 3; ++rd) in[rd] = tree_load(tbuf + w8 * kWinDw + tk[rd] * kRowDw);
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) za[rd] = tree_eval(in[rd], twp[rd]);
         }
@@ -370,8 +369,9 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) {
                 const int k = tk[rd];
-                // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror)
-                in[rd] = tree_load(tbuf + tw_[rd] * kWinDw + (k ? 21 - k : 0) * kRowDw);
+                // mirror bin 512 - k is stage-6 row 43 - k, i.e. row 21 - k of this pass (bin 0 has no mirror:
+                // its lane reads the stale row 21, which keeps the stride, and drops the result)
+                in[rd] = tree_load(tbuf + w8 * kWinDw + (21 - k) * kRowDw);
             }
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) {
@@ -398,10 +398,8 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         STAMP(5);
         // power terms -> LDS only after every tree of the wave has read its rows
 #pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
-            const int t = lane + 64 * rd;
-            if (t < 8 * kBins) vbuf[tw_[rd] * 24 + tk[rd]] = pw[rd];
-        }
+        for (int rd = 0; rd < 3; ++rd)
+            if (rd < 2 || last_valid) vbuf[w8 * 24 + tk[rd]] = pw[rd];
 
         // ---- B5: band means, 8 windows x 32 bands per wave.  The four windows a lane serves advance
         //      together: one LDS round trip per bin instead of four. -----------------------------------
