@@ -30,23 +30,29 @@ __device__ __forceinline__ float div_root(float x, float root) { return __fdiv_r
 //     q0 = x * r;  e = fma(-d, q0, x);  q = fma(e, r, q0)        with r = RN(1 / d).
 // tools/verify_const_div.c checks ALL 2^32 inputs for d = sqrtf(2), sqrtf(32), sqrtf(128): q equals the
 // correctly rounded quotient bit for bit whenever 2^-105 <= |x| < inf (and for +0; -0 gives +0, which
-// no later step can tell apart).  Inputs outside [2^-100, FLT_MAX] other than zero are only recorded
-// here (min over |x| - 1 ulp, max over |x|, as integers); the caller redoes the whole line with true
-// divisions when a lane saw one.
+// no later step can tell apart).  The guard records what a line met and the caller redoes the whole
+// line with true divisions when a lane saw anything else:
+//   * every dividend: min over t = 2 |x|bits - 1 (one shift-add per value, one min3 per pair); zero wraps
+//     to 0xFFFFFFFF and never trips it, anything in (0, 2^-100) does;
+//   * the 16 values a line starts from: max over |x|bits <= 2^126.  Later dividends are sums and
+//     differences of quotients, at most 4x the largest input after four levels, so they stay finite.
 constexpr uint32_t kFastDivLo = 0x0D800000u;   // 2^-100
-constexpr uint32_t kFastDivHi = 0x7F7FFFFFu;   // FLT_MAX
+constexpr uint32_t kFastDivHi = 0x7E800000u;   // 2^126
 
 struct DivGuard {
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    __device__ __forceinline__ bool bad() const { return lo < kFastDivLo - 1u || hi > kFastDivHi; }
+    __device__ __forceinline__ void dividends(float a, float b) {
+        lo = min(lo, min((__float_as_uint(a) << 1) - 1u, (__float_as_uint(b) << 1) - 1u));
+    }
+    __device__ __forceinline__ void inputs(float a, float b) {
+        hi = max(hi, max(__float_as_uint(a) & 0x7fffffffu, __float_as_uint(b) & 0x7fffffffu));
+    }
+    __device__ __forceinline__ bool bad() const { return lo < 2u * kFastDivLo - 1u || hi > kFastDivHi; }
 };
 
 template <bool FAST>
-__device__ __forceinline__ float div_c(float x, float d, float r, DivGuard& g) {
+__device__ __forceinline__ float div_c(float x, float d, float r) {
     if constexpr (FAST) {
-        const uint32_t u = __float_as_uint(x) & 0x7fffffffu;
-        g.lo = min(g.lo, u - 1u);          // zero wraps to 0xFFFFFFFF and never trips the guard
-        g.hi = max(g.hi, u);
         const float q0 = __fmul_rn(x, r);
         const float e = __fmaf_rn(-d, q0, x);
         return __fmaf_rn(e, r, q0);
@@ -72,25 +78,30 @@ __device__ __forceinline__ float haar16_impl(const float (&in)[16], float (&d)[1
                                              float root2, float r_root2, DivGuard& g) {
     float a[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = div_c<FAST>(in[i], root, r_root, g);
-    float s1[8], s2[4], s3[2];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        s1[i] = div_c<FAST>(__fadd_rn(a[2 * i], a[2 * i + 1]), root2, r_root2, g);
-        d[i] = div_c<FAST>(__fsub_rn(a[2 * i], a[2 * i + 1]), root2, r_root2, g);
+    for (int i = 0; i < 16; i += 2) {
+        if constexpr (FAST) {
+            g.inputs(in[i], in[i + 1]);
+            g.dividends(in[i], in[i + 1]);
+        }
+        a[i] = div_c<FAST>(in[i], root, r_root);
+        a[i + 1] = div_c<FAST>(in[i + 1], root, r_root);
     }
+    // one butterfly: (x + y) / sqrt 2 and (x - y) / sqrt 2
+    auto bfly = [&](float x, float y, float& sum, float& dif) {
+        const float sp = __fadd_rn(x, y), sm = __fsub_rn(x, y);
+        if constexpr (FAST) g.dividends(sp, sm);
+        sum = div_c<FAST>(sp, root2, r_root2);
+        dif = div_c<FAST>(sm, root2, r_root2);
+    };
+    float s1[8], s2[4], s3[2], s4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s2[i] = div_c<FAST>(__fadd_rn(s1[2 * i], s1[2 * i + 1]), root2, r_root2, g);
-        d[8 + i] = div_c<FAST>(__fsub_rn(s1[2 * i], s1[2 * i + 1]), root2, r_root2, g);
-    }
+    for (int i = 0; i < 8; ++i) bfly(a[2 * i], a[2 * i + 1], s1[i], d[i]);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        s3[i] = div_c<FAST>(__fadd_rn(s2[2 * i], s2[2 * i + 1]), root2, r_root2, g);
-        d[12 + i] = div_c<FAST>(__fsub_rn(s2[2 * i], s2[2 * i + 1]), root2, r_root2, g);
-    }
-    d[14] = div_c<FAST>(__fsub_rn(s3[0], s3[1]), root2, r_root2, g);
-    return div_c<FAST>(__fadd_rn(s3[0], s3[1]), root2, r_root2, g);
+    for (int i = 0; i < 4; ++i) bfly(s1[2 * i], s1[2 * i + 1], s2[i], d[8 + i]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bfly(s2[2 * i], s2[2 * i + 1], s3[i], d[12 + i]);
+    bfly(s3[0], s3[1], s4, d[14]);
+    return s4;
 }
 
 __device__ __forceinline__ float haar16(const float (&in)[16], float (&d)[15], float root, float root2) {
