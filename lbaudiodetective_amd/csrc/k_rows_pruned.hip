@@ -357,12 +357,14 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
             TreeIn in[3];
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) in[rd] = tree_load(tbuf + w8 * kWinDw + tk[rd] * kRowDw);
+            // ---- pass 2: the mirror rows reuse the same buffer.  LDS executes a wave's operations in
+            //      order, so these stores cannot pass the reads above, and they are on their way while
+            //      the trees of pass 1 are evaluated. ------------------------------------------------------
+            store_held<0, kRows - kRowsA>(held, tbuf + w8 * kWinDw + 2 * r);
 #pragma unroll
             for (int rd = 0; rd < 3; ++rd) za[rd] = tree_eval(in[rd], twp[rd]);
         }
         STAMP(4);
-        // ---- pass 2: mirror rows reuse the same buffer (in-order LDS: the stores cannot pass the reads)
-        store_held<0, kRows - kRowsA>(held, tbuf + w8 * kWinDw + 2 * r);
         float pw[3];
         {
             TreeIn in[3];
