@@ -49,10 +49,11 @@ template <int LOG2W> struct Passes {
     static constexpr int stages(int p) { return (LOGN - 3 * p) >= 3 ? 3 : (LOGN - 3 * p); }
     static constexpr int groups_per_lane(int p) { return ((N >> stages(p)) + 63) / 64; }
     static constexpr int twiddles(int p) { return (1 << stages(p)) - 1; }
-    // float2 slots of the per-lane twiddle cache before pass p
+    // float2 slots of the per-lane twiddle cache before pass p (pass 0 has wave-uniform twiddles: the
+    // eighth roots of unity, kept in scalar registers instead)
     static constexpr int cache_offset(int p) {
         int o = 0;
-        for (int i = 0; i < p; ++i) o += groups_per_lane(i) * twiddles(i) * 64;
+        for (int i = 1; i < p; ++i) o += groups_per_lane(i) * twiddles(i) * 64;
         return o;
     }
     static constexpr int cache_slots = cache_offset(count);
@@ -65,7 +66,9 @@ template <int LOG2W> struct Passes {
 template <int LOG2W, int P>
 __device__ __forceinline__ void build_cache(float2* cache, const float* __restrict__ tw, int tid, int nthreads) {
     using Ps = Passes<LOG2W>;
-    if constexpr (P < Ps::count) {
+    if constexpr (P == 0) {
+        build_cache<LOG2W, 1>(cache, tw, tid, nthreads);
+    } else if constexpr (P < Ps::count) {
         constexpr int LOGN = Ps::LOGN, N = Ps::N;
         constexpr int S0 = Ps::first_stage(P), NS = Ps::stages(P), G = 1 << NS;
         constexpr int low_bits = LOGN - S0 - NS + 1, step = 1 << low_bits;
@@ -98,6 +101,58 @@ __device__ __forceinline__ void build_cache(float2* cache, const float* __restri
 // order; the stage-s partner of point n is n +- (N >> s) and its twiddle index is the bit-reversed
 // value of n's top s-1 bits.  Every butterfly uses the general nested-fma form: for the twiddles 1 and
 // -i this equals the oracle's multiplication-free form up to the sign of zeros.
+// Pass 0 (stages 1..3, or fewer for tiny windows): the twiddle of a butterfly depends only on its
+// register slot -- 1, -i and the odd eighth roots W8, W8^3 read once from the master table -- so stages
+// 1 and 2 are the oracle's multiplication-free forms and no per-lane twiddle is fetched at all.
+template <int LOG2W>
+__device__ __forceinline__ void dit_pass0(float2* z, const float* __restrict__ tw, int lane) {
+    using Ps = Passes<LOG2W>;
+    constexpr int LOGN = Ps::LOGN, N = Ps::N;
+    constexpr int NS = Ps::stages(0), G = 1 << NS;
+    constexpr int step = N >> NS;
+    // W8^1 and W8^3 exist only when the pass has a third stage
+    const float w1r = NS == 3 ? tw[1 << (LOG2W - 3)] : 0.0f, w1i = NS == 3 ? tw[N + (1 << (LOG2W - 3))] : 0.0f;
+    const float w3r = NS == 3 ? tw[3 << (LOG2W - 3)] : 0.0f, w3i = NS == 3 ? tw[N + (3 << (LOG2W - 3))] : 0.0f;
+    (void)LOGN;
+#pragma unroll 1
+    for (int q = 0; q < Ps::groups_per_lane(0); ++q) {
+        const int g = lane + 64 * q;
+        if (g < step) {
+            f32x2 x[G];
+#pragma unroll
+            for (int e = 0; e < G; ++e) {
+                const float2 t = z[zslot(g + e * step)];
+                x[e] = mk2(t.x, t.y);
+            }
+#pragma unroll
+            for (int t = 0; t < NS; ++t) {
+                const int half = G >> (t + 1);
+#pragma unroll
+                for (int e = 0; e < G; ++e) {
+                    if (e & half) continue;
+                    const int h = e >> (NS - t);                       // butterfly block of this stage
+                    const int j = t == 2 ? ((h & 1) << 1 | (h >> 1)) : h;   // bit-reversed within t bits
+                    const f32x2 u = x[e], v = x[e + half], vs = v.yx;
+                    if (j == 0) {                                       // w = 1
+                        x[e] = u + v;
+                        x[e + half] = u - v;
+                    } else if ((t == 1 && j == 1) || (t == 2 && j == 2)) {   // w = -i: w v = (v.y, -v.x)
+                        x[e] = fma2(mk2(1.0f, -1.0f), vs, u);
+                        x[e + half] = fma2(mk2(-1.0f, 1.0f), vs, u);
+                    } else {
+                        const float wr = j == 1 ? w1r : w3r, wi = j == 1 ? w1i : w3i;
+                        x[e] = fma2(mk2(wr, wr), v, fma2(mk2(-wi, wi), vs, u));
+                        x[e + half] = fma2(mk2(-wr, -wr), v, fma2(mk2(wi, -wi), vs, u));
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < G; ++e) z[zslot(g + e * step)] = make_float2(x[e].x, x[e].y);
+        }
+    }
+    wave_sync();
+}
+
 template <int LOG2W, int P, bool CACHED>
 __device__ __forceinline__ void dit_pass(float2* z, const float2* cache, const float* __restrict__ tw, int lane) {
     using Ps = Passes<LOG2W>;
@@ -157,7 +212,10 @@ __device__ __forceinline__ void dit_pass(float2* z, const float2* cache, const f
 
 template <int LOG2W, int P, bool CACHED>
 __device__ __forceinline__ void dit_all(float2* z, const float2* cache, const float* __restrict__ tw, int lane) {
-    if constexpr (P < Passes<LOG2W>::count) {
+    if constexpr (P == 0) {
+        dit_pass0<LOG2W>(z, tw, lane);
+        dit_all<LOG2W, 1, CACHED>(z, cache, tw, lane);
+    } else if constexpr (P < Passes<LOG2W>::count) {
         dit_pass<LOG2W, P, CACHED>(z, cache, tw, lane);
         dit_all<LOG2W, P + 1, CACHED>(z, cache, tw, lane);
     }
@@ -200,10 +258,17 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
         const uint64_t first = clip * samples_per_clip + (uint64_t)wi * stride;
         // sample formats: 0 float32, 1 int16 / 32768, 2 int32 / 2^31 (what LBAudioDetectiveConvertToFormat,
         // LBAudioDetective.m:413-437, asks AudioConverter to do for integer PCM)
+#ifdef LBAD_EXP_NOLOAD
+        if (fmt == 0) {
+            for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)i + (float)first;
+        }
+#else
         if (fmt == 0) {
             const float* src = static_cast<const float*>(pcm_raw) + first;
             for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = src[i];
-        } else if (fmt == 1) {
+        }
+#endif
+        else if (fmt == 1) {
             const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
             for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)src[i] * (1.0f / 32768.0f);
         } else {
@@ -212,10 +277,16 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
         }
         wave_sync();
 
+#ifndef LBAD_EXP_NOFFT
         dit_all<LOG2W, 0, CACHED>(z, cache, tw, lane);
+#endif
 
         // split pass for the bins the bands read, then the reference's per-bin power term
+#ifdef LBAD_EXP_NOSPLIT
+        for (uint32_t k = kmin + lane; k < kmin + 64 && k < kmax; k += 64) {
+#else
         for (uint32_t k = kmin + lane; k < kmax; k += 64) {
+#endif
             float re, im;
             if (k == 0) {
                 const float2 z0 = z[0];   // zslot(0) == 0
