@@ -221,8 +221,12 @@ __device__ __forceinline__ void dit_all(float2* z, const float2* cache, const fl
     }
 }
 
-// LDS floats per wave: N (+ skew) complex points, then N floats of power terms
-template <int LOG2W> constexpr int wave_floats() { return 2 * ((1 << (LOG2W - 1)) + ((1 << (LOG2W - 1)) >> 5)) + (1 << (LOG2W - 1)); }
+// LDS floats per wave: N (+ skew) complex points, then one power term per bin the bands read
+template <int LOG2W> constexpr int point_floats() { return 2 * ((1 << (LOG2W - 1)) + ((1 << (LOG2W - 1)) >> 5)); }
+inline uint32_t bins_padded(uint32_t kmin, uint32_t kmax) { return (kmax - kmin + 63u) & ~63u; }
+
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
 
 template <int LOG2W, int WPB, bool CACHED>
 __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
@@ -237,18 +241,21 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
-    constexpr int kZf = 2 * (N + (N >> 5));
+    constexpr int kZf = point_floats<LOG2W>();
+    // LDS: [per-lane twiddle cache][split-pass twiddles W^k, k in [kmin, kmax)][per wave: points, power terms]
     float2* cache = reinterpret_cast<float2*>(smem);
     constexpr int kCacheFloats = CACHED ? 2 * Passes<LOG2W>::cache_slots : 0;
-    float* zf = smem + kCacheFloats + (size_t)wave * wave_floats<LOG2W>();
+    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    float2* split_tw = reinterpret_cast<float2*>(smem + kCacheFloats);
+    float* zf = smem + kCacheFloats + 2 * nread + (size_t)wave * (kZf + nread);
     float2* z = reinterpret_cast<float2*>(zf);
     float* vbuf = zf + kZf;
-    if constexpr (CACHED) {
-        build_cache<LOG2W, 0>(cache, tw, threadIdx.x, WPB * 64);
-        __syncthreads();   // the only workgroup barrier: the shared twiddle cache is complete
+    if constexpr (CACHED) build_cache<LOG2W, 0>(cache, tw, threadIdx.x, WPB * 64);
+    for (uint32_t i = threadIdx.x; i < nread; i += WPB * 64) {
+        const uint32_t k = kmin + i < (uint32_t)N ? kmin + i : 0u;
+        split_tw[i] = make_float2(tw[k], tw[N + k]);
     }
-    const float* twr = tw;
-    const float* twi = tw + N;
+    __syncthreads();   // the only workgroup barrier: the shared twiddle tables are complete
     const float inv_norm = 1.0f / (float)(W / 4);  // (Float32)(width/2), width = W/2; exact power of two
 
     // persistent waves: each walks the windows with a stride of the whole grid
@@ -258,22 +265,23 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
         const uint64_t first = clip * samples_per_clip + (uint64_t)wi * stride;
         // sample formats: 0 float32, 1 int16 / 32768, 2 int32 / 2^31 (what LBAudioDetectiveConvertToFormat,
         // LBAudioDetective.m:413-437, asks AudioConverter to do for integer PCM)
-#ifdef LBAD_EXP_NOLOAD
+        // Sample i = lane + 64 q lands at float 2 zslot(i >> 1) + (i & 1) = lane + 66 q: each run of 64
+        // samples is one contiguous LDS row, so float32 input goes straight from HBM/L2 to LDS
+        // (global_load_lds_dword, no registers), and the integer formats need no per-sample index math.
         if (fmt == 0) {
-            for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)i + (float)first;
-        }
-#else
-        if (fmt == 0) {
-            const float* src = static_cast<const float*>(pcm_raw) + first;
-            for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = src[i];
-        }
-#endif
-        else if (fmt == 1) {
-            const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
-            for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)src[i] * (1.0f / 32768.0f);
+            const float* src = static_cast<const float*>(pcm_raw) + first + lane;
+#pragma unroll 8
+            for (int q = 0; q < W / 64; ++q)
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * q), (lvoid_t*)(zf + 66 * q), 4, 0, 0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        } else if (fmt == 1) {
+            const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first + lane;
+#pragma unroll 8
+            for (int q = 0; q < W / 64; ++q) zf[lane + 66 * q] = (float)src[64 * q] * (1.0f / 32768.0f);
         } else {
-            const int32_t* src = static_cast<const int32_t*>(pcm_raw) + first;
-            for (int i = lane; i < W; i += 64) zf[2 * zslot(i >> 1) + (i & 1)] = (float)src[i] * (1.0f / 2147483648.0f);
+            const int32_t* src = static_cast<const int32_t*>(pcm_raw) + first + lane;
+#pragma unroll 8
+            for (int q = 0; q < W / 64; ++q) zf[lane + 66 * q] = (float)src[64 * q] * (1.0f / 2147483648.0f);
         }
         wave_sync();
 
@@ -298,7 +306,8 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
                 const float2 b = z[zslot((int)(__brev((uint32_t)N - k) >> (32 - LOGN)))];
                 const float sr = a.x + b.x, si = a.y - b.y;
                 const float dr = a.x - b.x, di = a.y + b.y;
-                const float wr = twr[k], wi2 = twi[k];
+                const float2 wk = split_tw[k - kmin];
+                const float wr = wk.x, wi2 = wk.y;
                 re = __fmaf_rn(wr, di, __fmaf_rn(wi2, dr, sr));
                 im = __fmaf_rn(-wr, dr, __fmaf_rn(wi2, di, si));
             }
@@ -332,13 +341,17 @@ template <int LOG2W, int WPB, bool CACHED>
 hipError_t launch_variant(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
                           uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     constexpr size_t cache_bytes = CACHED ? (size_t)Passes<LOG2W>::cache_slots * sizeof(float2) : 0;
-    constexpr size_t lds = cache_bytes + (size_t)WPB * wave_floats<LOG2W>() * sizeof(float);
+    const uint32_t nread = bins_padded(plan.table.kmin, plan.table.kmax);
+    const size_t lds = cache_bytes + ((size_t)2 * nread + (size_t)WPB * (point_floats<LOG2W>() + nread)) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     const uint32_t windows_per_clip = frames_per_clip * kRowsPerFrame;
     const uint64_t n_windows = n_clips * windows_per_clip;
     if (n_windows == 0) return hipSuccess;
     auto kern = fft_bands_kernel<LOG2W, WPB, CACHED>;
     static int resident = 0;
-    if (!resident) {
+    static size_t resident_lds = 0;
+    if (!resident || resident_lds != lds) {
+        resident_lds = lds;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -359,33 +372,48 @@ hipError_t launch_variant(const Plan& plan, const void* d_pcm, uint32_t fmt, uin
     return hipGetLastError();
 }
 
-// LDS-tile sizing knobs for the sweep of BASELINE configs[4] (tools/sweep_lds_tiles.py): waves per
-// workgroup and the twiddle cache can be overridden through the environment for W = 2048 and 4096.
 inline int env_int(const char* name, int fallback) {
     const char* v = std::getenv(name);
     return v && *v ? std::atoi(v) : fallback;
 }
 
+// Waves per workgroup.  The per-lane twiddle cache is shared by the workgroup, every wave adds its own
+// points and power terms, and waves never wait for each other, so the best shape is the largest
+// workgroup that still fits one CU's 160 KB (one workgroup per CU, its waves spread over the SIMDs):
+// W = 2048 -> 12 waves (3 per SIMD), W = 4096 -> 6.  Smaller windows keep 4 waves and several
+// workgroups per CU.  LBAD_FFT_WPB / LBAD_FFT_NOCACHE override the choice for the LDS-tile sweep of
+// BASELINE configs[4] (tools/sweep_lds_tiles.py).
+template <int LOG2W, int WPB>
+bool fits(const Plan& plan, bool cached) {
+    const size_t cache_bytes = cached ? (size_t)Passes<LOG2W>::cache_slots * sizeof(float2) : 0;
+    const uint32_t nread = bins_padded(plan.table.kmin, plan.table.kmax);
+    return cache_bytes + ((size_t)2 * nread + (size_t)WPB * (point_floats<LOG2W>() + nread)) * sizeof(float) <= 160 * 1024;
+}
+
 template <int LOG2W>
 hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
                       uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
-    constexpr int W = 1 << LOG2W;
-    constexpr int WPB = (W <= 4096) ? 4 : 2;
-    // the per-lane twiddle cache must leave room for the waves' own buffers
-    constexpr size_t cache_bytes = (size_t)Passes<LOG2W>::cache_slots * sizeof(float2);
-    constexpr size_t wave_bytes = (size_t)WPB * wave_floats<LOG2W>() * sizeof(float);
-    constexpr bool CACHED = cache_bytes + wave_bytes <= 160 * 1024;
-    if constexpr (LOG2W == 11 || LOG2W == 12) {
-        const int wpb = env_int("LBAD_FFT_WPB", WPB);
-        const bool cached = env_int("LBAD_FFT_NOCACHE", 0) == 0;
-#define LBAD_V(w, c) return launch_variant<LOG2W, w, c>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream)
-        if (wpb == 1) { if (cached) LBAD_V(1, true); else LBAD_V(1, false); }
-        if (wpb == 2) { if (cached) LBAD_V(2, true); else LBAD_V(2, false); }
-        if (!cached) LBAD_V(4, false);
-#undef LBAD_V
+    const int want = env_int("LBAD_FFT_WPB", 0);
+    const bool cached = env_int("LBAD_FFT_NOCACHE", 0) == 0;
+#define LBAD_TRY(w)                                                                                              \
+    if ((want == 0 || want == w) && fits<LOG2W, w>(plan, cached)) {                                             \
+        if (cached) return launch_variant<LOG2W, w, true>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream); \
+        return launch_variant<LOG2W, w, false>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream); \
     }
-    return launch_variant<LOG2W, WPB, CACHED>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames,
-                                              stream);
+    if constexpr (LOG2W == 11) {
+        LBAD_TRY(12) LBAD_TRY(8) LBAD_TRY(4) LBAD_TRY(2) LBAD_TRY(1)
+    } else if constexpr (LOG2W == 12) {
+        LBAD_TRY(6) LBAD_TRY(4) LBAD_TRY(2) LBAD_TRY(1)
+    } else if constexpr (LOG2W == 13) {
+        LBAD_TRY(2) LBAD_TRY(1)
+    } else {
+        LBAD_TRY(4)
+    }
+#undef LBAD_TRY
+    // the cache does not fit beside even the smallest workgroup: global twiddle loads
+    if constexpr (LOG2W >= 12)
+        return launch_variant<LOG2W, 1, false>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
+    return launch_variant<LOG2W, 4, false>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream);
 }
 
 }  // namespace
