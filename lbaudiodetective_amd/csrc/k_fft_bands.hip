@@ -114,7 +114,7 @@ __device__ __forceinline__ void dit_pass0(float2* z, const float* __restrict__ t
     const float w1r = NS == 3 ? tw[1 << (LOG2W - 3)] : 0.0f, w1i = NS == 3 ? tw[N + (1 << (LOG2W - 3))] : 0.0f;
     const float w3r = NS == 3 ? tw[3 << (LOG2W - 3)] : 0.0f, w3i = NS == 3 ? tw[N + (3 << (LOG2W - 3))] : 0.0f;
     (void)LOGN;
-#pragma unroll 1
+#pragma unroll 2
     for (int q = 0; q < Ps::groups_per_lane(0); ++q) {
         const int g = lane + 64 * q;
         if (g < step) {
@@ -161,9 +161,9 @@ __device__ __forceinline__ void dit_pass(float2* z, const float2* cache, const f
     constexpr int low_bits = LOGN - S0 - NS + 1;        // bits of n below the NS varying ones
     constexpr int step = 1 << low_bits;                  // distance handled by the last stage of the pass
     constexpr int T = Ps::twiddles(P);
-    // groups of one lane are processed one after the other: unrolling them all only multiplies the
-    // live registers (8 points + 7 twiddles each)
-#pragma unroll 1
+    // two groups of a lane are in flight together (their LDS round trips overlap); unrolling them all
+    // only multiplies the live registers (8 points + 7 twiddles each)
+#pragma unroll 2
     for (int q = 0; q < Ps::groups_per_lane(P); ++q) {
         const int g = lane + 64 * q;
         if (g < N / G) {

@@ -29,16 +29,19 @@ if "--one" in sys.argv:
     sys.exit(0)
 
 rows = []
-for wpb in (1, 2, 4):
+CACHE = 40960            # per-lane twiddle cache of passes 1..3 at W = 4096 (pass 0 uses scalar constants)
+NREAD = 384              # bins 3..347 read by the bands, padded to 64
+PER_WAVE = (2 * (2048 + 64) + NREAD) * 4
+for wpb in (1, 2, 4, 6):
     for nocache in (0, 1):
         env = dict(os.environ, LBAD_FFT_WPB=str(wpb), LBAD_FFT_NOCACHE=str(nocache))
         out = subprocess.run([sys.executable, __file__, "--one"], env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         r = json.loads(line[-1]) if line else {"stage1_ms": float("nan"), "windows_per_s": 0, "pcm_GBps": 0}
-        lds_wave = (2 * (2048 + 64) + 2048) * 4
-        lds = wpb * lds_wave + (0 if nocache else 55296)
-        rows.append((wpb, "off" if nocache else "on", lds, r["stage1_ms"], r["windows_per_s"], r["pcm_GBps"]))
-print("| waves / workgroup | twiddle cache | LDS per workgroup (B) | stage-1 ms (10 000 clips) | windows/s | algorithmic PCM GB/s |")
-print("|---|---|---|---|---|---|")
-for wpb, c, lds, ms, wps, gb in rows:
-    print(f"| {wpb} | {c} | {lds} | {ms:.2f} | {wps:.3g} | {gb:.1f} |")
+        lds = wpb * PER_WAVE + 2 * NREAD * 4 + (0 if nocache else CACHE)
+        per_cu = min(160 * 1024 // lds, 32 // wpb)
+        rows.append((wpb, "off" if nocache else "on", lds, per_cu, per_cu * wpb, r["stage1_ms"], r["windows_per_s"], r["pcm_GBps"]))
+print("| waves / workgroup | twiddle cache | LDS per workgroup (B) | workgroups / CU | waves / CU | stage-1 ms (10 000 clips) | windows/s | algorithmic PCM GB/s |")
+print("|---|---|---|---|---|---|---|---|")
+for wpb, c, lds, per_cu, waves, ms, wps, gb in rows:
+    print(f"| {wpb} | {c} | {lds} | {per_cu} | {waves} | {ms:.2f} | {wps:.3g} | {gb:.1f} |")
