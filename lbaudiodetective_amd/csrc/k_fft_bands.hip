@@ -269,11 +269,13 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
         // samples is one contiguous LDS row, so float32 input goes straight from HBM/L2 to LDS
         // (global_load_lds_dword, no registers), and the integer formats need no per-sample index math.
         if (fmt == 0) {
+#ifndef LBAD_EXP_NOLOAD
             const float* src = static_cast<const float*>(pcm_raw) + first + lane;
 #pragma unroll 8
             for (int q = 0; q < W / 64; ++q)
                 __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * q), (lvoid_t*)(zf + 66 * q), 4, 0, 0);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
         } else if (fmt == 1) {
             const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first + lane;
 #pragma unroll 8
@@ -290,11 +292,17 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
 #endif
 
         // split pass for the bins the bands read, then the reference's per-bin power term
+        // (the trip count is wave-uniform -- nread is a multiple of 64 -- so two iterations can be in flight;
+        // lanes past kmax redo bin kmin and drop the result)
 #ifdef LBAD_EXP_NOSPLIT
-        for (uint32_t k = kmin + lane; k < kmin + 64 && k < kmax; k += 64) {
+        for (uint32_t it = 0; it < 1; ++it) {
 #else
-        for (uint32_t k = kmin + lane; k < kmax; k += 64) {
+#pragma unroll 2
+        for (uint32_t it = 0; it < nread / 64; ++it) {
 #endif
+            const uint32_t kk = kmin + lane + 64 * it;
+            const bool live = kk < kmax;
+            const uint32_t k = live ? kk : kmin;
             float re, im;
             if (k == 0) {
                 const float2 z0 = z[0];   // zslot(0) == 0
@@ -313,7 +321,8 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
             }
             if (re > 0.0f) re = __fmul_rn(re, inv_norm);
             if (im > 0.0f) im = __fmul_rn(im, inv_norm);
-            vbuf[k - kmin] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+            const float pw = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+            if (live) vbuf[k - kmin] = pw;
         }
         wave_sync();
 
@@ -322,14 +331,17 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
             const float div = __uint_as_float(band_tbl[2 * nbands + b]);
             // the sum must run in bin order (float32 addition is not associative); the loads are issued
             // in batches of 8 so that their LDS latency overlaps instead of serialising with the adds
+            // A skipped term (past the band, NaN, inf: LBAudioDetective.m:398-401) is replaced by +0, which
+            // leaves p -- a sum of squares, never -0 -- unchanged; that keeps the selects off the chain of adds.
             float p = 0.0f;
             for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
                 float x[8];
 #pragma unroll
                 for (uint32_t q = 0; q < 8; ++q) x[q] = (k0 + q < hi) ? vbuf[k0 + q - kmin] : 0.0f;
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q)
-                    if (k0 + q < hi && x[q] == x[q] && fabsf(x[q]) != INFINITY) p = __fadd_rn(p, x[q]);
+                for (uint32_t q = 0; q < 8; ++q) x[q] = (x[q] == x[q] && fabsf(x[q]) != INFINITY) ? x[q] : 0.0f;
+#pragma unroll
+                for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, x[q]);
             }
             frames[win * nbands + b] = __fdiv_rn(p, div);
         }
