@@ -49,6 +49,7 @@ struct Plan {
     uint32_t* d_bands = nullptr;  // [bands] lo, [bands] hi, then [bands] divisor as float bits
     float* d_bin_const = nullptr; // per-bin twiddles of the pruned kernel (only when pruned_ok)
     bool pruned_ok = false;
+    bool full_ok = false;         // k_rows_full.hip applies
     bool valid = false;
 };
 
@@ -66,6 +67,11 @@ void rows_pruned_constants(std::vector<float>& out);
 hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint32_t fmt,
                               uint64_t n_clips, uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
                               hipStream_t stream);
+
+// specialised stage 1 without pruning (k_rows_full.hip): 1024- and 2048-sample windows, any band table
+bool rows_full_supported(const Plan& plan);
+hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
+                            uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
 
 // specialised stage 2 (k_haar_select32.hip): 128 x 32 frames, keep <= 128
 bool haar_select32_supported(const Plan& plan);

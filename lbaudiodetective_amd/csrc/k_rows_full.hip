@@ -1,0 +1,360 @@
+// k_rows_full.hip -- specialised stage 1 for 1024- and 2048-sample windows with ANY band table
+// (the reference's default 5512 Hz / 2048 among them): windows -> 128 x bands frame rows.
+//
+// Same arithmetic as k_fft_bands.hip / oracle rfft_exec (radix-2 DIT, nested-fma butterflies), laid out
+// like k_rows_pruned.hip but without pruning:
+//
+//   * L = N / 64 lanes own one window (N = W / 2 complex points; L = 8 or 16).  Lane r holds the 64
+//     points z[r + L m] and runs DIT stages 1..6 in registers with compile-time twiddles.
+//   * The remaining log2 L stages are, for every k64, an L-point transform over the lanes' values
+//     X_r[k64].  They cross lanes through a per-wave LDS transpose, one row per lane and pass: in pass
+//     p lane j receives the L values of "its" row, runs the L-point DIT in registers with the row's
+//     L - 1 twiddles (an LDS table built once per workgroup) and ends up with the bins k64 + 64 u.
+//   * Lane j is given rows in pairs (a, 64 - a) -- and (0, 32) -- because bin k of the real transform
+//     needs Z[k] and Z[N - k]: with that pairing the split pass, the positive-only normalisation and
+//     the power term are lane-local.  Power terms of the bins the bands read go to LDS, band sums run
+//     in bin order as in the reference.
+//   * A workgroup (4 waves) owns 256 / L consecutive windows of one frame and reads their PCM span from
+//     HBM once.
+#include "internal.hpp"
+#include "fft64_lane.hpp"
+
+#include <type_traits>
+
+namespace lbad {
+namespace {
+
+using namespace lane64;
+
+constexpr int kStride = 64;
+constexpr int kWaves = 4;
+constexpr int kThreads = kWaves * 64;
+
+template <int LOG2L> struct Shape {
+    static constexpr int L = 1 << LOG2L;               // lanes per window
+    static constexpr int N = 64 * L;                   // complex points
+    static constexpr int W = 2 * N;                    // samples per window
+    static constexpr int LOG2W = 7 + LOG2L;
+    static constexpr int R = 64 / L;                   // rows (k64 values) per lane = transpose passes
+    static constexpr int WPW = 64 / L;                 // windows per wave
+    static constexpr int UW = kWaves * WPW;            // windows per workgroup
+    static constexpr int kSpan = (UW - 1) * kStride + W;
+    // the L lanes of a window read 2 L consecutive floats; the windows of a 32-lane group must land on
+    // disjoint banks: skew every run of 64 samples by 2 L dwords
+    static constexpr int kSkew = 2 * L;
+    static constexpr int kSpanDw = kSpan + kSkew * (kSpan >> 6);
+    static constexpr int kRowDw = 2 * L + 4;           // transpose row: L values of 8 B, padded by 16 B
+    // one pass of one window; the windows a 32-lane group writes together must start 2 L banks apart
+    static constexpr int kWinDw = L * kRowDw + (L == 8 ? 16 : 32);
+    static constexpr int kTwRowDw = 2 * L + 2;         // cross-lane twiddles of one row: (L - 1) x 8 B, padded
+};
+
+// L-point DIT over the lanes' values of one row.  v[] is in bit-reversed lane order on entry (slot i
+// holds lane brev(i)) and in natural order of u on exit: v[u] = X[k64 + 64 u].  tw[] holds the row's
+// twiddles stage by stage: [1][2][4]...; butterfly jj of a stage uses W^(k64 + 64 jj).
+template <int L>
+__device__ __forceinline__ void cross_fft(cplx (&v)[L], const float* tw) {
+    int t0 = 0;
+#pragma unroll
+    for (int half = 1; half < L; half <<= 1) {
+        cplx w[L / 2];
+#pragma unroll
+        for (int jj = 0; jj < half; ++jj) w[jj] = *reinterpret_cast<const f32x2*>(tw + 2 * (t0 + jj));
+#pragma unroll
+        for (int b = 0; b < L; b += 2 * half)
+#pragma unroll
+            for (int jj = 0; jj < half; ++jj) {
+                const cplx a = v[b + jj], c = v[b + jj + half], cs = c.yx;
+                const float wr = w[jj].x, wi = w[jj].y;
+                v[b + jj] = fma2(mk(wr, wr), c, fma2(mk(-wi, wi), cs, a));
+                v[b + jj + half] = fma2(mk(-wr, -wr), c, fma2(mk(wi, -wi), cs, a));
+            }
+        t0 += half;
+    }
+}
+
+template <int L> __device__ __forceinline__ constexpr int brevL(int v) {
+    int r = 0;
+    for (int b = 1; b < L; b <<= 1) {
+        r = (r << 1) | (v & 1);
+        v >>= 1;
+    }
+    return r;
+}
+
+template <int LOG2L, int M>
+__device__ __forceinline__ void load_points64(cplx (&x)[64], const float* src) {
+    using S = Shape<LOG2L>;
+    if constexpr (M < 64) {
+        // register slot M holds point m = brev6(M) of this lane: samples 2 (r + L m), 2 (r + L m) + 1 of
+        // the window, i.e. 2 L m floats after the lane base plus the skew of the 64-sample runs crossed
+        // (2 r + (2 L m mod 64) < 64, so the lane offset never crosses a run itself)
+        constexpr int m = brev6(M);
+        constexpr int off = 2 * S::L * m + S::kSkew * ((2 * S::L * m) >> 6);
+        x[M] = *(const lds_vf32x2*)(src + off);
+        load_points64<LOG2L, M + 1>(x, src);
+    }
+}
+
+// pass P of the transpose: destination lane j receives row  rho(j, P) = P even ? j R/2 + P/2
+//                                                                     : 64 - (j R/2 + P/2)  (32 for slot 0)
+template <int LOG2L, int P, int J>
+__device__ __forceinline__ void store_pass(const cplx (&x)[64], float* tcol) {
+    using S = Shape<LOG2L>;
+    if constexpr (J < S::L) {
+        constexpr int slot = J * (S::R / 2) + P / 2;
+        constexpr int row = (P & 1) == 0 ? slot : (slot == 0 ? 32 : 64 - slot);
+        *(lds_vf32x2*)(tcol + J * S::kRowDw) = x[row];
+        store_pass<LOG2L, P, J + 1>(x, tcol);
+    }
+}
+
+template <int LOG2L, int FMT>
+__global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint64_t samples_per_clip,
+                                                                 uint32_t frames_per_clip, uint64_t n_units,
+                                                                 uint64_t units_per_xcd, const float* __restrict__ tw,
+                                                                 const uint32_t* __restrict__ band_tbl, uint32_t nbands,
+                                                                 uint32_t kmin, uint32_t kmax, float* __restrict__ frames) {
+    using S = Shape<LOG2L>;
+    constexpr int L = S::L, N = S::N, R = S::R, WPW = S::WPW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][per wave: transpose pass / power terms]
+    float* span = smem;
+    float* ctw = smem + S::kSpanDw;
+    float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
+    const uint32_t wave_dw = (uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread;
+    float* tbuf = reinterpret_cast<float*>(split_tw + nread) + wave * wave_dw;
+    float* vbuf = tbuf;   // the power terms reuse the wave's transpose area after the last pass
+
+    // XCD-aware unit mapping as in k_rows_pruned.hip (speed only)
+    const uint64_t unit = (uint64_t)(blockIdx.x & 7) * units_per_xcd + (blockIdx.x >> 3);
+    if (unit >= n_units) return;
+    constexpr int kUnitsPerFrame = 128 / S::UW;
+    const uint64_t frame = unit / kUnitsPerFrame;
+    const uint32_t part = (uint32_t)(unit % kUnitsPerFrame);
+    const uint64_t clip = frame / frames_per_clip;
+    const uint32_t fi = (uint32_t)(frame % frames_per_clip);
+    const uint64_t first = clip * samples_per_clip + ((uint64_t)fi * 128 + part * S::UW) * kStride;
+
+    // ---- A: span -> LDS (skewed), twiddle tables ---------------------------------------------------
+    if constexpr (FMT == 0) {
+        const float* src = static_cast<const float*>(pcm_raw) + first;
+        for (int s = threadIdx.x; s < S::kSpan; s += kThreads) span[s + S::kSkew * (s >> 6)] = src[s];
+    } else if constexpr (FMT == 1) {
+        const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
+        for (int s = threadIdx.x; s < S::kSpan; s += kThreads) span[s + S::kSkew * (s >> 6)] = (float)src[s] * (1.0f / 32768.0f);
+    } else {
+        const int32_t* src = static_cast<const int32_t*>(pcm_raw) + first;
+        for (int s = threadIdx.x; s < S::kSpan; s += kThreads)
+            span[s + S::kSkew * (s >> 6)] = (float)src[s] * (1.0f / 2147483648.0f);
+    }
+    // cross-lane stage t = 1..log2 L (overall stage s = 6 + t): butterfly jj of row k64 uses
+    // W_(2^s)^(k64 + 64 jj) = tw[(k64 + 64 jj) << (LOG2W - s)]
+    for (int i = threadIdx.x; i < 64 * (L - 1); i += kThreads) {
+        const int row = i / (L - 1), e = i % (L - 1);
+        int t = 1;
+        while ((1 << t) - 1 <= e) ++t;
+        const int jj = e - ((1 << (t - 1)) - 1);
+        const uint32_t ti = (uint32_t)(row + 64 * jj) << (S::LOG2W - 6 - t);
+        ctw[row * S::kTwRowDw + 2 * e] = tw[ti];
+        ctw[row * S::kTwRowDw + 2 * e + 1] = tw[N + ti];
+    }
+    for (uint32_t i = threadIdx.x; i < nread; i += kThreads) {
+        const uint32_t k = kmin + i < (uint32_t)N ? kmin + i : 0u;
+        split_tw[i] = make_float2(tw[k], tw[N + k]);
+    }
+    __syncthreads();
+
+    const int wl = lane / L, r = lane % L;          // window of the wave, lane of the window
+    const float inv_norm = 1.0f / (float)(S::W / 4);
+
+    // ---- B: 64 points of this lane, DIT stages 1..6 in registers -----------------------------------
+    cplx x[64];
+    {
+        // window w of the workgroup starts at sample 64 w, i.e. at float (64 + kSkew) w
+        const int w = wave * WPW + wl;
+        load_points64<LOG2L, 0>(x, span + (64 + S::kSkew) * w + 2 * r);
+    }
+    stage_blocks<1, 0>(x);
+    stage_blocks<2, 0>(x);
+    stage_blocks<3, 0>(x);
+    stage_blocks<4, 0>(x);
+    stage_blocks<5, 0>(x);
+    stage_blocks<6, 0>(x);
+
+    // ---- C: log2 L cross-lane stages, R passes; pairs of passes end in the split pass ---------------
+    float* tcol = tbuf + wl * S::kWinDw + 2 * r;                 // this lane's column of its window's pass
+    const float* trow = tbuf + wl * S::kWinDw + r * S::kRowDw;   // the row this lane receives
+    float pw[R / 2][2 * L];
+    auto run_pass = [&](auto pass_tag, cplx (&y)[L], int row) {
+        constexpr int P = decltype(pass_tag)::value;
+        store_pass<LOG2L, P, 0>(x, tcol);
+#pragma unroll
+        for (int i = 0; i < L; i += 2) {
+            const float4 q = *reinterpret_cast<const float4*>(trow + 2 * i);
+            y[brevL<L>(i)] = mk(q.x, q.y);
+            y[brevL<L>(i + 1)] = mk(q.z, q.w);
+        }
+        cross_fft<L>(y, ctw + row * S::kTwRowDw);
+    };
+    // power term of bin k from A = Z[k], B = Z[N - k] (LBAudioDetective.m:373-396 after the vDSP packing)
+    auto power = [&](cplx a, cplx b, uint32_t k) -> float {
+        const uint32_t ks = k >= kmin && k < kmax ? k - kmin : 0u;     // bins outside the bands: computed, never stored
+        const float2 wk = split_tw[ks];
+        const float sr = a.x + b.x, si = a.y - b.y;
+        const float dr = a.x - b.x, di = a.y + b.y;
+        float re = __fmaf_rn(wk.x, di, __fmaf_rn(wk.y, dr, sr));
+        float im = __fmaf_rn(-wk.x, dr, __fmaf_rn(wk.y, di, si));
+        if (k == 0) {                                                   // DC and Nyquist share bin 0
+            const float sm = a.x + a.y, df = a.x - a.y;
+            re = sm + sm;
+            im = df + df;
+        }
+        if (re > 0.0f) re = __fmul_rn(re, inv_norm);
+        if (im > 0.0f) im = __fmul_rn(im, inv_norm);
+        return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+    };
+    auto slot_work = [&](auto q_tag) {
+        constexpr int Q = decltype(q_tag)::value;
+        const int slot = r * (R / 2) + Q;
+        const int row_a = slot, row_b = slot == 0 ? 32 : 64 - slot;
+        cplx ya[L], yb[L];
+        run_pass(std::integral_constant<int, 2 * Q>{}, ya, row_a);
+        run_pass(std::integral_constant<int, 2 * Q + 1>{}, yb, row_b);
+        // Split pass by pairs: bin ka = row_a + 64 u and its partner kb = N - ka = row_b + 64 (L - 1 - u).
+        // Slot 0 (rows 0 and 32 pair with themselves) re-indexes: pair 0 = (bin 0, bin N/2), pairs
+        // 1..L/2-1 = (64 u, 64 (L - u)) of row 0, pairs L/2.. = (32 + 64 v, 32 + 64 (L - 1 - v)) of row 32.
+#pragma unroll
+        for (int u = 0; u < L; ++u) {
+            cplx a = ya[u], b = yb[L - 1 - u];
+            uint32_t ka = (uint32_t)(row_a + 64 * u);
+            if constexpr (Q == 0) {
+                if (slot == 0) {
+                    if (u == 0) { b = ya[L / 2]; }
+                    else if (u < L / 2) { b = ya[L - u]; }
+                    else { a = yb[u - L / 2]; b = yb[L - 1 - (u - L / 2)]; ka = (uint32_t)(32 + 64 * (u - L / 2)); }
+                }
+            }
+            uint32_t kb = (uint32_t)N - ka;
+            cplx a2 = b, b2 = a;
+            if constexpr (Q == 0) {
+                if (slot == 0 && u == 0) { kb = (uint32_t)(N / 2); a2 = b; b2 = b; b = a; }
+            }
+            pw[Q][2 * u] = power(a, b, ka);
+            pw[Q][2 * u + 1] = power(a2, b2, kb);
+        }
+        // pin the order: without this the scheduler sinks every split pass below the last transpose and
+        // keeps the outputs of all passes alive at once (several hundred bytes of scratch)
+#pragma unroll
+        for (int i = 0; i < 2 * L; ++i) asm volatile("" : "+v"(pw[Q][i]));
+    };
+    if constexpr (R >= 2) slot_work(std::integral_constant<int, 0>{});
+    if constexpr (R >= 4) slot_work(std::integral_constant<int, 1>{});
+    if constexpr (R >= 8) {
+        slot_work(std::integral_constant<int, 2>{});
+        slot_work(std::integral_constant<int, 3>{});
+    }
+
+    // ---- D: power terms -> LDS (every read of the last pass has returned: the values are in
+    //         registers), band means in bin order -----------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+        const int slot = r * (R / 2) + q;
+#pragma unroll
+        for (int u = 0; u < L; ++u) {
+            uint32_t ka = (uint32_t)(slot + 64 * u);
+            if (q == 0 && slot == 0 && u >= L / 2) ka = (uint32_t)(32 + 64 * (u - L / 2));
+            uint32_t kb = (uint32_t)N - ka;
+            if (q == 0 && slot == 0 && u == 0) kb = (uint32_t)(N / 2);
+            if (ka >= kmin && ka < kmax) vbuf[wl * nread + (ka - kmin)] = pw[q][2 * u];
+            if (kb >= kmin && kb < kmax && kb != ka) vbuf[wl * nread + (kb - kmin)] = pw[q][2 * u + 1];
+        }
+    }
+    // (wave-local: LDS operations of one wave execute in order)
+    for (uint32_t t = lane; t < WPW * nbands; t += 64) {
+        const uint32_t ww = t / nbands, band = t % nbands;
+        const uint32_t lo = band_tbl[band], hi = band_tbl[nbands + band];
+        const float div = __uint_as_float(band_tbl[2 * nbands + band]);
+        float p = 0.0f;
+        for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
+            float v[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) v[q] = (k0 + q < hi) ? vbuf[ww * nread + (k0 + q - kmin)] : 0.0f;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) v[q] = (v[q] == v[q] && fabsf(v[q]) != INFINITY) ? v[q] : 0.0f;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[q]);
+        }
+        const uint32_t row = part * S::UW + wave * WPW + ww;
+        frames[(frame * 128 + row) * nbands + band] = __fdiv_rn(p, div);
+    }
+}
+
+template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax) {
+    using S = Shape<LOG2L>;
+    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    const uint32_t wave_dw = (uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread;
+    return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * (size_t)nread + (size_t)kWaves * wave_dw) * sizeof(float);
+}
+
+template <int LOG2L, int FMT>
+hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frames, uint64_t samples_per_clip,
+                           uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    using S = Shape<LOG2L>;
+    const size_t lds = lds_bytes<LOG2L>(plan.table.kmin, plan.table.kmax);
+    static size_t attr_lds = 0;
+    if (attr_lds != lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    const uint64_t n_units = n_frames * (128 / S::UW), units_per_xcd = (n_units + 7) / 8;
+    if (units_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT>), dim3((uint32_t)(units_per_xcd * 8)), dim3(kThreads), lds, stream,
+                       d_pcm, samples_per_clip, frames_per_clip, n_units, units_per_xcd, plan.d_tw, plan.d_bands,
+                       plan.bands, plan.table.kmin, plan.table.kmax, d_frames);
+    return hipGetLastError();
+}
+
+template <int LOG2L>
+hipError_t launch_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_frames, uint64_t samples_per_clip,
+                       uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    switch (fmt) {
+        case 0: return launch_full_fmt<LOG2L, 0>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 1: return launch_full_fmt<LOG2L, 1>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 2: return launch_full_fmt<LOG2L, 2>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+// 1024- and 2048-sample windows at the reference's stride; the compile-time W_64 table must be
+// bit-identical to the run-time master table and the LDS budget must allow two workgroups per CU
+bool rows_full_supported(const Plan& p) {
+    if (p.stride != (uint32_t)kStride || p.bands > 64 || p.bands == 0) return false;
+    if (p.window != 1024 && p.window != 2048) return false;
+    if (p.table.kmax <= p.table.kmin) return false;
+    std::vector<float> re, im;
+    make_twiddles(p.window, re, im);
+    const uint32_t step = p.window / 64;
+    for (int t = 0; t < 32; ++t)
+        if (re[step * t] != kTw64Re[t] || im[step * t] != kTw64Im[t]) return false;
+    const size_t lds = p.window == 1024 ? lds_bytes<3>(p.table.kmin, p.table.kmax) : lds_bytes<4>(p.table.kmin, p.table.kmax);
+    return lds <= 80 * 1024;
+}
+
+hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
+                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    const uint64_t n_frames = n_clips * frames_per_clip;
+    if (n_frames == 0) return hipSuccess;
+    if (n_frames > 0x7ffffffull) return hipErrorInvalidValue;
+    if (plan.window == 1024) return launch_full<3>(plan, d_pcm, fmt, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+    return launch_full<4>(plan, d_pcm, fmt, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+}
+
+}  // namespace lbad

@@ -21,7 +21,7 @@
 // results are bit-identical because every surviving butterfly is evaluated exactly as in the
 // full network.
 #include "internal.hpp"
-#include "twiddle64.inc"
+#include "fft64_lane.hpp"
 
 namespace lbad {
 namespace {
@@ -48,66 +48,7 @@ constexpr int kLdsBytes = (kSpanDw + kTDw + kConstDw + 4) * 4;   // 75 856 B: tw
 constexpr int kWgPerCu = 2;
 static_assert(kWgPerCu * kLdsBytes <= 160 * 1024, "two workgroups must fit one CU's LDS");
 
-// A complex value is one even-aligned VGPR pair (.x = re, .y = im).  Butterflies are written on the
-// pair so that they compile to v_pk_fma_f32 / v_pk_add_f32 with op_sel swizzles and SGPR twiddle
-// pairs (two IEEE operations per instruction, no register shuffling); each half is the same
-// correctly rounded fma / add the oracle performs.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef f32x2 cplx;
-
-__device__ __forceinline__ cplx fma2(cplx a, cplx b, cplx c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ cplx mk(float x, float y) {
-    cplx r;
-    r.x = x;
-    r.y = y;
-    return r;
-}
-typedef __attribute__((address_space(3))) volatile f32x2 lds_vf32x2;   // LDS, not mergeable into ds_*2_b64
-
-__device__ __forceinline__ constexpr int brev6(int v) {
-    return ((v & 1) << 5) | ((v & 2) << 3) | ((v & 4) << 1) | ((v & 8) >> 1) | ((v & 16) >> 3) | ((v & 32) >> 5);
-}
-
-// full butterfly on registers, twiddle index t into the W_64 table (compile time)
-template <int T>
-__device__ __forceinline__ void bfly(cplx& u, cplx& v) {
-    const cplx a = u, b = v;
-    if constexpr (T == 0) {
-        u = a + b;
-        v = a - b;
-    } else if constexpr (T == 16) {  // w = -i: w b = (b.y, -b.x); 1 * x + y rounds exactly like x + y
-        u = fma2(mk(1.0f, -1.0f), b.yx, a);
-        v = fma2(mk(-1.0f, 1.0f), b.yx, a);
-    } else {
-        constexpr float wr = kTw64Re[T], wi = kTw64Im[T];
-        const cplx bs = b.yx;
-        // u.x = fma(wr, b.x, fma(-wi, b.y, a.x)), u.y = fma(wr, b.y, fma(wi, b.x, a.y)); v likewise negated
-        u = fma2(mk(wr, wr), b, fma2(mk(-wi, wi), bs, a));
-        v = fma2(mk(-wr, -wr), b, fma2(mk(wi, -wi), bs, a));
-    }
-}
-
-template <int S, int BASE, int J>
-__device__ __forceinline__ void stage_block_j(cplx (&x)[64]) {
-    constexpr int half = 1 << (S - 1);
-    if constexpr (J < half) {
-        bfly<J*(64 >> S)>(x[BASE + J], x[BASE + J + half]);
-        stage_block_j<S, BASE, J + 1>(x);
-    }
-}
-
-template <int S, int BASE>
-__device__ __forceinline__ void stage_blocks(cplx (&x)[64]) {
-    if constexpr (BASE < 64) {
-        stage_block_j<S, BASE, 0>(x);
-        stage_blocks<S, BASE + (1 << S)>(x);
-    }
-}
-
-// u + w v with a run-time twiddle (tree stages use per-lane tables)
-__device__ __forceinline__ cplx madd(cplx u, float wr, float wi, cplx v) {
-    return fma2(mk(wr, wr), v, fma2(mk(-wi, wi), v.yx, u));
-}
+using namespace lane64;
 
 // stage-6 outputs: row i < 22 is k64 = i ("+" output of pair j = i); row i >= 22 is k64 = i + 21
 // ("-" output of pair j = i - 11)

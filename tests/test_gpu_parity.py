@@ -59,7 +59,11 @@ CONFIGS = {
     "small_odd": dict(sample_rate=8000, window=64, stride=16, bands=7, subfp_len=33),
     "wide": dict(sample_rate=16000, window=256, stride=100, bands=64, subfp_len=256),
     "tiny_bands": dict(sample_rate=11025, window=512, stride=64, bands=2, subfp_len=20),
+    "D_22k_1024": dict(sample_rate=22050, window=1024),                 # 1024-point windows reading bins up to 43
+    "E_11k_2048_64": dict(sample_rate=11025, window=2048, bands=64, subfp_len=256),
 }
+# configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, the others -> k_rows_full.hip
+SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64"}
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
@@ -68,7 +72,7 @@ def test_stages_bit_exact(lb, gpu, oracle, name):
     n = cfg.window + cfg.stride * (128 * 2 + 17)          # two full frames and a ragged tail
     rate = int(cfg.sample_rate)
     pcm = oracle.synth_clips(SEED, 100, 3, rate, n, stereo_sum=(name == "C_48k_4096"))
-    variants = (1, 2) if name == "B_44k_1024" else (1,)      # 2 = specialised kernels (config B has them)
+    variants = (1, 2) if name in SPECIALISED else (1,)       # 2 = specialised kernels only
     for variant in variants:
         bits, raw, haar = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant, taps=True)
         for c in range(3):
@@ -78,7 +82,7 @@ def test_stages_bit_exact(lb, gpu, oracle, name):
             assert np.array_equal(raw[c], oraw, equal_nan=True), f"{name}/v{variant}: band energies differ (clip {c})"
             assert np.array_equal(haar[c], ohaar, equal_nan=True), f"{name}/v{variant}: Haar coefficients differ (clip {c})"
             assert np.array_equal(bits[c], obits), f"{name}/v{variant}: sub-fingerprint bits differ (clip {c})"
-    if name != "B_44k_1024":
+    if name not in SPECIALISED:
         det = lb.Detective().configure(**CONFIGS[name])
         det.set_kernel_variant(2)                            # no specialisation for this configuration
         with pytest.raises(lb.LBAudioDetectiveError):
@@ -560,7 +564,7 @@ def test_integer_pcm_matches_float_path(lb, gpu, oracle, name):
     raw32 = rng.integers(-2**31, 2**31 - 1, pcm.shape, dtype=np.int64).astype(np.int32)
     f32_of_i32 = (raw32.astype(np.float64) / 2**31).astype(np.float32)
     want32 = oracle.fingerprint_batch(f32_of_i32, cfg)
-    for variant in ((0, 1) if name == "B_44k_1024" else (1,)):
+    for variant in ((0, 1) if name in SPECIALISED else (1,)):
         det = lb.Detective().configure(**CONFIGS[name])
         det.set_kernel_variant(variant)
         got = _bits(lb, det.fingerprint_clips_device(i16), cfg.subfp_len)

@@ -12,8 +12,14 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 t0 = time.time()
 for t in range(trials):
-    kind = rng.integers(0, 4)
-    if kind == 0:      # config B shape through the specialised kernels, odd clip counts / lengths / content
+    kind = rng.integers(0, 6)
+    if kind == 1:      # stride 64 with 1024- / 2048-sample windows: the unpruned specialised kernel (k_rows_full.hip)
+        cfg = O.Config(float(rng.choice([5512, 8000, 11025, 16000, 22050, 32000, 44100, 48000])), int(rng.choice([1024, 2048])),
+                       64, int(rng.integers(1, 65)), 1)
+        cfg.subfp_len = int(rng.integers(1, min(256, 128 * cfg.bands) + 1))
+        n = cfg.window + 64 * 128 * int(rng.integers(1, 3)) + int(rng.integers(0, 8192))
+        clips = int(rng.integers(1, 5))
+    elif kind == 0:      # config B shape through the specialised kernels, odd clip counts / lengths / content
         cfg = O.Config(44100, 1024)
         n = 1024 + 64 * 128 * int(rng.integers(1, 4)) + int(rng.integers(0, 8192))
         clips = int(rng.integers(1, 9))
