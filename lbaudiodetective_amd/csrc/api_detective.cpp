@@ -21,6 +21,7 @@ static void free_plan(Plan& p) {
     if (p.d_tw) (void)hipFree(p.d_tw);
     if (p.d_bands) (void)hipFree(p.d_bands);
     if (p.d_bin_const) (void)hipFree(p.d_bin_const);
+    if (p.d_claim) (void)hipFree(p.d_claim);
     p = Plan();
 }
 
@@ -71,6 +72,7 @@ OSStatus ensure_plan(LBAudioDetective* d) {
         LBAD_HIP(hipMemcpy(p.d_bin_const, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     p.full_ok = rows_full_supported(p);
+    if (p.full_ok) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
     p.valid = true;
     return noErr;
 }

@@ -50,6 +50,7 @@ struct Plan {
     float* d_bin_const = nullptr; // per-bin twiddles of the pruned kernel (only when pruned_ok)
     bool pruned_ok = false;
     bool full_ok = false;         // k_rows_full.hip applies
+    uint32_t* d_claim = nullptr;  // its per-XCD claim counters (8 words)
     bool valid = false;
 };
 

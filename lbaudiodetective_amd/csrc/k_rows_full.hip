@@ -109,40 +109,24 @@ __device__ __forceinline__ void store_pass(const cplx (&x)[64], float* tcol) {
     }
 }
 
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+// span of one unit -> LDS, every run of 64 samples followed by kSkew pad dwords.  float32: one
+// global_load_lds_dword per run (no registers, the wave does not wait); int16 / int32 convert in registers.
 template <int LOG2L, int FMT>
-__global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint64_t samples_per_clip,
-                                                                 uint32_t frames_per_clip, uint64_t n_units,
-                                                                 uint64_t units_per_xcd, const float* __restrict__ tw,
-                                                                 const uint32_t* __restrict__ band_tbl, uint32_t nbands,
-                                                                 uint32_t kmin, uint32_t kmax, float* __restrict__ frames) {
+__device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, uint64_t first, float* span, int wave, int lane) {
     using S = Shape<LOG2L>;
-    constexpr int L = S::L, N = S::N, R = S::R, WPW = S::WPW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63;
-    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
-    // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][per wave: transpose pass / power terms]
-    float* span = smem;
-    float* ctw = smem + S::kSpanDw;
-    float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
-    const uint32_t wave_dw = (uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread;
-    float* tbuf = reinterpret_cast<float*>(split_tw + nread) + wave * wave_dw;
-    float* vbuf = tbuf;   // the power terms reuse the wave's transpose area after the last pass
-
-    // XCD-aware unit mapping as in k_rows_pruned.hip (speed only)
-    const uint64_t unit = (uint64_t)(blockIdx.x & 7) * units_per_xcd + (blockIdx.x >> 3);
-    if (unit >= n_units) return;
-    constexpr int kUnitsPerFrame = 128 / S::UW;
-    const uint64_t frame = unit / kUnitsPerFrame;
-    const uint32_t part = (uint32_t)(unit % kUnitsPerFrame);
-    const uint64_t clip = frame / frames_per_clip;
-    const uint32_t fi = (uint32_t)(frame % frames_per_clip);
-    const uint64_t first = clip * samples_per_clip + ((uint64_t)fi * 128 + part * S::UW) * kStride;
-
-    // ---- A: span -> LDS (skewed), twiddle tables ---------------------------------------------------
+    constexpr int kPitch = 64 + S::kSkew;
     if constexpr (FMT == 0) {
-        const float* src = static_cast<const float*>(pcm_raw) + first;
-        for (int s = threadIdx.x; s < S::kSpan; s += kThreads) span[s + S::kSkew * (s >> 6)] = src[s];
+        const float* src = static_cast<const float*>(pcm_raw) + first + lane + 64 * wave;
+        float* dst = span + kPitch * wave;
+        constexpr int kRuns = S::kSpan / 64, kFull = kRuns / kWaves;
+#pragma unroll
+        for (int i = 0; i < kFull; ++i)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * kWaves * i), (lvoid_t*)(dst + kPitch * kWaves * i), 4, 0, 0);
+        if (wave < kRuns - kFull * kWaves)
+            __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64 * kWaves * kFull), (lvoid_t*)(dst + kPitch * kWaves * kFull), 4, 0, 0);
     } else if constexpr (FMT == 1) {
         const int16_t* src = static_cast<const int16_t*>(pcm_raw) + first;
         for (int s = threadIdx.x; s < S::kSpan; s += kThreads) span[s + S::kSkew * (s >> 6)] = (float)src[s] * (1.0f / 32768.0f);
@@ -151,6 +135,55 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         for (int s = threadIdx.x; s < S::kSpan; s += kThreads)
             span[s + S::kSkew * (s >> 6)] = (float)src[s] * (1.0f / 2147483648.0f);
     }
+}
+
+// Persistent workgroups, two per CU, as in k_rows_pruned.hip: every XCD owns a contiguous range of
+// frames, the first ones are static, the rest is claimed a frame at a time from a per-XCD counter; the
+// span of unit u + 1 streams into the span buffer as soon as every wave holds its points of unit u, and
+// the rows of u drain to HBM during u + 1.  The twiddle tables are built once per workgroup.
+template <int LOG2L, int FMT>
+__global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint64_t samples_per_clip,
+                                                                 uint32_t frames_per_clip, uint64_t n_units,
+                                                                 uint64_t units_per_xcd, const float* __restrict__ tw,
+                                                                 const uint32_t* __restrict__ band_tbl, uint32_t nbands,
+                                                                 uint32_t kmin, uint32_t kmax,
+                                                                 uint32_t* __restrict__ claim_ctr,
+                                                                 float* __restrict__ frames) {
+    using S = Shape<LOG2L>;
+    constexpr int L = S::L, N = S::N, R = S::R, WPW = S::WPW;
+    constexpr uint32_t kUnitsPerFrame = 128 / S::UW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][claim slot][per wave: transpose pass / power terms]
+    float* span = smem;
+    float* ctw = smem + S::kSpanDw;
+    float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
+    uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + nread);
+    const uint32_t wave_dw = (uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread;
+    float* tbuf = reinterpret_cast<float*>(claim_slot + 4) + wave * wave_dw;
+    float* vbuf = tbuf;   // the power terms reuse the wave's transpose area after the last pass
+
+    // workgroup b runs on XCD b % 8 (observed dispatch order; speed only, see k_rows_pruned.hip)
+    const uint32_t wg_per_xcd = gridDim.x >> 3;
+    const uint64_t xcd_begin = (uint64_t)(blockIdx.x & 7) * units_per_xcd;     // a whole number of frames
+    const uint64_t xcd_end = xcd_begin + units_per_xcd < n_units ? xcd_begin + units_per_xcd : n_units;
+    uint64_t unit = xcd_begin + kUnitsPerFrame * (uint64_t)(blockIdx.x >> 3);
+    if (unit >= xcd_end) return;
+    auto span_start = [&](uint64_t u) {
+        const uint32_t frame = (uint32_t)(u / kUnitsPerFrame);          // the launcher keeps unit numbers below 2^31
+        const uint32_t part = (uint32_t)(u % kUnitsPerFrame);
+        const uint32_t clip = frame / frames_per_clip;
+        const uint32_t fi = frame - clip * frames_per_clip;
+        return (uint64_t)clip * samples_per_clip + (uint64_t)(fi * 128 + part * S::UW) * kStride;
+    };
+    uint32_t* my_ctr = claim_ctr + (blockIdx.x & 7);
+    const bool claimer = threadIdx.x == 0;
+    uint32_t claimed = 0;
+
+    // ---- once per workgroup: first span, twiddle tables ----------------------------------------------
+    span_to_lds<LOG2L, FMT>(pcm_raw, span_start(unit), span, wave, lane);
     // cross-lane stage t = 1..log2 L (overall stage s = 6 + t): butterfly jj of row k64 uses
     // W_(2^s)^(k64 + 64 jj) = tw[(k64 + 64 jj) << (LOG2W - s)]
     for (int i = threadIdx.x; i < 64 * (L - 1); i += kThreads) {
@@ -166,17 +199,39 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         const uint32_t k = kmin + i < (uint32_t)N ? kmin + i : 0u;
         split_tw[i] = make_float2(tw[k], tw[N + k]);
     }
-    __syncthreads();
 
     const int wl = lane / L, r = lane % L;          // window of the wave, lane of the window
     const float inv_norm = 1.0f / (float)(S::W / 4);
+    float* tcol = tbuf + wl * S::kWinDw + 2 * r;                 // this lane's column of its window's pass
+    const float* trow = tbuf + wl * S::kWinDw + r * S::kRowDw;   // the row this lane receives
 
-    // ---- B: 64 points of this lane, DIT stages 1..6 in registers -----------------------------------
+    float out[WPW];                  // band means of the previous unit, stored one iteration late
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) out[i] = 0.0f;
+    float* out_base = nullptr;
+    for (;;) {
+    // ---- A: this unit's span has landed (own loads: vmcnt, the other waves': barrier) -------------------
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    const uint32_t part = (uint32_t)(unit % kUnitsPerFrame);
+    if (part == kUnitsPerFrame - 1 && claimer) claim_slot[0] = claimed;    // claimed at part 0 of this frame
+    __syncthreads();
+
+    // ---- B: 64 points of this lane; once every wave has its points the span buffer is free -----------
     cplx x[64];
     {
         // window w of the workgroup starts at sample 64 w, i.e. at float (64 + kSkew) w
         const int w = wave * WPW + wl;
         load_points64<LOG2L, 0>(x, span + (64 + S::kSkew) * w + 2 * r);
+    }
+    const uint64_t next = part == kUnitsPerFrame - 1
+                              ? xcd_begin + kUnitsPerFrame * ((uint64_t)wg_per_xcd + claim_slot[0]) : unit + 1;
+    __syncthreads();
+    if (next < xcd_end) span_to_lds<LOG2L, FMT>(pcm_raw, span_start(next), span, wave, lane);
+    if (part == 0 && claimer) claimed = atomicAdd(my_ctr, 1u);
+    if (out_base) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
     }
     stage_blocks<1, 0>(x);
     stage_blocks<2, 0>(x);
@@ -186,8 +241,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     stage_blocks<6, 0>(x);
 
     // ---- C: log2 L cross-lane stages, R passes; pairs of passes end in the split pass ---------------
-    float* tcol = tbuf + wl * S::kWinDw + 2 * r;                 // this lane's column of its window's pass
-    const float* trow = tbuf + wl * S::kWinDw + r * S::kRowDw;   // the row this lane receives
+    // (bin numbers, twiddle addresses and store predicates are loop-invariant per lane; laundering r keeps
+    // the compiler from hoisting a hundred of them out of the persistent loop and spilling them)
+    int r_now = r;
+    asm volatile("" : "+v"(r_now));
     float pw[R / 2][2 * L];
     auto run_pass = [&](auto pass_tag, cplx (&y)[L], int row) {
         constexpr int P = decltype(pass_tag)::value;
@@ -219,7 +276,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     };
     auto slot_work = [&](auto q_tag) {
         constexpr int Q = decltype(q_tag)::value;
-        const int slot = r * (R / 2) + Q;
+        const int slot = r_now * (R / 2) + Q;
         const int row_a = slot, row_b = slot == 0 ? 32 : 64 - slot;
         cplx ya[L], yb[L];
         run_pass(std::integral_constant<int, 2 * Q>{}, ya, row_a);
@@ -262,7 +319,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     //         registers), band means in bin order -----------------------------------------------------
 #pragma unroll
     for (int q = 0; q < R / 2; ++q) {
-        const int slot = r * (R / 2) + q;
+        const int slot = r_now * (R / 2) + q;
 #pragma unroll
         for (int u = 0; u < L; ++u) {
             uint32_t ka = (uint32_t)(slot + 64 * u);
@@ -274,30 +331,43 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         }
     }
     // (wave-local: LDS operations of one wave execute in order)
-    for (uint32_t t = lane; t < WPW * nbands; t += 64) {
-        const uint32_t ww = t / nbands, band = t % nbands;
-        const uint32_t lo = band_tbl[band], hi = band_tbl[nbands + band];
-        const float div = __uint_as_float(band_tbl[2 * nbands + band]);
+    // task t = lane + 64 i -> window t / nbands of the wave, band t % nbands; rows of a wave's windows are
+    // consecutive, so the task's float sits at out_base[t]
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const uint32_t t = lane + 64 * i;
         float p = 0.0f;
-        for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
-            float v[8];
+        float div = 1.0f;
+        if (t < WPW * nbands) {
+            const uint32_t ww = t / nbands, band = t - ww * nbands;
+            const uint32_t lo = band_tbl[band], hi = band_tbl[nbands + band];
+            div = __uint_as_float(band_tbl[2 * nbands + band]);
+            for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
+                float v[8];
 #pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) v[q] = (k0 + q < hi) ? vbuf[ww * nread + (k0 + q - kmin)] : 0.0f;
+                for (uint32_t q = 0; q < 8; ++q) v[q] = (k0 + q < hi) ? vbuf[ww * nread + (k0 + q - kmin)] : 0.0f;
 #pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) v[q] = (v[q] == v[q] && fabsf(v[q]) != INFINITY) ? v[q] : 0.0f;
+                for (uint32_t q = 0; q < 8; ++q) v[q] = (v[q] == v[q] && fabsf(v[q]) != INFINITY) ? v[q] : 0.0f;
 #pragma unroll
-            for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[q]);
+                for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[q]);
+            }
         }
-        const uint32_t row = part * S::UW + wave * WPW + ww;
-        frames[(frame * 128 + row) * nbands + band] = __fdiv_rn(p, div);
+        out[i] = __fdiv_rn(p, div);
     }
+    out_base = frames + ((unit / kUnitsPerFrame) * 128 + part * S::UW + wave * WPW) * nbands;
+    if (next >= xcd_end) break;
+    unit = next;
+    }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i)
+        if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
 }
 
 template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax) {
     using S = Shape<LOG2L>;
     const uint32_t nread = (kmax - kmin + 63u) & ~63u;
     const uint32_t wave_dw = (uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread;
-    return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * (size_t)nread + (size_t)kWaves * wave_dw) * sizeof(float);
+    return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * (size_t)nread + 4 + (size_t)kWaves * wave_dw) * sizeof(float);
 }
 
 template <int LOG2L, int FMT>
@@ -312,11 +382,24 @@ hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frame
         if (e != hipSuccess) return e;
         attr_lds = lds;
     }
-    const uint64_t n_units = n_frames * (128 / S::UW), units_per_xcd = (n_units + 7) / 8;
+    // work is claimed by frames: every XCD's range is a whole number of frames
+    constexpr uint64_t U = 128 / S::UW;
+    const uint64_t n_units = n_frames * U, units_per_xcd = U * ((n_frames + 7) / 8);
     if (units_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT>), dim3((uint32_t)(units_per_xcd * 8)), dim3(kThreads), lds, stream,
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
+        n_cu = prop.multiProcessorCount;
+    }
+    uint64_t wg_per_xcd = ((uint64_t)n_cu * 2 + 7) / 8;          // two persistent workgroups per CU
+    if (wg_per_xcd > units_per_xcd / U) wg_per_xcd = units_per_xcd / U;
+    hipError_t e = hipMemsetAsync(plan.d_claim, 0, 8 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT>), dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), lds, stream,
                        d_pcm, samples_per_clip, frames_per_clip, n_units, units_per_xcd, plan.d_tw, plan.d_bands,
-                       plan.bands, plan.table.kmin, plan.table.kmax, d_frames);
+                       plan.bands, plan.table.kmin, plan.table.kmax, plan.d_claim, d_frames);
     return hipGetLastError();
 }
 
