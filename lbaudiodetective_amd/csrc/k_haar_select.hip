@@ -12,6 +12,8 @@
 // the sign bits of ranks < keep.  The result is identical to a full stable sort.
 #include "internal.hpp"
 
+#include <cmath>
+
 namespace lbad {
 namespace {
 
@@ -31,9 +33,11 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red) {
 
 // 1-D Haar of LBAudioDetectiveFrameDecomposeArray applied to `lines` independent lines of
 // length `len`; element e of line l sits at src[l * lstride + e * estride].
-__device__ void haar_lines(float* a, float* tmp, uint32_t lines, uint32_t len, uint32_t lstride, uint32_t estride) {
-    const float root = __fsqrt_rn((float)len);
-    const float root2 = __fsqrt_rn(2.0f);
+// `root` = sqrtf(len) is computed on the host: the device's sqrt is the 1-ulp v_sqrt_f32 (sqrtf(14.0f)
+// comes out one ulp low, for example), whatever -fhip-fp32-correctly-rounded-divide-sqrt promises.
+__device__ void haar_lines(float* a, float* tmp, uint32_t lines, uint32_t len, uint32_t lstride, uint32_t estride,
+                           float root) {
+    const float root2 = __fsqrt_rn(2.0f);   // constant-folded by the compiler (correctly rounded)
     for (uint32_t p = threadIdx.x; p < lines * len; p += kThreads) {
         const uint32_t l = p / len, e = p % len;
         const uint32_t at = l * lstride + e * estride;
@@ -61,7 +65,7 @@ __device__ void haar_lines(float* a, float* tmp, uint32_t lines, uint32_t len, u
 }
 
 __global__ __launch_bounds__(kThreads) void haar_select_kernel(const float* __restrict__ frames, uint32_t bands,
-                                                               uint32_t keep, uint32_t subfp_len,
+                                                               float root_bands, uint32_t keep, uint32_t subfp_len,
                                                                uint32_t* __restrict__ packed,
                                                                float* __restrict__ haar_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -81,8 +85,8 @@ __global__ __launch_bounds__(kThreads) void haar_select_kernel(const float* __re
     if (threadIdx.x == 0) s_ncand = 0;
     __syncthreads();
 
-    haar_lines(a, tmp, kRowsPerFrame, bands, bands, 1);   // every row      (Frame.m:114-116)
-    haar_lines(a, tmp, bands, kRowsPerFrame, 1, bands);   // every column   (Frame.m:118-131)
+    haar_lines(a, tmp, kRowsPerFrame, bands, bands, 1, root_bands);                          // every row (Frame.m:114-116)
+    haar_lines(a, tmp, bands, kRowsPerFrame, 1, bands, __fsqrt_rn((float)kRowsPerFrame));    // every column (:118-131); folded
 
     if (haar_out) {
         float* dst = haar_out + frame * n;
@@ -164,7 +168,7 @@ hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_fram
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
     const size_t lds = (size_t)2 * kRowsPerFrame * plan.bands * sizeof(float);
     hipLaunchKernelGGL(haar_select_kernel, dim3((uint32_t)n_frames), dim3(kThreads), lds, stream, d_frames,
-                       plan.bands, plan.keep, plan.subfp_len, d_packed, d_haar_out);
+                       plan.bands, std::sqrt((float)plan.bands), plan.keep, plan.subfp_len, d_packed, d_haar_out);
     return hipGetLastError();
 }
 

@@ -1,6 +1,8 @@
 // k_misc.hip -- small kernels behind the Frame API and the synthetic-input generators.
 #include "internal.hpp"
 
+#include <cmath>
+
 namespace lbad {
 namespace {
 
@@ -9,14 +11,15 @@ constexpr int kThreads = 256;
 // ---- generic 2-D Haar (LBAudioDetectiveFrame.m:113-153) for arbitrary rows x cols -------------
 // One thread walks one line serially, exactly like LBAudioDetectiveFrameDecomposeArray; used
 // only by the Frame API (the known-answer test matrix is 3 x 4), never by the batch path.
+// `root` = sqrtf(len) comes from the host: the device's sqrt is the 1-ulp v_sqrt_f32 (sqrtf(14.0f) is one
+// ulp low, for example), whatever -fhip-fp32-correctly-rounded-divide-sqrt promises.
 __global__ __launch_bounds__(kThreads) void haar_lines_kernel(float* m, float* tmp, uint32_t lines, uint32_t len,
-                                                              uint32_t lstride, uint32_t estride) {
+                                                              uint32_t lstride, uint32_t estride, float root) {
     const uint32_t l = blockIdx.x * kThreads + threadIdx.x;
     if (l >= lines) return;
     float* a = m + (size_t)l * lstride;
     float* t = tmp + (size_t)l * lstride;
-    const float root = __fsqrt_rn((float)len);
-    const float root2 = __fsqrt_rn(2.0f);
+    const float root2 = __fsqrt_rn(2.0f);   // constant-folded by the compiler (correctly rounded)
     for (uint32_t i = 0; i < len; ++i) a[(size_t)i * estride] = __fdiv_rn(a[(size_t)i * estride], root);
     uint32_t cnt = len;
     while (cnt > 1) {
@@ -163,9 +166,9 @@ void sine_table(int16_t* t) {
 hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream) {
     if (rows == 0 || cols == 0) return hipSuccess;
     hipLaunchKernelGGL(haar_lines_kernel, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, d_m,
-                       d_tmp, rows, cols, cols, 1u);
+                       d_tmp, rows, cols, cols, 1u, std::sqrt((float)cols));
     hipLaunchKernelGGL(haar_lines_kernel, dim3((cols + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, d_m,
-                       d_tmp, cols, rows, 1u, cols);
+                       d_tmp, cols, rows, 1u, cols, std::sqrt((float)rows));
     return hipGetLastError();
 }
 

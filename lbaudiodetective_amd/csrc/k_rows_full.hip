@@ -259,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     };
     // power term of bin k from A = Z[k], B = Z[N - k] (LBAudioDetective.m:373-396 after the vDSP packing)
     auto power = [&](cplx a, cplx b, uint32_t k) -> float {
-        const uint32_t ks = k >= kmin && k < kmax ? k - kmin : 0u;     // bins outside the bands: computed, never stored
+        const uint32_t ks = min(max(k, kmin), kmax - 1u) - kmin;       // bins outside the bands: computed, never stored
         const float2 wk = split_tw[ks];
         const float sr = a.x + b.x, si = a.y - b.y;
         const float dr = a.x - b.x, di = a.y + b.y;
@@ -270,8 +270,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
             re = sm + sm;
             im = df + df;
         }
-        if (re > 0.0f) re = __fmul_rn(re, inv_norm);
-        if (im > 0.0f) im = __fmul_rn(im, inv_norm);
+        // "if (x > 0) x *= 1 / (W/4)" is min(x * 2^-n, x): the same single rounding for x > 0, x itself
+        // otherwise (negative, zero of either sign, NaN)
+        re = fminf(__fmul_rn(re, inv_norm), re);
+        im = fminf(__fmul_rn(im, inv_norm), im);
         return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
     };
     auto slot_work = [&](auto q_tag) {

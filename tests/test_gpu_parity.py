@@ -61,6 +61,10 @@ CONFIGS = {
     "tiny_bands": dict(sample_rate=11025, window=512, stride=64, bands=2, subfp_len=20),
     "D_22k_1024": dict(sample_rate=22050, window=1024),                 # 1024-point windows reading bins up to 43
     "E_11k_2048_64": dict(sample_rate=11025, window=2048, bands=64, subfp_len=256),
+    # band counts whose square root the GPU's own sqrt instruction gets wrong by an ulp (6, 11, 14, 24, 30 ...):
+    # the Haar pre-scale divides by sqrtf(bands), which therefore comes from the host
+    "bands_14": dict(sample_rate=22050, window=256, stride=277, bands=14, subfp_len=180),
+    "bands_11": dict(sample_rate=16000, window=512, stride=64, bands=11, subfp_len=64),
 }
 # configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, the others -> k_rows_full.hip
 SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64"}
@@ -194,7 +198,7 @@ def test_haar_wavelet_decomposition(lb, gpu, oracle):
     assert np.array_equal(got, oracle.haar_2d(np.array(g["input"], np.float32)))
 
 
-@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 4), (5, 7), (128, 32), (128, 33), (64, 100)])
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 4), (5, 7), (128, 32), (128, 33), (64, 100), (14, 6), (30, 11), (24, 14)])
 def test_frame_decompose_and_extract(lb, gpu, oracle, rows, cols):
     rng = np.random.default_rng(rows * 1000 + cols)
     m = (rng.standard_normal((rows, cols)) * 100).astype(np.float32)

@@ -36,6 +36,26 @@ for t in range(trials):
     if mode == 2: pcm[:, : n // 3] = pcm[:, n // 3: 2 * (n // 3)]      # repeated content: many equal coefficients
     if mode == 3: pcm = np.sign(pcm).astype(np.float32)
     want = O.fingerprint_batch(pcm, cfg, nthreads=8)
+    only = os.environ.get("FUZZ_ONLY")
+    if only is not None and int(only) != t:           # replay: same random stream, GPU work for one trial only
+        if want.shape[1] >= 1 and clips >= 2:
+            rng.integers(1, cfg.subfp_len + 3)
+        continue
+    if only is not None:                               # ... and a stage-by-stage diagnosis of that trial
+        det = lb.Detective().configure(sample_rate=cfg.sample_rate, window=cfg.window, stride=cfg.stride,
+                                       bands=cfg.bands, subfp_len=cfg.subfp_len)
+        out, raw, haar = det.fingerprint_clips_device(torch.from_numpy(pcm).cuda(), taps=True)
+        raw, haar = raw.cpu().numpy(), haar.cpu().numpy()
+        for c in range(clips):
+            obits, oraw, ohaar = O.fingerprint_pcm(pcm[c], cfg, taps=True)
+            dr = np.argwhere(raw[c].view(np.uint32) != oraw.view(np.uint32))
+            dh = np.argwhere(haar[c].view(np.uint32) != ohaar.view(np.uint32))
+            print("clip", c, "raw diffs", len(dr), dr[:5].tolist(), "haar diffs", len(dh), dh[:5].tolist())
+            for f, rw, b in dh[:6]:
+                print("   haar", (f, rw, b), haar[c][f, rw, b], ohaar[f, rw, b], hex(haar[c][f, rw, b].view(np.uint32)), hex(ohaar[f, rw, b].view(np.uint32)), "raw row", oraw[f, rw].tolist()[:14])
+            print("   bits differ at", np.argwhere(lb.unpack_packed(out[c].cpu().numpy(), cfg.subfp_len) != obits)[:10].tolist())
+            for f, rw, b in dr[:5]:
+                print("   raw", (f, rw, b), raw[c][f, rw, b], oraw[f, rw, b], hex(raw[c][f, rw, b].view(np.uint32)), hex(oraw[f, rw, b].view(np.uint32)))
     det = lb.Detective().configure(sample_rate=cfg.sample_rate, window=cfg.window, stride=cfg.stride, bands=cfg.bands,
                                    subfp_len=cfg.subfp_len)
     packed = det.fingerprint_clips_device(torch.from_numpy(pcm).cuda())
