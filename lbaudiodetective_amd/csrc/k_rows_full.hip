@@ -159,8 +159,9 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][claim slot][per wave: transpose pass / power terms]
     float* span = smem;
     float* ctw = smem + S::kSpanDw;
+    // split-pass twiddles in consumption order: entry e = (slot q, pair u, half) of lane r at [e * L + r]
     float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
-    uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + nread);
+    uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + 64 * L);
     const uint32_t wave_dw = (uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread;
     float* tbuf = reinterpret_cast<float*>(claim_slot + 4) + wave * wave_dw;
     float* vbuf = tbuf;   // the power terms reuse the wave's transpose area after the last pass
@@ -195,8 +196,16 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         ctw[row * S::kTwRowDw + 2 * e] = tw[ti];
         ctw[row * S::kTwRowDw + 2 * e + 1] = tw[N + ti];
     }
-    for (uint32_t i = threadIdx.x; i < nread; i += kThreads) {
-        const uint32_t k = kmin + i < (uint32_t)N ? kmin + i : 0u;
+    // every lane meets the same 64 bins in every unit: W^k of each, laid out the way the lanes read them
+    // (conflict-free, no index arithmetic in the loop).  Bin numbering as in the split pass below.
+    for (int i = threadIdx.x; i < 64 * L; i += kThreads) {
+        const int rr = i % L, e = i / L, half = e & 1, u = (e >> 1) % L, q = (e >> 1) / L;
+        const int slot = rr * (R / 2) + q;
+        int ka = slot + 64 * u;
+        if (slot == 0 && u >= L / 2) ka = 32 + 64 * (u - L / 2);
+        int k = half ? N - ka : ka;
+        if (slot == 0 && u == 0 && half) k = N / 2;
+        k &= N - 1;                                    // (bin N of slot 0 never occurs; keeps the index in the table)
         split_tw[i] = make_float2(tw[k], tw[N + k]);
     }
 
@@ -258,14 +267,14 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         cross_fft<L>(y, ctw + row * S::kTwRowDw);
     };
     // power term of bin k from A = Z[k], B = Z[N - k] (LBAudioDetective.m:373-396 after the vDSP packing)
-    auto power = [&](cplx a, cplx b, uint32_t k) -> float {
-        const uint32_t ks = min(max(k, kmin), kmax - 1u) - kmin;       // bins outside the bands: computed, never stored
-        const float2 wk = split_tw[ks];
+    const float2* my_tw = split_tw + r;
+    auto power = [&](cplx a, cplx b, int e, bool dc) -> float {
+        const float2 wk = my_tw[e * L];                                 // bins outside the bands: computed, never stored
         const float sr = a.x + b.x, si = a.y - b.y;
         const float dr = a.x - b.x, di = a.y + b.y;
         float re = __fmaf_rn(wk.x, di, __fmaf_rn(wk.y, dr, sr));
         float im = __fmaf_rn(-wk.x, dr, __fmaf_rn(wk.y, di, si));
-        if (k == 0) {                                                   // DC and Nyquist share bin 0
+        if (dc) {                                                       // DC and Nyquist share bin 0
             const float sm = a.x + a.y, df = a.x - a.y;
             re = sm + sm;
             im = df + df;
@@ -289,21 +298,20 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
 #pragma unroll
         for (int u = 0; u < L; ++u) {
             cplx a = ya[u], b = yb[L - 1 - u];
-            uint32_t ka = (uint32_t)(row_a + 64 * u);
             if constexpr (Q == 0) {
                 if (slot == 0) {
                     if (u == 0) { b = ya[L / 2]; }
                     else if (u < L / 2) { b = ya[L - u]; }
-                    else { a = yb[u - L / 2]; b = yb[L - 1 - (u - L / 2)]; ka = (uint32_t)(32 + 64 * (u - L / 2)); }
+                    else { a = yb[u - L / 2]; b = yb[L - 1 - (u - L / 2)]; }
                 }
             }
-            uint32_t kb = (uint32_t)N - ka;
             cplx a2 = b, b2 = a;
-            if constexpr (Q == 0) {
-                if (slot == 0 && u == 0) { kb = (uint32_t)(N / 2); a2 = b; b2 = b; b = a; }
+            bool dc = false;
+            if (Q == 0 && u == 0) {
+                if (slot == 0) { a2 = b; b2 = b; b = a; dc = true; }     // (bin 0 from Z[0] alone, bin N/2 from Z[N/2] alone)
             }
-            pw[Q][2 * u] = power(a, b, ka);
-            pw[Q][2 * u + 1] = power(a2, b2, kb);
+            pw[Q][2 * u] = power(a, b, (Q * L + u) * 2, dc);
+            pw[Q][2 * u + 1] = power(a2, b2, (Q * L + u) * 2 + 1, false);
         }
         // pin the order: without this the scheduler sinks every split pass below the last transpose and
         // keeps the outputs of all passes alive at once (several hundred bytes of scratch)
@@ -369,7 +377,7 @@ template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax) {
     using S = Shape<LOG2L>;
     const uint32_t nread = (kmax - kmin + 63u) & ~63u;
     const uint32_t wave_dw = (uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread;
-    return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * (size_t)nread + 4 + (size_t)kWaves * wave_dw) * sizeof(float);
+    return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * 64 * (size_t)S::L + 4 + (size_t)kWaves * wave_dw) * sizeof(float);
 }
 
 template <int LOG2L, int FMT>
