@@ -225,8 +225,9 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective,
                                                 UInt32 inSampleFormat, UInt64 inNumberOfClips,
                                                 UInt64 inSamplesPerClip, Boolean* outBooleans);
 /* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band
- * count), 2 = specialised kernels (pruned 1024-point FFT for bands that read only bins 0..21, register
- * Haar/select for 128 x 32 frames); 2 returns ArgumentInvalid when the configuration has none. */
+ * count), 2 = specialised kernels (stride 64: pruned 1024-point FFT for bands that read only bins 0..21,
+ * register-resident 1024- / 2048-point FFT for any band table; register Haar/select for 128 x 32 frames);
+ * 2 returns ArgumentInvalid when the configuration has no specialised stage-1 kernel. */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
 /* HBM the frame-row buffer between the two kernels may take (default 16 GiB; 16 KiB per frame at 32
  * bands).  Batches that need more are processed in several launches. */
