@@ -732,3 +732,28 @@ def test_c_host_example_on_bird_fixtures(lb, gpu, tmp_path):
     det = lb.Detective()
     det.set_file_hop_mode(1)
     assert abs(match - det.compare_audio_urls(a, b)) < 5e-5            # printed with 4 decimals
+
+
+def test_batch_call_captures_into_a_hip_graph(lb, gpu, oracle):
+    """The batch entry point is plain stream work (a 32-byte memset and two kernels): it can be recorded
+    into a hipGraph on torch's capture stream and replayed on new input without touching the host path."""
+    cfg = oracle.Config(44100, 1024)
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    n = 44100
+    pcm = oracle.synth_clips(SEED, 500, 6, 44100, n)
+    want = oracle.fingerprint_batch(pcm, cfg)
+    clips = gpu.zeros((3, n), dtype=gpu.float32, device="cuda")
+    out = gpu.zeros((3, want.shape[1], lb.PACKED_BYTES), dtype=gpu.uint8, device="cuda")
+    side = gpu.cuda.Stream()
+    with gpu.cuda.stream(side):
+        det.fingerprint_clips_device(clips, out=out)              # warm-up: plan, scratch, function attributes
+    gpu.cuda.synchronize()
+    graph = gpu.cuda.CUDAGraph()
+    with gpu.cuda.graph(graph):
+        det.fingerprint_clips_device(clips, out=out)
+    for first in (0, 3):
+        clips.copy_(gpu.from_numpy(pcm[first:first + 3]))
+        graph.replay()
+        gpu.cuda.synchronize()
+        got = lb.unpack_packed(out.cpu().numpy(), cfg.subfp_len).reshape(3, -1, cfg.subfp_len)
+        assert np.array_equal(got, want[first:first + 3])
