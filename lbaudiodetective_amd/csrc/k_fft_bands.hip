@@ -44,9 +44,14 @@ __device__ __forceinline__ int zslot(int n) { return n + (n >> 5); }
 template <int LOG2W> struct Passes {
     static constexpr int LOGN = LOG2W - 1;
     static constexpr int N = 1 << LOGN;
-    static constexpr int count = (LOGN + 2) / 3;
-    static constexpr int first_stage(int p) { return 1 + 3 * p; }
-    static constexpr int stages(int p) { return (LOGN - 3 * p) >= 3 ? 3 : (LOGN - 3 * p); }
+    // Pass 0 has wave-uniform twiddles and may therefore take more stages per LDS trip than the others:
+    // five at W = 4096 (32 points per lane, passes 5 + 3 + 3 instead of 3 + 3 + 3 + 2), three elsewhere.
+    static constexpr int kFirst = LOG2W == 12 ? 5 : (LOGN >= 3 ? 3 : LOGN);
+    static constexpr int count = 1 + (LOGN - kFirst + 2) / 3;
+    static constexpr int first_stage(int p) { return p == 0 ? 1 : 1 + kFirst + 3 * (p - 1); }
+    static constexpr int stages(int p) {
+        return p == 0 ? kFirst : ((LOGN - kFirst - 3 * (p - 1)) >= 3 ? 3 : (LOGN - kFirst - 3 * (p - 1)));
+    }
     static constexpr int groups_per_lane(int p) { return ((N >> stages(p)) + 63) / 64; }
     static constexpr int twiddles(int p) { return (1 << stages(p)) - 1; }
     // float2 slots of the per-lane twiddle cache before pass p (pass 0 has wave-uniform twiddles: the
@@ -101,19 +106,31 @@ __device__ __forceinline__ void build_cache(float2* cache, const float* __restri
 // order; the stage-s partner of point n is n +- (N >> s) and its twiddle index is the bit-reversed
 // value of n's top s-1 bits.  Every butterfly uses the general nested-fma form: for the twiddles 1 and
 // -i this equals the oracle's multiplication-free form up to the sign of zeros.
-// Pass 0 (stages 1..3, or fewer for tiny windows): the twiddle of a butterfly depends only on its
-// register slot -- 1, -i and the odd eighth roots W8, W8^3 read once from the master table -- so stages
-// 1 and 2 are the oracle's multiplication-free forms and no per-lane twiddle is fetched at all.
+// Pass 0 (stages 1..kFirst): the twiddle of a butterfly depends only on its register slot --
+// W_(2^(t+1))^j with j the bit-reversed block index -- so the few distinct values are read once from the
+// master table into scalar registers, stages 1 and 2 (and every j = 0 or quarter-turn butterfly) are the
+// oracle's multiplication-free forms, and no per-lane twiddle is fetched at all.
+__device__ __forceinline__ constexpr int brev_bits(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
 template <int LOG2W>
 __device__ __forceinline__ void dit_pass0(float2* z, const float* __restrict__ tw, int lane) {
     using Ps = Passes<LOG2W>;
-    constexpr int LOGN = Ps::LOGN, N = Ps::N;
+    constexpr int N = Ps::N;
     constexpr int NS = Ps::stages(0), G = 1 << NS;
     constexpr int step = N >> NS;
-    // W8^1 and W8^3 exist only when the pass has a third stage
-    const float w1r = NS == 3 ? tw[1 << (LOG2W - 3)] : 0.0f, w1i = NS == 3 ? tw[N + (1 << (LOG2W - 3))] : 0.0f;
-    const float w3r = NS == 3 ? tw[3 << (LOG2W - 3)] : 0.0f, w3i = NS == 3 ? tw[N + (3 << (LOG2W - 3))] : 0.0f;
-    (void)LOGN;
+    // distinct non-trivial twiddles: W_(2^NS)^j for j = 1 .. 2^(NS-1) - 1 (index j << (LOG2W - NS)); the
+    // stage-t twiddle W_(2^(t+1))^j is entry j << (NS - 1 - t) of the same family
+    constexpr int NT = NS >= 1 ? (1 << (NS - 1)) : 1;
+    float wre[NT], wim[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        wre[j] = tw[j << (LOG2W - NS)];
+        wim[j] = tw[N + (j << (LOG2W - NS))];
+    }
 #pragma unroll 2
     for (int q = 0; q < Ps::groups_per_lane(0); ++q) {
         const int g = lane + 64 * q;
@@ -131,16 +148,17 @@ __device__ __forceinline__ void dit_pass0(float2* z, const float* __restrict__ t
                 for (int e = 0; e < G; ++e) {
                     if (e & half) continue;
                     const int h = e >> (NS - t);                       // butterfly block of this stage
-                    const int j = t == 2 ? ((h & 1) << 1 | (h >> 1)) : h;   // bit-reversed within t bits
+                    const int j = brev_bits(h, t);                     // twiddle W_(2^(t+1))^j
+                    const int fam = j << (NS - 1 - t);                 // its index in the W_(2^NS) family
                     const f32x2 u = x[e], v = x[e + half], vs = v.yx;
-                    if (j == 0) {                                       // w = 1
+                    if (fam == 0) {                                     // w = 1
                         x[e] = u + v;
                         x[e + half] = u - v;
-                    } else if ((t == 1 && j == 1) || (t == 2 && j == 2)) {   // w = -i: w v = (v.y, -v.x)
+                    } else if (2 * fam == NT) {                         // w = -i: w v = (v.y, -v.x)
                         x[e] = fma2(mk2(1.0f, -1.0f), vs, u);
                         x[e + half] = fma2(mk2(-1.0f, 1.0f), vs, u);
                     } else {
-                        const float wr = j == 1 ? w1r : w3r, wi = j == 1 ? w1i : w3i;
+                        const float wr = wre[fam], wi = wim[fam];
                         x[e] = fma2(mk2(wr, wr), v, fma2(mk2(-wi, wi), vs, u));
                         x[e + half] = fma2(mk2(-wr, -wr), v, fma2(mk2(wi, -wi), vs, u));
                     }
@@ -415,7 +433,7 @@ hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_
     if constexpr (LOG2W == 11) {
         LBAD_TRY(12) LBAD_TRY(8) LBAD_TRY(4) LBAD_TRY(2) LBAD_TRY(1)
     } else if constexpr (LOG2W == 12) {
-        LBAD_TRY(6) LBAD_TRY(4) LBAD_TRY(2) LBAD_TRY(1)
+        LBAD_TRY(7) LBAD_TRY(6) LBAD_TRY(4) LBAD_TRY(2) LBAD_TRY(1)
     } else if constexpr (LOG2W == 13) {
         LBAD_TRY(2) LBAD_TRY(1)
     } else {
