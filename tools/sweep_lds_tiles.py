@@ -29,10 +29,10 @@ if "--one" in sys.argv:
     sys.exit(0)
 
 rows = []
-CACHE = 40960            # per-lane twiddle cache of passes 1..3 at W = 4096 (pass 0 uses scalar constants)
+CACHE = 28672            # per-lane twiddle cache of passes 1..2 at W = 4096 (pass 0: five stages on scalar constants)
 NREAD = 384              # bins 3..347 read by the bands, padded to 64
 PER_WAVE = (2 * (2048 + 64) + NREAD) * 4
-for wpb in (1, 2, 4, 6):
+for wpb in (1, 2, 4, 6, 7):
     for nocache in (0, 1):
         env = dict(os.environ, LBAD_FFT_WPB=str(wpb), LBAD_FFT_NOCACHE=str(nocache))
         out = subprocess.run([sys.executable, __file__, "--one"], env=env, capture_output=True, text=True)
