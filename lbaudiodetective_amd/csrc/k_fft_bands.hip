@@ -345,7 +345,11 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
         wave_sync();
 
         for (uint32_t b = lane; b < nbands; b += 64) {
+#ifdef LBAD_EXP_NOBANDS
+            const uint32_t lo = band_tbl[b], hi = lo + 1;
+#else
             const uint32_t lo = band_tbl[b], hi = band_tbl[nbands + b];
+#endif
             const float div = __uint_as_float(band_tbl[2 * nbands + b]);
             // the sum must run in bin order (float32 addition is not associative); the loads are issued
             // in batches of 8 so that their LDS latency overlaps instead of serialising with the adds
