@@ -242,12 +242,14 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         for (int i = 0; i < WPW; ++i)
             if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
     }
+    __builtin_amdgcn_s_setprio(0);     // arithmetic-heavy phase: let the co-resident wave's LDS work go first
     stage_blocks<1, 0>(x);
     stage_blocks<2, 0>(x);
     stage_blocks<3, 0>(x);
     stage_blocks<4, 0>(x);
     stage_blocks<5, 0>(x);
     stage_blocks<6, 0>(x);
+    __builtin_amdgcn_s_setprio(3);
 
     // ---- C: log2 L cross-lane stages, R passes; pairs of passes end in the split pass ---------------
     // (bin numbers, twiddle addresses and store predicates are loop-invariant per lane; laundering r keeps
