@@ -40,6 +40,27 @@ def allreduce_best(key_tensor, group=None):
     return key_tensor
 
 
+def gather_packed(local_packed, group=None):
+    """Optional last step of sharded fingerprinting: every rank contributes its [n_local, count, 32]
+    packed sub-fingerprints (160 B per one-second clip) and receives all of them in rank order.  Ranks
+    may hold different numbers of clips.  The fingerprint path itself needs no collective."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_packed
+    world = dist.get_world_size(group)
+    n = torch.tensor([local_packed.shape[0]], dtype=torch.int64, device=local_packed.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    biggest = max(counts)
+    padded = torch.zeros((biggest,) + tuple(local_packed.shape[1:]), dtype=local_packed.dtype, device=local_packed.device)
+    padded[: local_packed.shape[0]] = local_packed
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
 def broadcast_fingerprint(fp, src: int = 0, group=None, device=None):
     """Send rank `src`'s query fingerprint to every rank (the 160-byte "query broadcast" of the sharded
     compare).  `fp` is a Fingerprint on the source rank and may be None elsewhere; returns a Fingerprint
