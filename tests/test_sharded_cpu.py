@@ -42,6 +42,14 @@ def _worker(rank, world, port, n_entries, planted, q, ret):
     key = torch.tensor([sharded.make_key(bits, begin + idx) if idx >= 0 else 0], dtype=torch.int64)
     sharded.allreduce_best(key)
     ret[rank] = sharded.decode_key(int(key.item()))
+    # optional gather of packed sub-fingerprints: ragged per-rank counts, rank order preserved
+    mine = torch.full((3 + rank, 5, 32), rank + 1, dtype=torch.uint8)
+    allp = sharded.gather_packed(mine)
+    assert allp.shape == (sum(3 + r for r in range(world)), 5, 32)
+    off = 0
+    for r in range(world):
+        assert bool((allp[off:off + 3 + r] == r + 1).all())
+        off += 3 + r
     dist.barrier()
     dist.destroy_process_group()
 
