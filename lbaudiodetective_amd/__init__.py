@@ -8,7 +8,7 @@ from .api import (  # noqa: F401
     Corpus, Detective, Fingerprint, Frame, Stream, LBAudioDetectiveError, noErr, pack_subfingerprint,
     frames_to_subfingerprints_device, read_audio_url, synth_clips_device, synth_corpus_device, unpack_packed, unpack_subfingerprint,
 )
-from .sharded import ShardedCorpus, broadcast_fingerprint, shard_range  # noqa: F401
+from .sharded import ShardedCorpus, broadcast_fingerprint, gather_packed, shard_range  # noqa: F401
 
 __all__ = [
     "build", "lib", "constant", "Corpus", "Detective", "Fingerprint", "Frame", "Stream", "LBAudioDetectiveError",
