@@ -162,7 +162,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // split-pass twiddles in consumption order: entry e = (slot q, pair u, half) of lane r at [e * L + r]
     float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
     uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + 64 * L);
-    const uint32_t wave_dw = (uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread;
+    // (+ 64: one scratch word per lane behind the power terms, the target of stores for bins no band reads)
+    const uint32_t wave_dw = ((uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread) + 64u;
     float* tbuf = reinterpret_cast<float*>(claim_slot + 4) + wave * wave_dw;
     float* vbuf = tbuf;   // the power terms reuse the wave's transpose area after the last pass
 
@@ -213,6 +214,26 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     const float inv_norm = 1.0f / (float)(S::W / 4);
     float* tcol = tbuf + wl * S::kWinDw + 2 * r;                 // this lane's column of its window's pass
     const float* trow = tbuf + wl * S::kWinDw + r * S::kRowDw;   // the row this lane receives
+
+    // which of this lane's 64 bins a band reads (bit (q L + u) 2 + half), fixed for the life of the workgroup
+    uint32_t need[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < R / 2; ++q) {
+        const int slot = r * (R / 2) + q;
+#pragma unroll
+        for (int u = 0; u < L; ++u) {
+            uint32_t ka = (uint32_t)(slot + 64 * u);
+            if (q == 0 && slot == 0 && u >= L / 2) ka = (uint32_t)(32 + 64 * (u - L / 2));
+            uint32_t kb = (uint32_t)N - ka;
+            if (q == 0 && slot == 0 && u == 0) kb = (uint32_t)(N / 2);
+            const int bit = (q * L + u) * 2;
+            if (ka >= kmin && ka < kmax) need[bit >> 5] |= 1u << (bit & 31);
+            if (kb >= kmin && kb < kmax && kb != ka) need[(bit + 1) >> 5] |= 1u << ((bit + 1) & 31);
+        }
+    }
+    // per-lane corrections of the bin numbers of slot 0 (rows 0 and 32 pair with themselves)
+    const int adj_a = r == 0 ? 32 - 32 * L : 0;      // pairs u >= L/2 of slot 0 are bins 32 + 64 (u - L/2)
+    const int adj_b = r == 0 ? N / 2 : 0;            // pair 0 of slot 0: partner bin N/2 instead of N
 
     float out[WPW];                  // band means of the previous unit, stored one iteration late
 #pragma unroll
@@ -329,17 +350,26 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
 
     // ---- D: power terms -> LDS (every read of the last pass has returned: the values are in
     //         registers), band means in bin order -----------------------------------------------------
+    {
+        // a power term goes to vbuf[window][bin - kmin] when a band reads the bin, to the lane's scratch
+        // word otherwise: no bin arithmetic, predicates or divergent stores in the loop
+        float* vwin = vbuf + wl * nread - kmin;
+        float* dummy = vbuf + WPW * nread + lane;
 #pragma unroll
-    for (int q = 0; q < R / 2; ++q) {
-        const int slot = r_now * (R / 2) + q;
+        for (int q = 0; q < R / 2; ++q) {
+            const int slot = r_now * (R / 2) + q;
 #pragma unroll
-        for (int u = 0; u < L; ++u) {
-            uint32_t ka = (uint32_t)(slot + 64 * u);
-            if (q == 0 && slot == 0 && u >= L / 2) ka = (uint32_t)(32 + 64 * (u - L / 2));
-            uint32_t kb = (uint32_t)N - ka;
-            if (q == 0 && slot == 0 && u == 0) kb = (uint32_t)(N / 2);
-            if (ka >= kmin && ka < kmax) vbuf[wl * nread + (ka - kmin)] = pw[q][2 * u];
-            if (kb >= kmin && kb < kmax && kb != ka) vbuf[wl * nread + (kb - kmin)] = pw[q][2 * u + 1];
+            for (int u = 0; u < L; ++u) {
+                int ka = slot + 64 * u;
+                if (q == 0 && u >= L / 2) ka += adj_a;
+                int kb = N - ka;
+                if (q == 0 && u == 0) kb -= adj_b;
+                const int bit = (q * L + u) * 2;
+                float* pa = (need[bit >> 5] >> (bit & 31)) & 1u ? vwin + ka : dummy;
+                float* pb = (need[(bit + 1) >> 5] >> ((bit + 1) & 31)) & 1u ? vwin + kb : dummy;
+                *pa = pw[q][2 * u];
+                *pb = pw[q][2 * u + 1];
+            }
         }
     }
     // (wave-local: LDS operations of one wave execute in order)
@@ -378,7 +408,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
 template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax) {
     using S = Shape<LOG2L>;
     const uint32_t nread = (kmax - kmin + 63u) & ~63u;
-    const uint32_t wave_dw = (uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread;
+    const uint32_t wave_dw = ((uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread) + 64u;
     return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * 64 * (size_t)S::L + 4 + (size_t)kWaves * wave_dw) * sizeof(float);
 }
 
