@@ -457,6 +457,41 @@ def test_full_size_fingerprint_batch(lb, gpu, oracle):
     assert int((words[:, 6] >> 8).abs().sum().item()) == 0 and int(words[:, 7].abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize("name,rate,window,seconds,n,stereo", [
+    ("configs[0] settings (defaults)", 5512, 2048, 9, 20_000, False),
+    ("configs[4]", 48000, 4096, 1, 10_000, True),
+])
+def test_full_size_other_configurations(lb, gpu, oracle, name, rate, window, seconds, n, stereo):
+    """The processing configurations of BASELINE configs[0] and configs[4] at batch size: specialised /
+    automatic and generic kernels agree on the whole batch, twins give identical bits, a sample is
+    bit-exact against the oracle, and a chunked run equals the single launch."""
+    samples = rate * seconds
+    if _free_gib(gpu) < 30:
+        pytest.skip("needs ~20 GiB of HBM")
+    clips = lb.synth_clips_device(SEED, 0, n, rate, samples, stereo)
+    twins = [5, n // 2, n - 1]
+    for t in twins[1:]:
+        clips[t].copy_(clips[twins[0]])
+    det = lb.Detective().configure(sample_rate=rate, window=window)
+    auto = det.fingerprint_clips_device(clips)
+    det.set_kernel_variant(1)
+    generic = det.fingerprint_clips_device(clips)
+    gpu.cuda.synchronize()
+    assert gpu.equal(auto, generic), name
+    for t in twins[1:]:
+        assert gpu.equal(auto[t], auto[twins[0]])
+    det.set_kernel_variant(0)
+    det.set_scratch_limit(1 << 27)
+    chunked = det.fingerprint_clips_device(clips)
+    gpu.cuda.synchronize()
+    assert gpu.equal(chunked, auto)
+    pick = [0, 1, n // 3, n - 2]
+    cfg = oracle.Config(rate, window)
+    want = oracle.fingerprint_batch(clips[pick].cpu().numpy(), cfg, nthreads=4)
+    got = lb.unpack_packed(auto[pick].cpu().numpy(), 200).reshape(want.shape)
+    assert np.array_equal(got, want), name
+
+
 @pytest.mark.parametrize("n", [1_000_000, 10_000_000])
 def test_full_size_corpus(lb, gpu, oracle, n):
     """configs[2]/[3]: 1 M and 10 M fingerprints.  The planted near-duplicate is found with the
