@@ -171,17 +171,42 @@ Boolean LBAudioDetectiveFrameEqualToFrame(LBAudioDetectiveFrameRef inFrame1, LBA
  * Part 2 -- additions
  * ==================================================================================== */
 
-/* How the file entry points hop between windows when the file's rate differs from the processing
- * rate.  0 (default): analysisStride samples at the PROCESSING rate, like the PCM entry points.
- * 1: what upstream actually does -- its seek offsets and its length are in FILE
- * frames, so the hop is analysisStride * processingRate / fileRate processing-rate samples (rounded,
- * at least 1) and the window count is (fileFrames - windowSize) / analysisStride. */
+/* How the file entry points walk a file whose rate differs from the processing rate.
+ * Hop mode 1 (default) is what upstream does (LBAudioDetective.m:236,250,275,287-288): its
+ * length and its seek offsets are in FILE frames while every read asks for windowSize frames at the
+ * PROCESSING rate, so the window count is (fileFrames - windowSize) / analysisStride and the hop is
+ * analysisStride * processingRate / fileRate processing-rate samples (rounded, at least 1).
+ * Hop mode 0: analysisStride samples at the processing rate, like the PCM entry points. */
 OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef inDetective, UInt32 inMode);
+/* Hop mode 1 only -- the windows upstream starts so close to the end of the file that ExtAudioFileRead
+ * cannot deliver windowSize frames (the last ~windowSize * fileRate / processingRate file frames):
+ *   1 (default) the read delivers nothing: inNumberFrames = 0 makes every band of the row 0.0
+ *     (LBAudioDetective.m:382-383,404).  This is the behaviour that reproduces the essay's Fig. 24
+ *     (eight lossless `_eql` fixtures within 0.5 points);
+ *   2 partial reads, literally: the unread part of the in-place FFT buffer keeps the previous window's
+ *     packed spectrum and nRead replaces the window size in the band arithmetic (:275,281,351-355,373-395);
+ *   0 the unread part is cleared (not upstream). */
+OSStatus LBAudioDetectiveSetFileTailMode(LBAudioDetectiveRef inDetective, UInt32 inMode);
+/* Converter model of the file entry points (Apple's is closed source): 0 (default) Kaiser-windowed sinc,
+ * 24 zero crossings, cut-off 0.92 Nyquist; 1 short sinc (4 zero crossings, cut-off at Nyquist: leaky);
+ * 2 linear interpolation (no anti-alias filter). */
+OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef inDetective, UInt32 inMode);
 /* Decode a file to mono float32, optionally converted to inSampleRate (0 = keep the file's rate).
  * The buffer is owned by the caller and released with LBAudioDetectiveFreeSamples. */
 OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
                                       UInt64* outCount, Float64* outSampleRate);
+OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate,
+                                                   UInt32 inResamplerMode, Float32** outSamples, UInt64* outCount,
+                                                   Float64* outSampleRate);
 void LBAudioDetectiveFreeSamples(Float32* inSamples);
+/* The file loop of LBAudioDetective.m:241-293 on a file that is already decoded and converted:
+ * inClientSamples = the whole file at the processing rate, inFileFrames = its length in FILE frames (what
+ * kExtAudioFileProperty_FileLengthFrames reports, :236), inHop = processing-rate samples between window
+ * starts.  Honours the file tail mode.  LBAudioDetectiveProcessAudioURL in hop mode 1 is
+ * decode + convert + this. */
+OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef inDetective, const Float32* inClientSamples,
+                                           UInt64 inClientCount, UInt64 inFileFrames, UInt32 inHop,
+                                           LBAudioDetectiveFingerprintRef* outFingerprint);
 
 /* Number of sub-fingerprints a buffer of inNumberOfSamples yields with the detective's
  * window/stride (framing of LBAudioDetective.m:250-255; 0 when shorter than a window). */

@@ -93,6 +93,11 @@ _SIGNATURES = {
     "LBAudioDetectiveFrameEqualToFrame": (Boolean, [Ref, Ref]),
     # ---- additions ----
     "LBAudioDetectiveSetFileHopMode": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveSetFileTailMode": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveSetResamplerMode": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveReadAudioURLWithResampler": (OSStatus, [C.c_char_p, Float64, UInt32, _P(_P(Float32)), _P(UInt64),
+                                                            _P(Float64)]),
+    "LBAudioDetectiveProcessFileStream": (OSStatus, [Ref, C.c_void_p, UInt64, UInt64, UInt32, _P(Ref)]),
     "LBAudioDetectiveReadAudioURL": (OSStatus, [C.c_char_p, Float64, _P(_P(Float32)), _P(UInt64), _P(Float64)]),
     "LBAudioDetectiveFreeSamples": (None, [_P(Float32)]),
     "LBAudioDetectiveGetSubfingerprintCount": (UInt64, [Ref, UInt64]),

@@ -288,8 +288,28 @@ class Detective:
         return int(self._L.LBAudioDetectiveGetSubfingerprintCount(self._ref, n_samples))
 
     def set_file_hop_mode(self, mode: int):
-        """0: hop in processing-rate samples; 1: upstream's file-frame hop."""
+        """1 (default): upstream's file-frame hop; 0: hop in processing-rate samples."""
         _check(self._L.LBAudioDetectiveSetFileHopMode(self._ref, mode), "SetFileHopMode")
+        return self
+
+    def set_file_tail_mode(self, mode: int):
+        """Hop mode 1, windows reaching past the end of the file: 1 (default) nothing is read -> zero rows,
+        2 partial reads over the stale spectrum, 0 zero-filled."""
+        _check(self._L.LBAudioDetectiveSetFileTailMode(self._ref, mode), "SetFileTailMode")
+        return self
+
+    def set_resampler_mode(self, mode: int):
+        """0 (default) long Kaiser sinc, 1 short sinc, 2 linear interpolation."""
+        _check(self._L.LBAudioDetectiveSetResamplerMode(self._ref, mode), "SetResamplerMode")
+        return self
+
+    def process_file_stream(self, client_samples, file_frames: int, hop: int) -> "Fingerprint":
+        """Upstream's file loop (D.m:241-293) on a file already converted to the processing rate."""
+        x = _f32(client_samples).reshape(-1)
+        out = N.Ref()
+        _check(self._L.LBAudioDetectiveProcessFileStream(self._ref, x.ctypes.data, x.size, int(file_frames), int(hop),
+                                                         C.byref(out)), "ProcessFileStream")
+        return Fingerprint(_ref=out.value)
 
     # file entry points (D.h:218,235)
     def process_audio_url(self, path: str) -> Fingerprint:
@@ -495,11 +515,11 @@ class Corpus:
         return int(idx.value), float(score.value)
 
 
-def read_audio_url(path: str, sample_rate: float = 0.0):
+def read_audio_url(path: str, sample_rate: float = 0.0, resampler: int = 0):
     """Decode a CAF/WAV file to mono float32 (numpy), optionally resampled; returns (samples, rate)."""
     buf, n, rate = C.POINTER(N.Float32)(), N.UInt64(0), N.Float64(0.0)
-    _check(N.lib().LBAudioDetectiveReadAudioURL(path.encode(), float(sample_rate), C.byref(buf), C.byref(n),
-                                                C.byref(rate)), "ReadAudioURL")
+    _check(N.lib().LBAudioDetectiveReadAudioURLWithResampler(path.encode(), float(sample_rate), int(resampler),
+                                                             C.byref(buf), C.byref(n), C.byref(rate)), "ReadAudioURL")
     try:
         out = np.ctypeslib.as_array(buf, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
     finally:

@@ -25,6 +25,20 @@ static void free_plan(Plan& p) {
     p = Plan();
 }
 
+// stride-dependent part of a plan: which specialised stage-1 kernels apply, and their tables
+static OSStatus plan_kernels(Plan& p) {
+    p.pruned_ok = rows_pruned_supported(p);
+    if (p.pruned_ok && !p.d_bin_const) {
+        std::vector<float> bc;
+        rows_pruned_constants(bc);
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bin_const), bc.size() * sizeof(float)));
+        LBAD_HIP(hipMemcpy(p.d_bin_const, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    p.full_ok = rows_full_supported(p);
+    if (p.full_ok && !p.d_claim) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
+    return noErr;
+}
+
 // (re)build the device tables when the configuration changed since the last call
 OSStatus ensure_plan(LBAudioDetective* d) {
     const double rate = d->format.mSampleRate;
@@ -33,9 +47,15 @@ OSStatus ensure_plan(LBAudioDetective* d) {
         d->subfp_len > kRowsPerFrame * d->bands)
         return kLBAudioDetectiveArgumentInvalid;
     Plan& p = d->plan;
-    if (p.valid && p.sample_rate == rate && p.window == d->window && p.stride == d->stride && p.bands == d->bands &&
-        p.subfp_len == d->subfp_len)
+    if (p.valid && p.sample_rate == rate && p.window == d->window && p.bands == d->bands && p.subfp_len == d->subfp_len) {
+        if (p.stride == d->stride) return noErr;
+        p.stride = d->stride;          // the tables do not depend on the hop; the kernel choice does
+        p.valid = false;
+        OSStatus st = plan_kernels(p);
+        if (st != noErr) return st;
+        p.valid = true;
         return noErr;
+    }
     if (!device_ready()) return kLBAudioDetectiveDeviceUnavailable;
     free_plan(p);
     p.sample_rate = rate;
@@ -64,15 +84,8 @@ OSStatus ensure_plan(LBAudioDetective* d) {
     }
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bands), tbl.size() * sizeof(uint32_t)));
     LBAD_HIP(hipMemcpy(p.d_bands, tbl.data(), tbl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    p.pruned_ok = rows_pruned_supported(p);
-    if (p.pruned_ok) {
-        std::vector<float> bc;
-        rows_pruned_constants(bc);
-        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bin_const), bc.size() * sizeof(float)));
-        LBAD_HIP(hipMemcpy(p.d_bin_const, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
-    p.full_ok = rows_full_supported(p);
-    if (p.full_ok) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
+    OSStatus st = plan_kernels(p);
+    if (st != noErr) return st;
     p.valid = true;
     return noErr;
 }
@@ -87,10 +100,32 @@ static OSStatus ensure_scratch(LBAudioDetective* d, uint64_t floats) {
     return noErr;
 }
 
+// End-of-file treatment of upstream's file loop (one clip = one file, float32): rows from
+// `first_short` on belong to windows whose read cannot be met in full.
+struct FileTail {
+    uint32_t mode = 0;          // 1: nothing read -> all-zero rows; 2: partial reads over the stale spectrum
+    uint64_t first_short = 0;   // first such window
+    uint64_t n_client = 0;      // samples the file really has at the processing rate
+    const uint32_t* d_tbl = nullptr;   // mode 2: per window [n_read, lo[bands], hi[bands]] on the device
+};
+
+static hipError_t apply_file_tail(const Plan& p, const FileTail& t, const void* d_pcm, uint64_t rows, float* frames,
+                                  hipStream_t stream) {
+    if (t.first_short >= rows) return hipSuccess;
+    if (t.mode == 1)   // inNumberFrames == 0: empty band loops, 0 / width = +0.0f in every band (:382-404)
+        return hipMemsetAsync(frames + t.first_short * p.bands, 0, (rows - t.first_short) * p.bands * sizeof(float), stream);
+    if (t.mode == 2)
+        return launch_file_tail(p, static_cast<const float*>(d_pcm), t.n_client, p.stride, t.first_short,
+                                (uint32_t)(rows - t.first_short), t.d_tbl, frames, stream);
+    return hipSuccess;
+}
+
 // The batch hot path: every clip -> frames_per_clip packed sub-fingerprints.
 OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, uint32_t fmt, uint64_t n_clips,
-                                  uint64_t spc, uint32_t* d_packed, float* d_raw, float* d_haar, hipStream_t stream) {
+                                  uint64_t spc, uint32_t* d_packed, float* d_raw, float* d_haar, hipStream_t stream,
+                                  const FileTail* tail = nullptr) {
     if (fmt > 2) return kLBAudioDetectiveArgumentInvalid;
+    if (tail && (n_clips != 1 || fmt != 0)) return kLBAudioDetectiveArgumentInvalid;
     const size_t elem = fmt == 1 ? 2 : 4;
     const char* d_pcm = static_cast<const char*>(d_pcm_raw);
     OSStatus st = ensure_plan(d);
@@ -117,6 +152,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     const uint64_t frame_floats = (uint64_t)kRowsPerFrame * p.bands;
     if (d_raw) {  // the caller's tap buffer doubles as the inter-kernel scratch
         LBAD_HIP(stage1(d_pcm, n_clips, d_raw));
+        if (tail) LBAD_HIP(apply_file_tail(p, *tail, d_pcm, per * kRowsPerFrame, d_raw, stream));
         LBAD_HIP(stage2(d_raw, n_clips * per, d_packed, d_haar));
         return noErr;
     }
@@ -140,12 +176,101 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
         const uint64_t nc = (n_clips - c0) < chunk ? (n_clips - c0) : chunk;
         LBAD_HIP(mark());
         LBAD_HIP(stage1(d_pcm + c0 * spc * elem, nc, d->d_frames));
+        if (tail) LBAD_HIP(apply_file_tail(p, *tail, d_pcm, per * kRowsPerFrame, d->d_frames, stream));
         LBAD_HIP(mark());
         LBAD_HIP(stage2(d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
                         d_haar ? d_haar + c0 * per * frame_floats : nullptr));
         LBAD_HIP(mark());
     }
     return noErr;
+}
+
+// ---- the one-off entry points (host buffers in, Booleans out) -----------------------------------
+// Device buffers, a pinned staging area and a stream live in the detective and only grow, so a
+// caller that fingerprints many short buffers (ProcessPCM, StreamPush, ProcessAudioURL) pays no
+// allocation per call.
+constexpr size_t kPinnedLimit = 64u << 20;   // larger transfers go straight from the caller's memory
+
+static OSStatus grow_device(void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return noErr;
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4;
+    LBAD_HIP(hipMalloc(ptr, want));
+    *cap = want;
+    return noErr;
+}
+
+static OSStatus ensure_io(LBAudioDetective* d, size_t pcm_bytes, size_t packed_bytes, size_t extra_bytes) {
+    OSStatus st = grow_device(&d->d_io_pcm, &d->d_io_pcm_cap, pcm_bytes + extra_bytes + 256);
+    if (st != noErr) return st;
+    st = grow_device(reinterpret_cast<void**>(&d->d_io_packed), &d->d_io_packed_cap, packed_bytes);
+    if (st != noErr) return st;
+    if (!d->io_stream) LBAD_HIP(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking));
+    const size_t stage = pcm_bytes + packed_bytes + extra_bytes;
+    if (stage <= kPinnedLimit && d->h_io_cap < stage) {
+        if (d->h_io) (void)hipHostFree(d->h_io);
+        d->h_io = nullptr;
+        d->h_io_cap = 0;
+        const size_t want = stage + stage / 4;
+        LBAD_HIP(hipHostMalloc(&d->h_io, want, hipHostMallocDefault));
+        d->h_io_cap = want;
+    }
+    return noErr;
+}
+
+// host clips -> Booleans through the persistent buffers.  `tail`/`tbl_words` describe the end-of-file
+// treatment of a single float32 clip (tbl = mode-2 table, copied behind the PCM).
+static OSStatus fingerprint_clips_host(LBAudioDetective* d, const void* clips, uint32_t fmt, uint64_t n_clips, uint64_t spc,
+                                       Boolean* out, FileTail* tail = nullptr, const std::vector<uint32_t>* tbl = nullptr) {
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    const uint64_t per = subfingerprint_count(spc, d->window, d->stride);
+    if (per == 0 || n_clips == 0) return noErr;
+    const size_t pcm_bytes = (size_t)n_clips * spc * (fmt == 1 ? 2 : 4);
+    const size_t pcm_pad = (pcm_bytes + 255) & ~(size_t)255;
+    const size_t n_sub = (size_t)n_clips * per;
+    const size_t packed_bytes = n_sub * LBAD_PACKED_BYTES;
+    const size_t tbl_bytes = tbl ? tbl->size() * sizeof(uint32_t) : 0;
+    st = ensure_io(d, pcm_pad, packed_bytes, tbl_bytes);
+    if (st != noErr) return st;
+    hipStream_t stream = d->io_stream;
+    char* dev = static_cast<char*>(d->d_io_pcm);
+    const bool pinned = pcm_pad + packed_bytes + tbl_bytes <= kPinnedLimit;
+    char* stage = static_cast<char*>(d->h_io);
+    std::vector<uint32_t> packed_big;
+    uint32_t* packed_host;
+    if (pinned) {
+        std::memcpy(stage, clips, pcm_bytes);
+        if (tbl_bytes) std::memcpy(stage + pcm_pad, tbl->data(), tbl_bytes);
+        LBAD_HIP(hipMemcpyAsync(dev, stage, pcm_pad + tbl_bytes, hipMemcpyHostToDevice, stream));
+        packed_host = reinterpret_cast<uint32_t*>(stage + pcm_pad + tbl_bytes);
+    } else {
+        LBAD_HIP(hipMemcpyAsync(dev, clips, pcm_bytes, hipMemcpyHostToDevice, stream));
+        if (tbl_bytes) LBAD_HIP(hipMemcpyAsync(dev + pcm_pad, tbl->data(), tbl_bytes, hipMemcpyHostToDevice, stream));
+        packed_big.resize(n_sub * LBAD_PACKED_WORDS);
+        packed_host = packed_big.data();
+    }
+    if (tail) tail->d_tbl = reinterpret_cast<const uint32_t*>(dev + pcm_pad);
+    st = fingerprint_clips_device(d, dev, fmt, n_clips, spc, d->d_io_packed, nullptr, nullptr, stream, tail);
+    if (st != noErr) return st;
+    LBAD_HIP(hipMemcpyAsync(packed_host, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
+    LBAD_HIP(hipStreamSynchronize(stream));
+    for (size_t s = 0; s < n_sub; ++s)
+        LBAudioDetectiveUnpackSubfingerprint(packed_host + s * LBAD_PACKED_WORDS, d->subfp_len, out + s * d->subfp_len);
+    return noErr;
+}
+
+// :297-298,326-328 -- New(0), then the length is fixed when the first sub-fingerprint arrives
+static LBAudioDetectiveFingerprintRef fingerprint_from_bools(const LBAudioDetective* d, const Boolean* bools, uint64_t per) {
+    LBAudioDetectiveFingerprintRef fp = LBAudioDetectiveFingerprintNew(0);
+    for (uint64_t s = 0; s < per; ++s) {
+        UInt32 len = d->subfp_len;
+        LBAudioDetectiveFingerprintSetSubfingerprintLength(fp, &len);
+        LBAudioDetectiveFingerprintAddSubfingerprint(fp, const_cast<Boolean*>(bools) + (size_t)s * d->subfp_len);
+    }
+    return fp;
 }
 
 }  // namespace lbad
@@ -168,6 +293,10 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective == NULL) return kLBAudioDetectiveArgumentInvalid;
     lbad::free_plan(inDetective->plan);
     if (inDetective->d_frames) (void)hipFree(inDetective->d_frames);
+    if (inDetective->d_io_pcm) (void)hipFree(inDetective->d_io_pcm);
+    if (inDetective->d_io_packed) (void)hipFree(inDetective->d_io_packed);
+    if (inDetective->h_io) (void)hipHostFree(inDetective->h_io);
+    if (inDetective->io_stream) (void)hipStreamDestroy(inDetective->io_stream);
     for (hipEvent_t e : inDetective->ev) (void)hipEventDestroy(e);
     delete inDetective;
     return noErr;
@@ -309,31 +438,7 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef d, const voi
                                                 UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
                                                 Boolean* outBooleans) {
     if (!d || !inClips || !outBooleans || inSampleFormat > 2) return kLBAudioDetectiveArgumentInvalid;
-    OSStatus st = ensure_plan(d);
-    if (st != noErr) return st;
-    const uint64_t per = lbad::subfingerprint_count(inSamplesPerClip, d->window, d->stride);
-    if (per == 0 || inNumberOfClips == 0) return noErr;
-    const size_t pcm_bytes = (size_t)inNumberOfClips * inSamplesPerClip * (inSampleFormat == 1 ? 2 : 4);
-    const size_t n_sub = (size_t)inNumberOfClips * per;
-    void* d_pcm = nullptr;
-    uint32_t* d_packed = nullptr;
-    LBAD_HIP(hipMalloc(&d_pcm, pcm_bytes));
-    st = lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&d_packed), n_sub * LBAD_PACKED_BYTES), "hipMalloc", __LINE__);
-    std::vector<uint32_t> packed(n_sub * LBAD_PACKED_WORDS);
-    if (st == noErr) st = lbad::hip_status(hipMemcpy(d_pcm, inClips, pcm_bytes, hipMemcpyHostToDevice), "copy pcm", __LINE__);
-    if (st == noErr)
-        st = lbad::fingerprint_clips_device(d, d_pcm, inSampleFormat, inNumberOfClips, inSamplesPerClip, d_packed, nullptr,
-                                            nullptr, nullptr);
-    if (st == noErr)
-        st = lbad::hip_status(hipMemcpy(packed.data(), d_packed, n_sub * LBAD_PACKED_BYTES, hipMemcpyDeviceToHost),
-                              "copy packed", __LINE__);
-    if (d_packed) (void)hipFree(d_packed);
-    (void)hipFree(d_pcm);
-    if (st != noErr) return st;
-    for (size_t s = 0; s < n_sub; ++s)
-        LBAudioDetectiveUnpackSubfingerprint(packed.data() + s * LBAD_PACKED_WORDS, d->subfp_len,
-                                             outBooleans + s * d->subfp_len);
-    return noErr;
+    return lbad::fingerprint_clips_host(d, inClips, inSampleFormat, inNumberOfClips, inSamplesPerClip, outBooleans);
 }
 
 OSStatus LBAudioDetectiveProcessPCM(LBAudioDetectiveRef d, const Float32* inSamples, UInt64 inNumberOfSamples,
@@ -344,17 +449,10 @@ OSStatus LBAudioDetectiveProcessPCM(LBAudioDetectiveRef d, const Float32* inSamp
     const uint64_t per = lbad::subfingerprint_count(inNumberOfSamples, d->window, d->stride);
     std::vector<Boolean> bools((size_t)per * d->subfp_len);
     if (per) {
-        st = LBAudioDetectiveFingerprintClips(d, inSamples, 1, inNumberOfSamples, bools.data());
+        st = lbad::fingerprint_clips_host(d, inSamples, 0, 1, inNumberOfSamples, bools.data());
         if (st != noErr) return st;
     }
-    // :297-298,326-328 -- New(0), then the length is fixed when the first sub-fingerprint arrives
-    LBAudioDetectiveFingerprintRef fp = LBAudioDetectiveFingerprintNew(0);
-    for (uint64_t s = 0; s < per; ++s) {
-        UInt32 len = d->subfp_len;
-        LBAudioDetectiveFingerprintSetSubfingerprintLength(fp, &len);
-        LBAudioDetectiveFingerprintAddSubfingerprint(fp, bools.data() + (size_t)s * d->subfp_len);
-    }
-    *outFingerprint = fp;
+    *outFingerprint = lbad::fingerprint_from_bools(d, bools.data(), per);
     return noErr;
 }
 
@@ -390,16 +488,29 @@ OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef d, UInt32 inMode) {
     return noErr;
 }
 
-OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
-                                      UInt64* outCount, Float64* outSampleRate) {
-    if (!inFileURL || !outSamples || !outCount) return kLBAudioDetectiveArgumentInvalid;
+OSStatus LBAudioDetectiveSetFileTailMode(LBAudioDetectiveRef d, UInt32 inMode) {
+    if (!d || inMode > 2) return kLBAudioDetectiveArgumentInvalid;
+    d->tail_mode = inMode;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef d, UInt32 inMode) {
+    if (!d || inMode > 2) return kLBAudioDetectiveArgumentInvalid;
+    d->resampler = inMode;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate,
+                                                   UInt32 inResamplerMode, Float32** outSamples, UInt64* outCount,
+                                                   Float64* outSampleRate) {
+    if (!inFileURL || !outSamples || !outCount || inResamplerMode > 2) return kLBAudioDetectiveArgumentInvalid;
     std::vector<float> mono, conv;
     double rate = 0.0;
     OSStatus st = read_url(inFileURL, mono, rate);
     if (st != noErr) return st;
     const std::vector<float>* src = &mono;
     if (inSampleRate > 0.0 && std::fabs(inSampleRate - rate) > 1e-9 * rate) {
-        lbad::resample(mono, rate, inSampleRate, conv);
+        if (!lbad::resample(mono, rate, inSampleRate, inResamplerMode, conv)) return kLBAudioDetectiveArgumentInvalid;
         src = &conv;
         rate = inSampleRate;
     }
@@ -412,7 +523,67 @@ OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 
     return noErr;
 }
 
+OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
+                                      UInt64* outCount, Float64* outSampleRate) {
+    return LBAudioDetectiveReadAudioURLWithResampler(inFileURL, inSampleRate, 0, outSamples, outCount, outSampleRate);
+}
+
 void LBAudioDetectiveFreeSamples(Float32* inSamples) { std::free(inSamples); }
+
+// Upstream's loop over a file already converted to the processing rate (`client`), with upstream's
+// bookkeeping: the window count from the length in FILE frames (:236,250-255), window i starting i * hop
+// client samples in (:287-288), and the chosen treatment of the windows that reach past the end.
+OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32* inClientSamples, UInt64 inClientCount,
+                                           UInt64 inFileFrames, UInt32 inHop, LBAudioDetectiveFingerprintRef* outFingerprint) {
+    if (!d || !outFingerprint || (!inClientSamples && inClientCount) || inHop == 0) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    const uint32_t W = d->window;
+    uint64_t frames = 0;
+    if (d->stride != 0 && inFileFrames >= W) frames = ((inFileFrames - W) / d->stride) / lbad::kRowsPerFrame;   // :250,255
+    if (frames == 0) {
+        *outFingerprint = LBAudioDetectiveFingerprintNew(0);
+        return noErr;
+    }
+    const uint64_t rows = frames * lbad::kRowsPerFrame;
+    const uint64_t need = rows * inHop + W;                // (need - W) / hop / 128 == frames
+    std::vector<float> padded;
+    const float* pcm = inClientSamples;
+    if (need > inClientCount) {                             // stage 1 transforms every window; the tail is redone below
+        padded.assign(need, 0.0f);
+        std::memcpy(padded.data(), inClientSamples, sizeof(float) * inClientCount);
+        pcm = padded.data();
+    }
+    lbad::FileTail tail;
+    tail.mode = d->tail_mode;
+    tail.n_client = inClientCount;
+    tail.first_short = inClientCount >= W ? (inClientCount - W) / inHop + 1 : 0;
+    std::vector<uint32_t> tbl;
+    if (tail.mode == 2 && tail.first_short < rows) {        // nRead shrinks monotonically (:252,275: in/out argument)
+        const uint32_t bands = d->bands;
+        const uint64_t n_tail = rows - tail.first_short;
+        tbl.resize((size_t)n_tail * (1 + 2 * bands));
+        uint32_t n_read = W;
+        for (uint64_t t = 0; t < n_tail; ++t) {
+            const uint64_t start = (tail.first_short + t) * inHop;
+            const uint64_t avail = inClientCount > start ? inClientCount - start : 0;
+            if (avail < n_read) n_read = (uint32_t)avail;
+            uint32_t* e = tbl.data() + (size_t)t * (1 + 2 * bands);
+            e[0] = n_read;
+            lbad::make_band_bounds(d->format.mSampleRate, W, n_read, d->plan.table, e + 1, e + 1 + bands);
+        }
+    }
+    std::vector<Boolean> bools((size_t)frames * d->subfp_len);
+    const uint32_t saved = d->stride;
+    d->stride = inHop;                                      // the plan is keyed by the hop between windows
+    st = ensure_plan(d);
+    if (st == noErr)
+        st = lbad::fingerprint_clips_host(d, pcm, 0, 1, need, bools.data(), tail.mode ? &tail : nullptr, tbl.empty() ? nullptr : &tbl);
+    d->stride = saved;
+    if (st != noErr) return st;
+    *outFingerprint = lbad::fingerprint_from_bools(d, bools.data(), frames);
+    return noErr;
+}
 
 OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
@@ -424,29 +595,15 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetective
     const double rate = d->format.mSampleRate;
     if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
     // ExtAudioFile converts to the client format (:229); here: decode on the host, then resample
-    lbad::resample(file, file_rate, rate, mono);
-    if (d->hop_mode == 0 || std::fabs(file_rate - rate) <= 1e-9 * rate)
-        return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
+    if (!lbad::resample(file, file_rate, rate, d->resampler, mono)) return kLBAudioDetectiveArgumentInvalid;
+    if (d->hop_mode == 0) return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
 
-    // hop_mode 1 -- what upstream actually does with a file whose rate differs from the processing
-    // rate: the length (:236) and the seek offsets (:287-288) are in FILE frames while each
-    // read returns windowSize CLIENT frames, so the hop is analysisStride file frames =
-    // analysisStride * rate / file_rate client samples and the window count comes from the file length.
-    const uint64_t file_frames = file.size();
-    if (d->stride == 0 || file_frames < d->window) return LBAudioDetectiveProcessPCM(d, mono.data(), 0, outFingerprint);
-    const uint64_t image_width = (file_frames - d->window) / d->stride;                    // :250
-    const uint64_t frames = image_width / lbad::kRowsPerFrame;                              // :255
+    // hop_mode 1 -- what upstream does: the length (:236) and the seek offsets (:287-288) are
+    // in FILE frames while each read asks for windowSize CLIENT frames, so the hop is analysisStride file
+    // frames = analysisStride * rate / file_rate client samples and the window count comes from the file length.
     uint32_t hop = (uint32_t)std::llround((double)d->stride * rate / file_rate);
     if (hop < 1) hop = 1;
-    // windows that start near the end of the file read short upstream and keep stale buffer contents;
-    // here the stream is zero-padded instead
-    const uint64_t need = frames * lbad::kRowsPerFrame * hop + d->window;
-    mono.resize(need > mono.size() ? need : mono.size(), 0.0f);
-    const uint32_t saved = d->stride;
-    d->stride = hop;
-    st = LBAudioDetectiveProcessPCM(d, mono.data(), need, outFingerprint);
-    d->stride = saved;
-    return st;
+    return LBAudioDetectiveProcessFileStream(d, mono.data(), mono.size(), file.size(), hop, outFingerprint);
 }
 
 OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL1,
@@ -498,7 +655,7 @@ OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef s, const Float32* 
     const uint64_t hop = (uint64_t)lbad::kRowsPerFrame * d->stride;
     const uint64_t use = (uint64_t)d->window + ready * hop;            // yields exactly `ready` frames
     std::vector<Boolean> bools((size_t)ready * d->subfp_len);
-    st = LBAudioDetectiveFingerprintClips(d, s->pending.data(), 1, use, bools.data());
+    st = lbad::fingerprint_clips_host(d, s->pending.data(), 0, 1, use, bools.data());
     if (st != noErr) return st;
     for (uint64_t f = 0; f < ready; ++f) {
         UInt32 len = d->subfp_len;

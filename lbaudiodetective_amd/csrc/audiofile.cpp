@@ -146,8 +146,10 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
                 sample_rate = be_f64(p + body);
                 ima4 = std::memcmp(p + body + 8, "ima4", 4) == 0;
                 if (!ima4 && std::memcmp(p + body + 8, "lpcm", 4) != 0) return AudioFileStatus::Unsupported;
-                if (ima4 && (be32(p + body + 20) != 64 || be32(p + body + 16) != 34u * be32(p + body + 24)))
+                if (ima4 && (be32(p + body + 20) != 64 || be32(p + body + 24) == 0 || be32(p + body + 24) > 64 ||
+                             be32(p + body + 16) != 34u * be32(p + body + 24)))
                     return AudioFileStatus::Unsupported;
+                if (!(sample_rate > 0.0) || !std::isfinite(sample_rate)) return AudioFileStatus::Unsupported;
                 const uint32_t flags = be32(p + body + 12);
                 is_float = flags & 1u;
                 little = flags & 2u;
@@ -183,6 +185,7 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
                 uint16_t tag = le16(p + body);
                 channels = le16(p + body + 2);
                 sample_rate = (double)le32(p + body + 4);
+                if (!(sample_rate > 0.0)) return AudioFileStatus::Unsupported;
                 bits = le16(p + body + 14);
                 if (tag == 0xFFFE && len >= 26) tag = le16(p + body + 24);  // WAVE_FORMAT_EXTENSIBLE
                 if (tag != 1 && tag != 3) return AudioFileStatus::Unsupported;
@@ -192,6 +195,7 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
                 if (!have_fmt) return AudioFileStatus::Unsupported;
                 // 8-bit WAV is unsigned
                 if (!is_float && bits == 8) {
+                    if (channels == 0) return AudioFileStatus::Unsupported;
                     const size_t frames = len / channels;
                     mono.resize(frames);
                     for (size_t i = 0; i < frames; ++i) {
@@ -213,10 +217,15 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
 
 
 // ---- sample-rate conversion -------------------------------------------------------------------------
-// Apple's converter is closed source; this is a documented stand-in: band-limited interpolation with
-// a Kaiser-windowed sinc (beta 9, 24 zero crossings each side at the lower of the two rates, cut-off
-// 0.92 of the lower Nyquist), evaluated in double precision at position n * rate_in / rate_out for
-// output sample n and normalised to unit DC gain per output sample.
+// Apple's converter is closed source; these are documented stand-ins.  Mode 0 (default): band-limited
+// interpolation with a Kaiser-windowed sinc (beta 9, 24 zero crossings each side at the lower of the two
+// rates, cut-off 0.92 of the lower Nyquist), evaluated in double precision at position n * rate_in /
+// rate_out for output sample n and normalised to unit DC gain per output sample.  Mode 1: the same with a
+// short kernel (4 zero crossings, beta 3, cut-off at the Nyquist frequency: a wide transition band that
+// lets the octave above Nyquist alias in at -20..-40 dB).  Mode 2: linear interpolation between the two
+// neighbouring input samples (no anti-alias filter at all).  DESIGN.md section 8 measures the three against
+// the essay's figures: the long kernel and the short one are indistinguishable there, linear
+// interpolation is ruled out by Tests 3.1 / 3.2.
 namespace {
 double bessel_i0(double x) {
     double sum = 1.0, term = 1.0;
@@ -230,14 +239,30 @@ double bessel_i0(double x) {
 }
 }  // namespace
 
-void resample(const std::vector<float>& in, double rate_in, double rate_out, std::vector<float>& out) {
-    if (in.empty() || !(rate_in > 0.0) || !(rate_out > 0.0)) { out.clear(); return; }
-    if (rate_in == rate_out) { out = in; return; }
+bool resample(const std::vector<float>& in, double rate_in, double rate_out, uint32_t mode, std::vector<float>& out) {
+    out.clear();
+    if (mode > 2 || !(rate_in > 0.0) || !(rate_out > 0.0) || !std::isfinite(rate_in) || !std::isfinite(rate_out))
+        return false;
     const double ratio = rate_in / rate_out;                 // input samples per output sample
+    if (!(ratio >= 1.0 / 4096.0) || !(ratio <= 4096.0)) return false;
+    if (in.empty()) return true;
+    if (rate_in == rate_out) { out = in; return true; }
+    const uint64_t n_out = (uint64_t)((double)in.size() / ratio);
+    out.resize(n_out);
+    if (mode == 2) {
+        for (uint64_t n = 0; n < n_out; ++n) {
+            const double pos = (double)n * ratio;
+            const size_t k = (size_t)pos;
+            const double f = pos - (double)k;
+            const double a = k < in.size() ? (double)in[k] : 0.0, b = k + 1 < in.size() ? (double)in[k + 1] : 0.0;
+            out[n] = (float)(a * (1.0 - f) + b * f);
+        }
+        return true;
+    }
     const double scale = ratio > 1.0 ? ratio : 1.0;          // kernel is stretched when decimating
-    const double cutoff = 0.92;
-    const int zero_crossings = 24;
-    const double beta = 9.0, i0b = bessel_i0(beta);
+    const double cutoff = mode == 0 ? 0.92 : 1.0;
+    const int zero_crossings = mode == 0 ? 24 : 4;
+    const double beta = mode == 0 ? 9.0 : 3.0, i0b = bessel_i0(beta);
     // kernel sampled 2048 times per unit of t in [0, zero_crossings], read with linear interpolation
     const int res = 2048;
     std::vector<double> table((size_t)zero_crossings * res + 2);
@@ -249,8 +274,6 @@ void resample(const std::vector<float>& in, double rate_in, double rate_out, std
         table[i] = cutoff * (a < 1e-12 ? 1.0 : std::sin(a) / a) * win;
     }
     const double half = zero_crossings * scale;              // kernel half-width in input samples
-    const uint64_t n_out = (uint64_t)((double)in.size() / ratio);
-    out.resize(n_out);
     for (uint64_t n = 0; n < n_out; ++n) {
         const double pos = (double)n * ratio;
         const long k0 = (long)std::ceil(pos - half), k1 = (long)std::floor(pos + half);
@@ -265,6 +288,7 @@ void resample(const std::vector<float>& in, double rate_in, double rate_out, std
         }
         out[n] = (float)(wsum != 0.0 ? acc / wsum : 0.0);
     }
+    return true;
 }
 
 }  // namespace lbad

@@ -35,6 +35,10 @@ struct BandTable {
 
 // host-side, double precision; mirrors LBAudioDetective.m:361-371,382-383
 void make_band_table(double sample_rate, uint32_t window, uint32_t bands, BandTable& out);
+// bin bounds of every band when ComputeFrequencies is handed n_frames != window (a short read, :281,382-383);
+// reads stay inside the window-sized buffer
+void make_band_bounds(double sample_rate, uint32_t window, uint32_t n_frames, const BandTable& table, uint32_t* lo,
+                      uint32_t* hi);
 // master twiddle table exp(-2 pi i k / W), k in [0, W/2)
 void make_twiddles(uint32_t W, std::vector<float>& re, std::vector<float>& im);
 
@@ -78,6 +82,11 @@ hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, u
 bool haar_select32_supported(const Plan& plan);
 hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_t n_frames, uint32_t* d_packed,
                                 float* d_haar_out, hipStream_t stream);
+
+// end-of-file chain of upstream's file loop, tail mode "stale" (k_file_tail.hip); d_tbl: per window
+// [n_read, lo[bands], hi[bands]]
+hipError_t launch_file_tail(const Plan& plan, const float* d_pcm, uint64_t n_client, uint32_t hop, uint64_t first_short,
+                            uint32_t n_tail, const uint32_t* d_tbl, float* d_frames, hipStream_t stream);
 
 // generic matrix ops behind the Frame API
 hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream);
@@ -140,11 +149,21 @@ struct LBAudioDetective {
     uint32_t stride;
     uint32_t bands;
     uint32_t variant = 0;
-    uint32_t hop_mode = 0;   // file entry points: 0 = hop in processing-rate samples, 1 = upstream's file-frame hop
+    uint32_t hop_mode = 1;   // file entry points: 0 = hop in processing-rate samples, 1 = upstream's file-frame hop
+    uint32_t tail_mode = 1;  // hop mode 1, windows past the end of the file: 0 zero-filled, 1 nothing read, 2 stale spectrum
+    uint32_t resampler = 0;  // 0 long Kaiser sinc, 1 short sinc, 2 linear interpolation
     lbad::Plan plan;         // lazily rebuilt when the configuration changes
     float* d_frames = nullptr;  // frame rows between stage 1 and stage 2
     uint64_t d_frames_cap = 0;  // in floats
     uint64_t scratch_limit = 16ull << 30;   // bytes of HBM the inter-stage buffer may take
+    // persistent buffers of the one-off (host in, host out) entry points; they only grow
+    void* d_io_pcm = nullptr;
+    size_t d_io_pcm_cap = 0;
+    uint32_t* d_io_packed = nullptr;
+    size_t d_io_packed_cap = 0;
+    void* h_io = nullptr;        // pinned staging for small calls
+    size_t h_io_cap = 0;
+    hipStream_t io_stream = nullptr;
     // optional per-stage timing (hipEvents on the caller's stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2

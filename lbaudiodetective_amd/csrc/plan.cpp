@@ -61,6 +61,19 @@ void make_band_table(double sample_rate, uint32_t window, uint32_t bands, BandTa
     out.kmax = kmax;
 }
 
+void make_band_bounds(double sample_rate, uint32_t window, uint32_t n_frames, const BandTable& table, uint32_t* lo,
+                      uint32_t* hi) {
+    const double bin_hz = sample_rate / (double)n_frames;   // :382-383 with inNumberFrames = n_frames
+    const uint32_t nyq = window / 2;
+    const uint32_t bands = (uint32_t)table.lo.size();
+    for (uint32_t i = 0; i < bands; ++i) {
+        uint32_t l = to_u32((double)(uint32_t)(2u * table.indices[i]) / bin_hz - 1.0);
+        uint32_t h = to_u32((double)(uint32_t)(2u * table.indices[i + 1]) / bin_hz - 1.0);
+        lo[i] = l > nyq ? nyq : l;
+        hi[i] = h > nyq ? nyq : h;
+    }
+}
+
 void make_twiddles(uint32_t W, std::vector<float>& re, std::vector<float>& im) {
     const uint32_t half = W / 2, quarter = W / 4, eighth = W / 8;
     re.assign(half, 0.0f);

@@ -370,6 +370,101 @@ uint64_t lbo_fingerprint_pcm_taps(const float* pcm, uint64_t n_samples, const lb
     return count;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * the file loop as upstream really runs it -- LBAudioDetective.m:236-293
+ *
+ * dataLength (:236) and the seek offsets (:287-288) are FILE frames, each read (:275) asks for
+ * CLIENT frames (processing rate), so with a 44.1 kHz file and the 5512 Hz client format
+ *   - the window count comes from the file length: imageWidth = (file_frames - W) / stride (:250);
+ *   - window i starts `hop` client samples after window i-1 (hop = stride * rate / file_rate);
+ *   - readNumberFrames is an in/out argument declared outside the loop (:252,275): a short read near
+ *     the end of the file shrinks every later request as well;
+ *   - the FFT runs in place in `samples` (:351-355), so the W - nRead floats a short read leaves
+ *     untouched are the PREVIOUS window's packed spectrum, and the FFT still spans all W floats;
+ *   - ComputeFrequencies is handed nRead as inNumberFrames (:281): width, the positive-only
+ *     normalisation and the band bin bounds (:373,382-383,390-395) all follow nRead.
+ * `client` is the whole file already converted to the processing rate.  Before the first read the
+ * buffer is taken as zeros (upstream: uninitialised stack).
+ * ---------------------------------------------------------------------------------------- */
+uint64_t lbo_fingerprint_file_loop(const float* client, uint64_t n_client, uint64_t file_frames,
+                                   uint32_t hop, int tail_mode, const lbo_config* cfg,
+                                   uint8_t* out_bools, float* frames_raw, uint32_t* out_n_read) {
+    if (!config_ok(cfg) || hop == 0 || tail_mode < 0 || tail_mode > 2) return (uint64_t)-1;
+    if (file_frames < cfg->window) return 0;
+    const uint64_t image_width = (file_frames - cfg->window) / cfg->stride;      /* :250 */
+    const uint64_t count = image_width / LBO_ROWS_PER_FRAME;                      /* :255 */
+    if (count == 0) return 0;
+    row_ctx rc;
+    if (row_ctx_init(&rc, cfg)) return (uint64_t)-1;
+    const uint32_t W = cfg->window;
+    const size_t frame_elems = (size_t)LBO_ROWS_PER_FRAME * cfg->bands;
+    float* frame = (float*)malloc(sizeof(float) * frame_elems);
+    uint8_t* pairs = (uint8_t*)malloc((size_t)2 * cfg->subfp_len);
+    float* samples = (float*)calloc(W, sizeof(float));                           /* :243 */
+    uint32_t* lo = (uint32_t*)malloc(sizeof(uint32_t) * 2 * cfg->bands);
+    uint32_t* hi = lo + cfg->bands;
+    uint32_t n_read = W;                                                         /* :252 */
+    for (uint64_t f = 0; f < count; ++f) {
+        for (uint32_t r = 0; r < LBO_ROWS_PER_FRAME; ++r) {                      /* :262-290 */
+            const uint64_t i = f * LBO_ROWS_PER_FRAME + r;
+            const uint64_t start = i * (uint64_t)hop;                            /* :287-288 */
+            const uint64_t avail = n_client > start ? n_client - start : 0;
+            float* row = frame + (size_t)r * cfg->bands;
+            if (tail_mode == LBO_TAIL_NOTHING && avail < W) {
+                /* a read that cannot be met in full delivers 0 frames (and, readNumberFrames being
+                 * in/out, so does every later one): inNumberFrames == 0 makes both bin bounds of
+                 * every band (UInt32)(0 - 1.0) == 0 on ARM (:382-383), the loops are empty, the row
+                 * is 0 / width (:404).  The FFT of the stale buffer still runs but is never read. */
+                n_read = 0;
+                if (out_n_read) out_n_read[i] = 0;
+                for (uint32_t b = 0; b < cfg->bands; ++b) row[b] = 0.0f / (float)(rc.indices[b + 1] - rc.indices[b]);
+                continue;
+            }
+            if (tail_mode == LBO_TAIL_ZERO_FILL) {
+                /* not upstream: the unread part of the window is cleared */
+                memset(samples, 0, sizeof(float) * W);
+                n_read = W;
+                memcpy(samples, client + (avail ? start : 0), sizeof(float) * (avail < W ? avail : W));
+                if (out_n_read) out_n_read[i] = W;
+                rfft_exec(&rc.plan, samples, rc.zr, rc.zr + rc.plan.N, rc.spec);
+                lbo_band_energies(rc.spec, W, cfg->bands, rc.indices, rc.lo, rc.hi, row);
+                continue;
+            }
+            if (avail < n_read) n_read = (uint32_t)avail;                        /* :275, in/out */
+            memcpy(samples, client + (avail ? start : 0), sizeof(float) * n_read);
+            if (out_n_read) out_n_read[i] = n_read;
+            rfft_exec(&rc.plan, samples, rc.zr, rc.zr + rc.plan.N, rc.spec);     /* :353-355 */
+            memcpy(samples, rc.spec, sizeof(float) * W);                         /* in place */
+            const float* spec = samples;
+            if (n_read == W) {
+                lbo_band_energies(spec, W, cfg->bands, rc.indices, rc.lo, rc.hi, row);
+            } else {
+                /* bin bounds from nRead (:382-383); reads stay inside the W-float buffer */
+                const double hz_per_bin = cfg->sample_rate / (double)n_read;
+                for (uint32_t b = 0; b < cfg->bands; ++b) {
+                    uint32_t l = trunc_u32(((double)(uint32_t)(2u * rc.indices[b])) / hz_per_bin - 1.0);
+                    uint32_t h = trunc_u32(((double)(uint32_t)(2u * rc.indices[b + 1])) / hz_per_bin - 1.0);
+                    if (l > W / 2) l = W / 2;
+                    if (h > W / 2) h = W / 2;
+                    lo[b] = l;
+                    hi[b] = h;
+                }
+                lbo_band_energies(spec, n_read, cfg->bands, rc.indices, lo, hi, row);
+            }
+        }
+        if (frames_raw) memcpy(frames_raw + f * frame_elems, frame, sizeof(float) * frame_elems);
+        lbo_haar_2d(frame, LBO_ROWS_PER_FRAME, cfg->bands);
+        lbo_extract(frame, LBO_ROWS_PER_FRAME, cfg->bands, cfg->subfp_len, pairs);
+        memcpy(out_bools + f * cfg->subfp_len, pairs, cfg->subfp_len);
+    }
+    free(lo);
+    free(samples);
+    free(pairs);
+    free(frame);
+    row_ctx_free(&rc);
+    return count;
+}
+
 uint64_t lbo_fingerprint_pcm(const float* pcm, uint64_t n_samples, const lbo_config* cfg,
                              uint8_t* out_bools) {
     return lbo_fingerprint_pcm_taps(pcm, n_samples, cfg, out_bools, NULL, NULL);

@@ -101,6 +101,17 @@ uint64_t lbo_fingerprint_pcm(const float* pcm, uint64_t n_samples, const lbo_con
 uint64_t lbo_fingerprint_pcm_taps(const float* pcm, uint64_t n_samples, const lbo_config* cfg,
                                   uint8_t* out_bools, float* frames_raw, float* frames_haar);
 
+/* The file loop with upstream's file-frame bookkeeping and short reads at the end of the file
+ * (LBAudioDetective.m:236-293): `client` is the file at the processing rate, file_frames
+ * its length in FILE frames, hop the client samples between window starts.  frames_raw (optional)
+ * receives the frames before the Haar, out_n_read (optional) nRead of every window used. */
+#define LBO_TAIL_ZERO_FILL 0  /* unread part of a short window cleared (not upstream)                    */
+#define LBO_TAIL_NOTHING   1  /* a read that cannot be met in full delivers 0 frames: all-zero rows       */
+#define LBO_TAIL_STALE     2  /* partial reads; the unread part keeps the previous window's spectrum       */
+uint64_t lbo_fingerprint_file_loop(const float* client, uint64_t n_client, uint64_t file_frames,
+                                   uint32_t hop, int tail_mode, const lbo_config* cfg,
+                                   uint8_t* out_bools, float* frames_raw, uint32_t* out_n_read);
+
 /* n_clips equal-length clips, nthreads OpenMP threads (cpu_baseline leg). */
 int lbo_fingerprint_batch(const float* pcm, uint64_t n_clips, uint64_t samples_per_clip,
                           const lbo_config* cfg, uint8_t* out_bools, int nthreads);

@@ -74,6 +74,8 @@ def lib():
     sig("lbo_subfingerprint_count", C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint32])
     sig("lbo_fingerprint_pcm", C.c_uint64, [f32p, C.c_uint64, cfgp, u8p])
     sig("lbo_fingerprint_pcm_taps", C.c_uint64, [f32p, C.c_uint64, cfgp, u8p, C.c_void_p, C.c_void_p])
+    sig("lbo_fingerprint_file_loop", C.c_uint64, [f32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, cfgp,
+                                                   u8p, C.c_void_p, C.c_void_p])
     sig("lbo_fingerprint_batch", C.c_int, [f32p, C.c_uint64, C.c_uint64, cfgp, u8p, C.c_int])
     sig("lbo_compare_sub", C.c_float, [u8p, u8p, C.c_uint32, C.c_uint32])
     sig("lbo_compare_fp", C.c_float, [u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32])
@@ -168,6 +170,28 @@ def fingerprint_pcm(pcm: np.ndarray, cfg: Config, taps: bool = False):
     if got == 2**64 - 1:
         raise ValueError("invalid config")
     return out, raw, haar
+
+
+TAIL_ZERO_FILL, TAIL_NOTHING, TAIL_STALE = 0, 1, 2
+
+
+def fingerprint_file_loop(client: np.ndarray, file_frames: int, hop: int, cfg: Config, tail_mode: int = TAIL_NOTHING,
+                          taps: bool = False):
+    """Upstream's file loop with file-frame bookkeeping and short reads (lbo_fingerprint_file_loop)."""
+    client = np.ascontiguousarray(client, np.float32)
+    n = 0
+    if file_frames >= cfg.window:
+        n = ((file_frames - cfg.window) // cfg.stride) // ROWS_PER_FRAME
+    out = np.zeros((n, cfg.subfp_len), np.uint8)
+    raw = np.zeros((n, ROWS_PER_FRAME, cfg.bands), np.float32)
+    n_read = np.zeros(n * ROWS_PER_FRAME, np.uint32)
+    got = lib().lbo_fingerprint_file_loop(
+        client if client.size else np.zeros(1, np.float32), client.size, file_frames, hop, tail_mode, C.byref(cfg),
+        out.reshape(-1) if n else np.zeros(1, np.uint8),
+        raw.ctypes.data_as(C.c_void_p) if n else None, n_read.ctypes.data_as(C.c_void_p) if n else None)
+    if got == 2**64 - 1:
+        raise ValueError("invalid config")
+    return (out, raw, n_read) if taps else out
 
 
 def fingerprint_batch(pcm: np.ndarray, cfg: Config, nthreads: int = 1) -> np.ndarray:

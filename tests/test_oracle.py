@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+SEED = 0x4C424144
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -230,3 +232,49 @@ def test_batch_threads_agree(oracle):
     pcm = oracle.synth_clips(9, 0, 6, 44100, 1024 + 128 * 64 * 2)
     cfg = oracle.Config(44100, 1024)
     assert np.array_equal(oracle.fingerprint_batch(pcm, cfg, 1), oracle.fingerprint_batch(pcm, cfg, 4))
+
+
+# ---------------------------------------------------------------------------------------------
+# upstream's file loop (LBAudioDetective.m:236-293) and the essay's figures
+# ---------------------------------------------------------------------------------------------
+def test_file_loop_tail_modes(oracle):
+    cfg = oracle.Config()
+    hop, n_client, file_frames = 8, 30000, 30000 * 8 + 5
+    pcm = oracle.synth_clip(SEED, 3, 8000, n_client)
+    frames = ((file_frames - cfg.window) // cfg.stride) // 128
+    first_short = (n_client - cfg.window) // hop + 1
+    assert frames * 128 > first_short                      # the tail is inside the windows used
+    # zero fill == the plain PCM path on the zero-padded stream with stride = hop
+    z, raw_z, nr_z = oracle.fingerprint_file_loop(pcm, file_frames, hop, cfg, oracle.TAIL_ZERO_FILL, taps=True)
+    need = frames * 128 * hop + cfg.window
+    padded = np.concatenate([pcm, np.zeros(need - n_client, np.float32)])
+    assert np.array_equal(z, oracle.fingerprint_pcm(padded, oracle.Config(stride=hop)))
+    # nothing read: rows of the short windows are +0.0, the others are untouched
+    n, raw_n, nr_n = oracle.fingerprint_file_loop(pcm, file_frames, hop, cfg, oracle.TAIL_NOTHING, taps=True)
+    rows_z, rows_n = raw_z.reshape(-1, 32), raw_n.reshape(-1, 32)
+    assert np.array_equal(rows_n[:first_short], rows_z[:first_short])
+    assert not rows_n[first_short:].any() and (nr_n[first_short:] == 0).all() and (nr_n[:first_short] == cfg.window).all()
+    # stale: nRead shrinks by the hop, the first short window still holds mostly samples, and the recursion over
+    # the previous spectrum overflows within a few dozen windows (rows of NaN-skipped terms are 0)
+    s, raw_s, nr_s = oracle.fingerprint_file_loop(pcm, file_frames, hop, cfg, oracle.TAIL_STALE, taps=True)
+    rows_s = raw_s.reshape(-1, 32)
+    assert np.array_equal(rows_s[:first_short], rows_z[:first_short])
+    assert nr_s[first_short] == n_client - first_short * hop and (np.diff(nr_s[first_short:].astype(np.int64)) == -hop).all()
+    assert np.isfinite(rows_s[first_short]).all() and not np.array_equal(rows_s[first_short], rows_z[first_short])
+    assert not rows_s[first_short + 100:].any()
+    assert z.shape == n.shape == s.shape == (frames, 200)
+
+
+def test_oracle_reproduces_essay_figures(oracle):
+    """The oracle, fed by the library's host-side decoder and converter, through upstream's file loop on
+    upstream's sixty fixtures, against the fifty numbers of the essay's Fig. 24-28
+    (tests/golden/essay_figures.json) -- the only end-to-end results the reference publishes.
+    Bounds and the two fixtures that cannot be reached: tools/birds_matrix.py."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools"))
+    import birds_matrix as bm
+    ms = bm.matrices("oracle")
+    assert bm.check(ms) == [], bm.summarize(ms)
+    d1 = np.diag(ms["test1"])
+    lossless = [i for i, b in enumerate(bm.BIRDS) if b not in bm.UNREACHABLE_TEST1]
+    assert np.abs(d1 - np.array(bm.ESSAY["tests"]["test1"]["right"]))[lossless].max() < 0.6
