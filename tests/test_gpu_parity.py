@@ -295,7 +295,11 @@ def test_file_entry_points(lb, gpu, oracle, tmp_path):
     det.configure(sample_rate=11025, window=512)
     pcm, rate = lb.read_audio_url(pa, 11025)
     assert rate == 11025 and pcm.size == a.size * 11025 // 5512
+    det.set_file_hop_mode(0)              # hop in processing-rate samples
     assert np.array_equal(det.process_audio_url(pa).to_bools(), oracle.fingerprint_pcm(pcm, oracle.Config(11025, 512)))
+    det.set_file_hop_mode(1)              # upstream: hop and length in file frames (64 file frames = 128 samples here)
+    want = oracle.fingerprint_file_loop(pcm, a.size, 128, oracle.Config(11025, 512), oracle.TAIL_NOTHING)
+    assert want.shape[0] > 0 and np.array_equal(det.process_audio_url(pa).to_bools(), want)
 
 
 # ---------------------------------------------------------------------------------------------
