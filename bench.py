@@ -167,6 +167,9 @@ def run_rank(args) -> int:
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
+        if torch.cuda.device_count() < world:
+            sys.stderr.write(f"bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible\n")
+            return 3
         torch.cuda.set_device(local_rank if world > 1 else 0)
         dev = torch.device("cuda", torch.cuda.current_device())
         if world > 1:

@@ -154,17 +154,17 @@ LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNewFromString(const ch
  * ==================================================================================== */
 LBAudioDetectiveFrameRef LBAudioDetectiveFrameNew(UInt32 inMaxRowCount);                       /* Fr.h:27 */
 void LBAudioDetectiveFrameDispose(LBAudioDetectiveFrameRef inFrame);                           /* Fr.h:35 */
-LBAudioDetectiveFrameRef LBAudioDetectiveFrameCopy(LBAudioDetectiveFrameRef inFrame);          /* Fr.h:44 */
-UInt32 LBAudioDetectiveFrameGetNumberOfRows(LBAudioDetectiveFrameRef inFrame);                 /* Fr.h:58 */
-Float32* LBAudioDetectiveFrameGetRow(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex);     /* Fr.h:69 */
-Float32 LBAudioDetectiveFrameGetValue(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex, UInt32 inColumnIndex); /* Fr.h:81 */
-Boolean LBAudioDetectiveFrameFull(LBAudioDetectiveFrameRef inFrame);                           /* Fr.h:91 */
-Boolean LBAudioDetectiveFrameSetRow(LBAudioDetectiveFrameRef inFrame, Float32* inRow, UInt32 inRowIndex, UInt32 inCount); /* Fr.h:107 */
-void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame);                         /* Fr.h:119  (GPU Haar) */
-size_t LBAudioDetectiveFrameFingerprintSize(LBAudioDetectiveFrameRef inFrame);                 /* Fr.h:129 */
-UInt32 LBAudioDetectiveFrameFingerprintLength(LBAudioDetectiveFrameRef inFrame);               /* Fr.h:139 */
+LBAudioDetectiveFrameRef LBAudioDetectiveFrameCopy(LBAudioDetectiveFrameRef inFrame);          /* Fr.h:45 */
+UInt32 LBAudioDetectiveFrameGetNumberOfRows(LBAudioDetectiveFrameRef inFrame);                 /* Fr.h:59 */
+Float32* LBAudioDetectiveFrameGetRow(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex);     /* Fr.h:71 */
+Float32 LBAudioDetectiveFrameGetValue(LBAudioDetectiveFrameRef inFrame, UInt32 inRowIndex, UInt32 inColumnIndex); /* Fr.h:83 */
+Boolean LBAudioDetectiveFrameFull(LBAudioDetectiveFrameRef inFrame);                           /* Fr.h:93 */
+Boolean LBAudioDetectiveFrameSetRow(LBAudioDetectiveFrameRef inFrame, Float32* inRow, UInt32 inRowIndex, UInt32 inCount); /* Fr.h:110 */
+void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame);                         /* Fr.h:121  (GPU Haar) */
+size_t LBAudioDetectiveFrameFingerprintSize(LBAudioDetectiveFrameRef inFrame);                 /* Fr.h:131 */
+UInt32 LBAudioDetectiveFrameFingerprintLength(LBAudioDetectiveFrameRef inFrame);               /* Fr.h:141 */
 void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, UInt32 inNumberOfWavelets,
-                                             Boolean* outFingerprint);                         /* Fr.h:150 (GPU rank) */
+                                             Boolean* outFingerprint);                         /* Fr.h:151 (GPU rank) */
 Boolean LBAudioDetectiveFrameEqualToFrame(LBAudioDetectiveFrameRef inFrame1, LBAudioDetectiveFrameRef inFrame2); /* Fr.h:162 */
 
 /* ======================================================================================
@@ -254,6 +254,11 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective,
  * register-resident 1024- / 2048-point FFT for any band table; register Haar/select for 128 x 32 frames);
  * 2 returns ArgumentInvalid when the configuration has no specialised stage-1 kernel. */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
+/* Measurement knobs of the generic stage-1 kernel (the LDS-tile sizing sweep of tools/sweep_lds_tiles.py):
+ * waves per workgroup (0 = automatic; a value the configuration cannot hold falls back to automatic) and
+ * whether the shared per-lane twiddle cache is used (default 1).  Results never depend on them. */
+OSStatus LBAudioDetectiveSetKernelTuning(LBAudioDetectiveRef inDetective, UInt32 inWavesPerWorkgroup,
+                                         UInt32 inTwiddleCache);
 /* HBM the frame-row buffer between the two kernels may take (default 16 GiB; 16 KiB per frame at 32
  * bands).  Batches that need more are processed in several launches. */
 OSStatus LBAudioDetectiveSetScratchLimit(LBAudioDetectiveRef inDetective, UInt64 inBytes);

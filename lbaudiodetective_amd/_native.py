@@ -93,6 +93,7 @@ _SIGNATURES = {
     "LBAudioDetectiveFrameEqualToFrame": (Boolean, [Ref, Ref]),
     # ---- additions ----
     "LBAudioDetectiveSetFileHopMode": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveSetKernelTuning": (OSStatus, [Ref, UInt32, UInt32]),
     "LBAudioDetectiveSetFileTailMode": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveSetResamplerMode": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveReadAudioURLWithResampler": (OSStatus, [C.c_char_p, Float64, UInt32, _P(_P(Float32)), _P(UInt64),

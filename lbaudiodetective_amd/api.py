@@ -287,6 +287,11 @@ class Detective:
     def subfingerprint_count(self, n_samples: int) -> int:
         return int(self._L.LBAudioDetectiveGetSubfingerprintCount(self._ref, n_samples))
 
+    def set_kernel_tuning(self, waves_per_workgroup: int = 0, twiddle_cache: bool = True):
+        """Measurement knobs of the generic stage-1 kernel (tools/sweep_lds_tiles.py)."""
+        _check(self._L.LBAudioDetectiveSetKernelTuning(self._ref, waves_per_workgroup, int(twiddle_cache)), "SetKernelTuning")
+        return self
+
     def set_file_hop_mode(self, mode: int):
         """1 (default): upstream's file-frame hop; 0: hop in processing-rate samples."""
         _check(self._L.LBAudioDetectiveSetFileHopMode(self._ref, mode), "SetFileHopMode")

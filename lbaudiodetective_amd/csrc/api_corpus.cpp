@@ -3,6 +3,7 @@
 // against N candidates, strict '<', first maximum wins) to an HBM-resident database.
 #include "internal.hpp"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace lbad {
@@ -236,21 +237,41 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 
     if (!f) return NULL;
     CorpusFileHeader h;
     LBAudioDetectiveCorpusRef c = NULL;
-    if (std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "LBADCRP1", 8) == 0 &&
-        h.n_planes == lbad::planes_per_entry(h.subfp_len, h.n_sub)) {
+    // the header is untrusted: the shape must be one the device path supports and the file must really hold
+    // count * n_planes planes before anything is allocated from it
+    std::fseek(f, 0, SEEK_END);
+    const long file_size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    bool ok = file_size >= (long)sizeof(h) && std::fread(&h, sizeof(h), 1, f) == 1 &&
+              std::memcmp(h.magic, "LBADCRP1", 8) == 0 && h.subfp_len > 0 &&
+              h.subfp_len <= LBAD_MAX_SUBFINGERPRINT_LENGTH && h.n_sub > 0 &&
+              lbad::planes_supported(h.subfp_len, h.n_sub) && h.n_planes == lbad::planes_per_entry(h.subfp_len, h.n_sub) &&
+              h.count <= 0xFFFFFFFFull &&
+              (uint64_t)(file_size - (long)sizeof(h)) / sizeof(uint4) / (h.n_planes ? h.n_planes : 1) >= h.count;
+    if (ok) {
         const uint64_t cap = inCapacity > h.count ? inCapacity : (h.count ? h.count : 1);
         c = LBAudioDetectiveCorpusNew(h.subfp_len, h.n_sub, cap);
-        std::vector<uint4> host(h.count);
-        for (uint32_t p = 0; c && p < h.n_planes && h.count; ++p) {
-            if (std::fread(host.data(), sizeof(uint4), h.count, f) != h.count ||
-                lbad::hip_status(hipMemcpy(c->d_planes + (size_t)p * c->capacity, host.data(), h.count * sizeof(uint4),
-                                           hipMemcpyHostToDevice), "corpus plane H2D", __LINE__) != noErr) {
-                LBAudioDetectiveCorpusDispose(c);
-                c = NULL;
+    }
+    if (c && h.count) {
+        // staged in bounded pieces, not one count-sized vector
+        const size_t piece = 1u << 20;
+        uint4* host = static_cast<uint4*>(std::malloc(sizeof(uint4) * (h.count < piece ? (size_t)h.count : piece)));
+        if (!host) ok = false;
+        for (uint32_t p = 0; ok && p < h.n_planes; ++p) {
+            for (uint64_t at = 0; ok && at < h.count; at += piece) {
+                const size_t n = (size_t)(h.count - at < piece ? h.count - at : piece);
+                ok = std::fread(host, sizeof(uint4), n, f) == n &&
+                     lbad::hip_status(hipMemcpy(c->d_planes + (size_t)p * c->capacity + at, host, n * sizeof(uint4),
+                                                hipMemcpyHostToDevice), "corpus plane H2D", __LINE__) == noErr;
             }
         }
-        if (c) c->count = h.count;
+        std::free(host);
+        if (!ok) {
+            LBAudioDetectiveCorpusDispose(c);
+            c = NULL;
+        }
     }
+    if (c) c->count = h.count;
     std::fclose(f);
     return c;
 }

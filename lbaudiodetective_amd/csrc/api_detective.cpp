@@ -47,6 +47,8 @@ OSStatus ensure_plan(LBAudioDetective* d) {
         d->subfp_len > kRowsPerFrame * d->bands)
         return kLBAudioDetectiveArgumentInvalid;
     Plan& p = d->plan;
+    p.tune_waves = d->tune_waves;
+    p.tune_cache = d->tune_cache;
     if (p.valid && p.sample_rate == rate && p.window == d->window && p.bands == d->bands && p.subfp_len == d->subfp_len) {
         if (p.stride == d->stride) return noErr;
         p.stride = d->stride;          // the tables do not depend on the hop; the kernel choice does
@@ -58,6 +60,8 @@ OSStatus ensure_plan(LBAudioDetective* d) {
     }
     if (!device_ready()) return kLBAudioDetectiveDeviceUnavailable;
     free_plan(p);
+    p.tune_waves = d->tune_waves;
+    p.tune_cache = d->tune_cache;
     p.sample_rate = rate;
     p.window = d->window;
     p.stride = d->stride;
@@ -350,6 +354,13 @@ OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef d, UInt32 inAnaly
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef d, UInt32 inVariant) {
     if (inVariant > 2) return kLBAudioDetectiveArgumentInvalid;
     d->variant = inVariant;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveSetKernelTuning(LBAudioDetectiveRef d, UInt32 inWavesPerWorkgroup, UInt32 inTwiddleCache) {
+    if (!d || inWavesPerWorkgroup > 16) return kLBAudioDetectiveArgumentInvalid;
+    d->tune_waves = inWavesPerWorkgroup;
+    d->tune_cache = inTwiddleCache != 0;
     return noErr;
 }
 

@@ -2,6 +2,8 @@
 // Mirrors the behaviour of LBAudioDetective/LBAudioDetectiveFingerprint.m; line cites refer to it.
 #include "internal.hpp"
 
+#include <mutex>
+
 #include <cmath>
 #include <cstring>
 
@@ -138,35 +140,70 @@ void pack_fingerprint(const LBAudioDetectiveFingerprint* fp, std::vector<uint32_
                                            out.data() + (size_t)s * kPackedWords);
 }
 
-// One-off compare of two slot-packed fingerprints on the GPU (fp1 = "query", fp2 = one entry).
+// One-off compare of two slot-packed fingerprints on the GPU.  The device buffer, the pinned result word and
+// the stream belong to the process (one set per device, created on first use, only growing): a caller that
+// compares many fingerprint pairs pays two small copies and one launch per call, no allocation.
+namespace {
+struct PairContext {
+    std::mutex lock;
+    uint32_t* d_words = nullptr;
+    size_t cap_words = 0;
+    unsigned int* d_bits = nullptr;
+    unsigned int* h_bits = nullptr;     // pinned
+    uint32_t* h_words = nullptr;        // pinned staging for small fingerprints
+    size_t h_cap_words = 0;
+    hipStream_t stream = nullptr;
+};
+PairContext g_pair[kMaxDevices];
+constexpr size_t kPairPinnedWords = 1u << 20;   // 4 MiB
+}  // namespace
+
 OSStatus compare_slots_once(const std::vector<uint32_t>& fp1, uint32_t n1, const std::vector<uint32_t>& fp2,
                             uint32_t n2, uint32_t length, uint32_t range, float* out) {
     if (!device_ready()) return kLBAudioDetectiveDeviceUnavailable;
-    uint32_t* d = nullptr;
-    const size_t w1 = fp1.size(), w2 = fp2.size();
-    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d), (w1 + w2) * sizeof(uint32_t)));
-    OSStatus st = noErr;
-    auto fail = [&](hipError_t e, const char* what, int line) {
-        st = hip_status(e, what, line);
-        return st != noErr;
-    };
-    uint32_t* d_q = d;
-    uint32_t* d_e = d + w1;
-    unsigned long long* d_key = nullptr;  // [key (8 bytes)][score (4 bytes)]
-    float* d_score = nullptr;
-    if (fail(hipMalloc(reinterpret_cast<void**>(&d_key), 16), "hipMalloc", __LINE__)) { (void)hipFree(d); return st; }
-    d_score = reinterpret_cast<float*>(d_key + 1);
-    do {
-        if (fail(hipMemcpy(d_q, fp1.data(), w1 * 4, hipMemcpyHostToDevice), "copy fp1", __LINE__)) break;
-        if (fail(hipMemcpy(d_e, fp2.data(), w2 * 4, hipMemcpyHostToDevice), "copy fp2", __LINE__)) break;
-        if (fail(hipMemset(d_key, 0, 16), "memset", __LINE__)) break;
-        if (fail(launch_compare_slots(d_e, 1, n2, length, d_q, n1, range, 0, d_score, d_key, nullptr),
-                 "compare kernel", __LINE__)) break;
-        if (fail(hipMemcpy(out, d_score, 4, hipMemcpyDeviceToHost), "copy score", __LINE__)) break;
-    } while (0);
-    (void)hipFree(d_key);
-    (void)hipFree(d);
-    return st;
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) return kLBAudioDetectiveDeviceUnavailable;
+    PairContext& c = g_pair[dev];
+    std::lock_guard<std::mutex> guard(c.lock);
+    if (!c.stream) {
+        LBAD_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_bits), sizeof(unsigned int)));
+        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.h_bits), sizeof(unsigned int), hipHostMallocDefault));
+    }
+    // Fp.m:123-131 -- the side with more sub-fingerprints is "1" (its non-zero pairs count as possible hits)
+    const bool swap = n1 < n2;
+    const std::vector<uint32_t>& a = swap ? fp2 : fp1;
+    const std::vector<uint32_t>& b = swap ? fp1 : fp2;
+    const uint32_t na = swap ? n2 : n1, nb = swap ? n1 : n2;
+    const size_t words = a.size() + b.size();
+    if (c.cap_words < words) {
+        if (c.d_words) (void)hipFree(c.d_words);
+        c.d_words = nullptr;
+        c.cap_words = 0;
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c.d_words), (words + words / 2) * sizeof(uint32_t)));
+        c.cap_words = words + words / 2;
+    }
+    if (words <= kPairPinnedWords && c.h_cap_words < words) {
+        if (c.h_words) (void)hipHostFree(c.h_words);
+        c.h_words = nullptr;
+        c.h_cap_words = 0;
+        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c.h_words), (words + words / 2) * sizeof(uint32_t), hipHostMallocDefault));
+        c.h_cap_words = words + words / 2;
+    }
+    if (words <= kPairPinnedWords) {
+        std::memcpy(c.h_words, a.data(), a.size() * 4);
+        std::memcpy(c.h_words + a.size(), b.data(), b.size() * 4);
+        LBAD_HIP(hipMemcpyAsync(c.d_words, c.h_words, words * 4, hipMemcpyHostToDevice, c.stream));
+    } else {
+        LBAD_HIP(hipMemcpyAsync(c.d_words, a.data(), a.size() * 4, hipMemcpyHostToDevice, c.stream));
+        LBAD_HIP(hipMemcpyAsync(c.d_words + a.size(), b.data(), b.size() * 4, hipMemcpyHostToDevice, c.stream));
+    }
+    LBAD_HIP(hipMemsetAsync(c.d_bits, 0, sizeof(unsigned int), c.stream));
+    LBAD_HIP(launch_compare_pair(c.d_words, na, c.d_words + a.size(), nb, length, range, c.d_bits, c.stream));
+    LBAD_HIP(hipMemcpyAsync(c.h_bits, c.d_bits, sizeof(unsigned int), hipMemcpyDeviceToHost, c.stream));
+    LBAD_HIP(hipStreamSynchronize(c.stream));
+    std::memcpy(out, c.h_bits, sizeof(float));
+    return noErr;
 }
 
 }  // namespace lbad
@@ -182,7 +219,6 @@ Float32 LBAudioDetectiveFingerprintCompareToFingerprint(LBAudioDetectiveFingerpr
     // ((a < b) ? b : a) never selects: the result stays 0.
     if (a->count == 0 || b->count == 0) return 0.0f;
     if (a->length != b->length || a->length == 0 || a->length > LBAD_MAX_SUBFINGERPRINT_LENGTH) return NAN;
-    if ((size_t)a->count * lbad::kPackedWords * 4 > 48 * 1024) return NAN;  // query must fit LDS
     std::vector<uint32_t> pa, pb;
     lbad::pack_fingerprint(a, pa);
     lbad::pack_fingerprint(b, pb);

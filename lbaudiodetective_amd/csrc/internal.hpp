@@ -25,6 +25,22 @@ OSStatus hip_status(hipError_t e, const char* what, int line);
     } while (0)
 
 bool device_ready();
+// Per-device facts and one-time set-up, keyed by the CURRENT device (a process may use several).
+constexpr int kMaxDevices = 64;
+int current_device();                       // hipGetDevice, -1 on failure
+int device_cu_count();                      // CUs of the current device (256 when the query fails)
+// One slot per device: returns true when `value` differs from what was recorded for the current device
+// (and records it) -- "has this function's attribute / table been set up on this device for this size?"
+struct PerDevice {
+    size_t seen[kMaxDevices] = {};
+    bool changed(size_t value) {
+        const int d = current_device();
+        if (d < 0 || d >= kMaxDevices) return true;
+        if (seen[d] == value) return false;
+        seen[d] = value;
+        return true;
+    }
+};
 
 // ---- per-configuration device plan ---------------------------------------------------------
 struct BandTable {
@@ -55,6 +71,10 @@ struct Plan {
     bool pruned_ok = false;
     bool full_ok = false;         // k_rows_full.hip applies
     uint32_t* d_claim = nullptr;  // its per-XCD claim counters (8 words)
+    // measurement knobs of the generic stage-1 kernel (LBAudioDetectiveSetKernelTuning): waves per workgroup
+    // (0 = automatic) and whether the per-lane twiddle cache is used
+    uint32_t tune_waves = 0;
+    bool tune_cache = true;
     bool valid = false;
 };
 
@@ -98,6 +118,10 @@ hipError_t launch_extract_generic(const float* d_m, uint32_t n, uint32_t n_wavel
 hipError_t launch_compare_slots(const uint32_t* d_entries, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
                                 const uint32_t* d_query, uint32_t n_query, uint32_t range, uint64_t index_base,
                                 float* d_scores, unsigned long long* d_key, hipStream_t stream);
+// one fingerprint against one (slot layout, a = the side with at least as many sub-fingerprints): the score's
+// float bits are atomicMax-ed into *d_out_bits (zeroed by the caller)
+hipError_t launch_compare_pair(const uint32_t* d_a, uint32_t n1, const uint32_t* d_b, uint32_t n2, uint32_t subfp_len,
+                               uint32_t range, unsigned int* d_out_bits, hipStream_t stream);
 // plane layout (tight bitstream, 16-byte planes); supported shapes only
 bool planes_supported(uint32_t subfp_len, uint32_t n_sub);
 uint32_t planes_per_entry(uint32_t subfp_len, uint32_t n_sub);
@@ -149,6 +173,8 @@ struct LBAudioDetective {
     uint32_t stride;
     uint32_t bands;
     uint32_t variant = 0;
+    uint32_t tune_waves = 0;  // copied into the plan
+    bool tune_cache = true;
     uint32_t hop_mode = 1;   // file entry points: 0 = hop in processing-rate samples, 1 = upstream's file-frame hop
     uint32_t tail_mode = 1;  // hop mode 1, windows past the end of the file: 0 zero-filled, 1 nothing read, 2 stale spectrum
     uint32_t resampler = 0;  // 0 long Kaiser sinc, 1 short sinc, 2 linear interpolation

@@ -114,6 +114,44 @@ __device__ __forceinline__ float sub_ratio(const SubWords& a, const SubWords& b,
     return possible ? __fdiv_rn((float)hits, (float)possible) : 0.0f;
 }
 
+// One fingerprint against one fingerprint (LBAudioDetectiveFingerprintCompareToFingerprint, Fp.m:119-149), both
+// in the slot layout and in global memory, any lengths: one thread per sliding offset walks the shorter side in
+// sub-fingerprint order (the float32 sum of Fp.m:139-142 is sequential by definition, the offsets are not),
+// the running MAX of Fp.m:144 becomes a block maximum and one atomicMax on the score's bit pattern (scores are
+// >= 0, so their bits order like the values).  `a` is the side with at least as many sub-fingerprints.
+__global__ __launch_bounds__(kThreads) void compare_pair_kernel(const uint32_t* __restrict__ a, uint32_t n1,
+                                                                const uint32_t* __restrict__ b, uint32_t n2,
+                                                                uint32_t pairs, unsigned int* __restrict__ out_bits) {
+    __shared__ uint32_t s_mask[kPackedWords];
+    __shared__ unsigned int s_best[kThreads / 64];
+    if (threadIdx.x < kPackedWords) s_mask[threadIdx.x] = range_mask(threadIdx.x, pairs);
+    __syncthreads();
+    const uint32_t offsets = n1 - n2 + 1;
+    unsigned int best = 0u;
+    for (uint32_t o = blockIdx.x * kThreads + threadIdx.x; o < offsets; o += gridDim.x * kThreads) {
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < n2; ++i) {
+            const SubWords x = load_sub<false>(a, 0, 0, n1, i + o, 0);
+            const SubWords y = load_sub<false>(b, 0, 0, n2, i, 0);
+            sum = __fadd_rn(sum, sub_ratio(x, y, s_mask));
+        }
+        const unsigned int bits = __float_as_uint(__fdiv_rn(sum, (float)n2));
+        best = bits > best ? bits : best;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned int v = __shfl_xor(best, off, 64);
+        best = v > best ? v : best;
+    }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int m = s_best[0];
+        for (int i = 1; i < kThreads / 64; ++i) m = s_best[i] > m ? s_best[i] : m;
+        if (m) atomicMax(out_bits, m);
+    }
+}
+
 template <bool PLANES>
 __global__ __launch_bounds__(kThreads) void compare_generic_kernel(
     const uint32_t* __restrict__ entries, uint64_t stride, uint64_t n_entries, uint32_t n_sub, uint32_t lp,
@@ -478,6 +516,18 @@ hipError_t launch_compare_planes_batch(const uint4* d_planes, uint64_t plane_str
         case 8: return launch_batch_n<8>(d_planes, plane_stride, n_entries, d_qblocks, n_queries, index_base, d_keys, stream);
         default: return hipErrorNotSupported;
     }
+}
+
+hipError_t launch_compare_pair(const uint32_t* d_a, uint32_t n1, const uint32_t* d_b, uint32_t n2, uint32_t subfp_len,
+                               uint32_t range, unsigned int* d_out_bits, hipStream_t stream) {
+    if (n1 < n2 || n2 == 0) return hipErrorInvalidValue;
+    const uint32_t lim = range < subfp_len ? range : subfp_len;   // Fp.m:155
+    const uint32_t pairs = (lim + 1) / 2;
+    const uint32_t offsets = n1 - n2 + 1;
+    uint32_t grid = (offsets + kThreads - 1) / kThreads;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(compare_pair_kernel, dim3(grid), dim3(kThreads), 0, stream, d_a, n1, d_b, n2, pairs, d_out_bits);
+    return hipGetLastError();
 }
 
 }  // namespace lbad

@@ -382,22 +382,22 @@ hipError_t launch_variant(const Plan& plan, const void* d_pcm, uint32_t fmt, uin
     const uint64_t n_windows = n_clips * windows_per_clip;
     if (n_windows == 0) return hipSuccess;
     auto kern = fft_bands_kernel<LOG2W, WPB, CACHED>;
-    static int resident = 0;
-    static size_t resident_lds = 0;
-    if (!resident || resident_lds != lds) {
-        resident_lds = lds;
+    static PerDevice attr;
+    static int resident_on[kMaxDevices] = {};
+    const int dev = current_device();
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    if (attr.changed(lds + 1)) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WPB * 64, lds) != hipSuccess || per_cu < 1)
             per_cu = 1;
-        resident = cus * per_cu;
+        resident_on[dev] = device_cu_count() * per_cu;
     }
+    const int resident = resident_on[dev];
     const uint64_t blocks_needed = (n_windows + WPB - 1) / WPB;
     const uint32_t grid = (uint32_t)(blocks_needed < (uint64_t)resident ? blocks_needed : (uint64_t)resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WPB * 64), lds, stream, d_pcm, fmt, samples_per_clip, plan.stride,
@@ -406,17 +406,12 @@ hipError_t launch_variant(const Plan& plan, const void* d_pcm, uint32_t fmt, uin
     return hipGetLastError();
 }
 
-inline int env_int(const char* name, int fallback) {
-    const char* v = std::getenv(name);
-    return v && *v ? std::atoi(v) : fallback;
-}
-
 // Waves per workgroup.  The per-lane twiddle cache is shared by the workgroup, every wave adds its own
 // points and power terms, and waves never wait for each other, so the best shape is the largest
 // workgroup that still fits one CU's 160 KB (one workgroup per CU, its waves spread over the SIMDs):
-// W = 2048 -> 12 waves (3 per SIMD), W = 4096 -> 6.  Smaller windows keep 4 waves and several
-// workgroups per CU.  LBAD_FFT_WPB / LBAD_FFT_NOCACHE override the choice for the LDS-tile sweep of
-// BASELINE configs[4] (tools/sweep_lds_tiles.py).
+// W = 2048 -> 12 waves (3 per SIMD), W = 4096 -> 7.  Smaller windows keep 4 waves and several
+// workgroups per CU.  plan.tune_waves / tune_cache (LBAudioDetectiveSetKernelTuning) override the choice for
+// the LDS-tile sweep of BASELINE configs[4] (tools/sweep_lds_tiles.py).
 template <int LOG2W, int WPB>
 bool fits(const Plan& plan, bool cached) {
     const size_t cache_bytes = cached ? (size_t)Passes<LOG2W>::cache_slots * sizeof(float2) : 0;
@@ -427,8 +422,8 @@ bool fits(const Plan& plan, bool cached) {
 template <int LOG2W>
 hipError_t launch_one(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
                       uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
-    const int want = env_int("LBAD_FFT_WPB", 0);
-    const bool cached = env_int("LBAD_FFT_NOCACHE", 0) == 0;
+    const int want = (int)plan.tune_waves;
+    const bool cached = plan.tune_cache;
 #define LBAD_TRY(w)                                                                                              \
     if ((want == 0 || want == w) && fits<LOG2W, w>(plan, cached)) {                                             \
         if (cached) return launch_variant<LOG2W, w, true>(plan, d_pcm, fmt, n_clips, samples_per_clip, frames_per_clip, d_frames, stream); \

@@ -182,12 +182,12 @@ hipError_t launch_extract_generic(const float* d_m, uint32_t n, uint32_t n_wavel
 }
 
 static hipError_t ensure_sine() {
-    static bool done = false;
-    if (done) return hipSuccess;
+    static PerDevice done;            // __constant__ memory is per device
+    if (!done.changed(1)) return hipSuccess;
     int16_t t[1024];
     sine_table(t);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_sine), t, sizeof(t));
-    if (e == hipSuccess) done = true;
+    if (e != hipSuccess) done.changed(0);
     return e;
 }
 

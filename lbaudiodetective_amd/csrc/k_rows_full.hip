@@ -417,24 +417,17 @@ hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frame
                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     using S = Shape<LOG2L>;
     const size_t lds = lds_bytes<LOG2L>(plan.table.kmin, plan.table.kmax);
-    static size_t attr_lds = 0;
-    if (attr_lds != lds) {
+    static PerDevice attr;
+    if (attr.changed(lds)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_lds = lds;
     }
     // work is claimed by frames: every XCD's range is a whole number of frames
     constexpr uint64_t U = 128 / S::UW;
     const uint64_t n_units = n_frames * U, units_per_xcd = U * ((n_frames + 7) / 8);
     if (units_per_xcd * 8 > 0x7fffffffull) return hipErrorInvalidValue;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = device_cu_count();
     uint64_t wg_per_xcd = ((uint64_t)n_cu * 2 + 7) / 8;          // two persistent workgroups per CU
     if (wg_per_xcd > units_per_xcd / U) wg_per_xcd = units_per_xcd / U;
     hipError_t e = hipMemsetAsync(plan.d_claim, 0, 8 * sizeof(uint32_t), stream);

@@ -424,22 +424,15 @@ template <int FMT>
 static hipError_t launch_rows_fmt(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint64_t n_frames,
                                   uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
                                   hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDevice attr;
+    if (attr.changed(kLdsBytes)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_rows_pruned_kernel<FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     // work is claimed by frames: every XCD's range is a whole number of frames
     const uint64_t n_units = n_frames * 4, units_per_xcd = 4 * ((n_frames + 7) / 8);
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipGetLastError();
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = device_cu_count();
     // every CU holds kWgPerCu persistent workgroups; a multiple of 8 so that each XCD gets the same number
     uint64_t wg_per_xcd = ((uint64_t)n_cu * kWgPerCu + 7) / 8;
     if (wg_per_xcd > units_per_xcd / 4) wg_per_xcd = units_per_xcd / 4;

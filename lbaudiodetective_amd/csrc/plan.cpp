@@ -19,6 +19,22 @@ bool device_ready() {
     return hipGetDeviceCount(&n) == hipSuccess && n > 0;
 }
 
+int current_device() {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
+int device_cu_count() {
+    static int cus[kMaxDevices] = {};
+    const int d = current_device();
+    if (d < 0 || d >= kMaxDevices) return 256;
+    if (cus[d] == 0) {
+        int n = 0;
+        cus[d] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0 ? n : 256;
+    }
+    return cus[d];
+}
+
 namespace {
 // (UInt32) of a Float64: values below zero give 0 (the reference's ARM targets saturate; see
 // SURVEY.md Q4 -- negative fractions occur for the first bands at 44.1 kHz / 1024).

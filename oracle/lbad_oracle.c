@@ -465,6 +465,45 @@ uint64_t lbo_fingerprint_file_loop(const float* client, uint64_t n_client, uint6
     return count;
 }
 
+/* Stage splits used by tools/vdsp_gap_probe.py: the pipeline behind an FFT that is NOT the canonical one
+ * (spectra in the packed layout of lbo_rfft_packed), and the frame stage alone. */
+int lbo_spectra_to_rows(const float* spectra, uint64_t n_windows, const lbo_config* cfg, float* rows) {
+    if (!config_ok(cfg)) return -1;
+    row_ctx rc;
+    if (row_ctx_init(&rc, cfg)) return -1;
+    for (uint64_t w = 0; w < n_windows; ++w)
+        lbo_band_energies(spectra + w * cfg->window, cfg->window, cfg->bands, rc.indices, rc.lo, rc.hi,
+                          rows + w * cfg->bands);
+    row_ctx_free(&rc);
+    return 0;
+}
+
+int lbo_rows_to_subfingerprints(const float* rows, uint64_t n_frames, const lbo_config* cfg, uint8_t* out_bools) {
+    if (!config_ok(cfg)) return -1;
+    const size_t frame_elems = (size_t)LBO_ROWS_PER_FRAME * cfg->bands;
+    float* frame = (float*)malloc(sizeof(float) * frame_elems);
+    uint8_t* pairs = (uint8_t*)malloc((size_t)2 * cfg->subfp_len);
+    for (uint64_t f = 0; f < n_frames; ++f) {
+        memcpy(frame, rows + f * frame_elems, sizeof(float) * frame_elems);
+        lbo_haar_2d(frame, LBO_ROWS_PER_FRAME, cfg->bands);
+        lbo_extract(frame, LBO_ROWS_PER_FRAME, cfg->bands, cfg->subfp_len, pairs);
+        memcpy(out_bools + f * cfg->subfp_len, pairs, cfg->subfp_len);
+    }
+    free(pairs);
+    free(frame);
+    return 0;
+}
+
+int lbo_rfft_packed_batch(const float* x, uint64_t n_windows, uint32_t W, float* out) {
+    fft_plan p;
+    if (plan_init(&p, W)) return -1;
+    float* z = (float*)malloc(sizeof(float) * W);
+    for (uint64_t w = 0; w < n_windows; ++w) rfft_exec(&p, x + w * W, z, z + p.N, out + w * W);
+    free(z);
+    plan_free(&p);
+    return 0;
+}
+
 uint64_t lbo_fingerprint_pcm(const float* pcm, uint64_t n_samples, const lbo_config* cfg,
                              uint8_t* out_bools) {
     return lbo_fingerprint_pcm_taps(pcm, n_samples, cfg, out_bools, NULL, NULL);

@@ -112,6 +112,12 @@ uint64_t lbo_fingerprint_file_loop(const float* client, uint64_t n_client, uint6
                                    uint32_t hop, int tail_mode, const lbo_config* cfg,
                                    uint8_t* out_bools, float* frames_raw, uint32_t* out_n_read);
 
+/* Stage splits (tools/vdsp_gap_probe.py): packed spectra of n_windows windows -> band rows; 128-row frames ->
+ * sub-fingerprints; the canonical FFT over a batch of windows. */
+int lbo_spectra_to_rows(const float* spectra, uint64_t n_windows, const lbo_config* cfg, float* rows);
+int lbo_rows_to_subfingerprints(const float* rows, uint64_t n_frames, const lbo_config* cfg, uint8_t* out_bools);
+int lbo_rfft_packed_batch(const float* x, uint64_t n_windows, uint32_t W, float* out);
+
 /* n_clips equal-length clips, nthreads OpenMP threads (cpu_baseline leg). */
 int lbo_fingerprint_batch(const float* pcm, uint64_t n_clips, uint64_t samples_per_clip,
                           const lbo_config* cfg, uint8_t* out_bools, int nthreads);

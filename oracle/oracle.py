@@ -76,6 +76,9 @@ def lib():
     sig("lbo_fingerprint_pcm_taps", C.c_uint64, [f32p, C.c_uint64, cfgp, u8p, C.c_void_p, C.c_void_p])
     sig("lbo_fingerprint_file_loop", C.c_uint64, [f32p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, cfgp,
                                                    u8p, C.c_void_p, C.c_void_p])
+    sig("lbo_spectra_to_rows", C.c_int, [f32p, C.c_uint64, cfgp, f32p])
+    sig("lbo_rows_to_subfingerprints", C.c_int, [f32p, C.c_uint64, cfgp, u8p])
+    sig("lbo_rfft_packed_batch", C.c_int, [f32p, C.c_uint64, C.c_uint32, f32p])
     sig("lbo_fingerprint_batch", C.c_int, [f32p, C.c_uint64, C.c_uint64, cfgp, u8p, C.c_int])
     sig("lbo_compare_sub", C.c_float, [u8p, u8p, C.c_uint32, C.c_uint32])
     sig("lbo_compare_fp", C.c_float, [u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32])
@@ -192,6 +195,34 @@ def fingerprint_file_loop(client: np.ndarray, file_frames: int, hop: int, cfg: C
     if got == 2**64 - 1:
         raise ValueError("invalid config")
     return (out, raw, n_read) if taps else out
+
+
+def rfft_packed_batch(windows: np.ndarray) -> np.ndarray:
+    """Canonical FFT of every row of a [n, W] float32 array."""
+    windows = np.ascontiguousarray(windows, np.float32)
+    out = np.empty_like(windows)
+    if lib().lbo_rfft_packed_batch(windows.reshape(-1), windows.shape[0], windows.shape[1], out.reshape(-1)) != 0:
+        raise ValueError("window must be a power of two >= 8")
+    return out
+
+
+def spectra_to_rows(spectra: np.ndarray, cfg: Config) -> np.ndarray:
+    """Band rows (LBAudioDetective.m:361-405) of [n, W] packed spectra from any FFT."""
+    spectra = np.ascontiguousarray(spectra, np.float32)
+    rows = np.empty((spectra.shape[0], cfg.bands), np.float32)
+    if lib().lbo_spectra_to_rows(spectra.reshape(-1), spectra.shape[0], C.byref(cfg), rows.reshape(-1)) != 0:
+        raise ValueError("invalid config")
+    return rows
+
+
+def rows_to_subfingerprints(rows: np.ndarray, cfg: Config) -> np.ndarray:
+    """Haar + ranked signs + truncation for [n_frames * 128, bands] rows."""
+    rows = np.ascontiguousarray(rows, np.float32)
+    n = rows.shape[0] // ROWS_PER_FRAME
+    out = np.zeros((n, cfg.subfp_len), np.uint8)
+    if n and lib().lbo_rows_to_subfingerprints(rows.reshape(-1), n, C.byref(cfg), out.reshape(-1)) != 0:
+        raise ValueError("invalid config")
+    return out
 
 
 def fingerprint_batch(pcm: np.ndarray, cfg: Config, nthreads: int = 1) -> np.ndarray:

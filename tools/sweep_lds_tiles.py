@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """BASELINE configs[4]: 48 kHz / 4096-point windows, stereo-summed clips -- LDS-tile sizing sweep of the
-generic stage-1 kernel: waves per workgroup x twiddle cache on/off.  Each point runs in a fresh process
-(the knobs are read when the kernel is first launched).  Prints a markdown table.
+generic stage-1 kernel: waves per workgroup x twiddle cache on/off (LBAudioDetectiveSetKernelTuning).  Each
+point runs in a fresh process so that it can be profiled on its own.  Prints a markdown table.
 
-    python tools/sweep_lds_tiles.py            # the sweep
-    python tools/sweep_lds_tiles.py --one      # one measurement with the current environment (internal)
+    python tools/sweep_lds_tiles.py                       # the sweep
+    python tools/sweep_lds_tiles.py --one WAVES CACHE     # one point (what the rocprofv3 passes run)
 """
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,10 @@ if "--one" in sys.argv:
     import torch
     import lbaudiodetective_amd as lb
     n = 10000
+    i = sys.argv.index("--one")
     det = lb.Detective().configure(sample_rate=48000, window=4096)
+    det.set_kernel_variant(1)                      # the generic kernel is the one being swept
+    det.set_kernel_tuning(int(sys.argv[i + 1]), bool(int(sys.argv[i + 2])))
     clips = lb.synth_clips_device(0x4C424144, 0, n, 48000, 48000, True)
     out = det.fingerprint_clips_device(clips)
     torch.cuda.synchronize()
@@ -34,8 +37,7 @@ NREAD = 384              # bins 3..347 read by the bands, padded to 64
 PER_WAVE = (2 * (2048 + 64) + NREAD) * 4
 for wpb in (1, 2, 4, 6, 7):
     for nocache in (0, 1):
-        env = dict(os.environ, LBAD_FFT_WPB=str(wpb), LBAD_FFT_NOCACHE=str(nocache))
-        out = subprocess.run([sys.executable, __file__, "--one"], env=env, capture_output=True, text=True)
+        out = subprocess.run([sys.executable, __file__, "--one", str(wpb), str(1 - nocache)], capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         r = json.loads(line[-1]) if line else {"stage1_ms": float("nan"), "windows_per_s": 0, "pcm_GBps": 0}
         lds = wpb * PER_WAVE + 2 * NREAD * 4 + (0 if nocache else CACHE)
