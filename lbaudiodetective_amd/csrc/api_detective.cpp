@@ -193,7 +193,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
 // Device buffers, a pinned staging area and a stream live in the detective and only grow, so a
 // caller that fingerprints many short buffers (ProcessPCM, StreamPush, ProcessAudioURL) pays no
 // allocation per call.
-constexpr size_t kPinnedLimit = 64u << 20;   // larger transfers go straight from the caller's memory
+constexpr size_t kPinnedLimit = 512u << 10;  // larger transfers go straight from the caller's memory (measured: staging 1.6 MB costs more than it saves)
 
 static OSStatus grow_device(void** ptr, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return noErr;
