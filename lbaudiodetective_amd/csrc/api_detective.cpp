@@ -35,7 +35,8 @@ static OSStatus plan_kernels(Plan& p) {
         LBAD_HIP(hipMemcpy(p.d_bin_const, bc.data(), bc.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     p.full_ok = rows_full_supported(p);
-    if (p.full_ok && !p.d_claim) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
+    p.stream_ok = rows_stream_supported(p);
+    if ((p.full_ok || p.stream_ok) && !p.d_claim) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
     return noErr;
 }
 
@@ -139,13 +140,15 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     if (per == 0 || n_clips == 0) return noErr;
     if (per > 0xFFFFFFFFull / kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
     // variant 0: specialised kernels when the configuration has them; 1: generic kernels; 2: specialised or error
-    bool special = p.pruned_ok || p.full_ok;
+    const bool stream_ok = p.stream_ok && (spc & 1) == 0;
+    bool special = p.pruned_ok || p.full_ok || stream_ok;
     if (d->variant == 1) special = false;
     if (d->variant == 2 && !special) return kLBAudioDetectiveArgumentInvalid;
     auto stage1 = [&](const void* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
         if (special && p.pruned_ok)
             return launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
-        if (special) return launch_rows_full(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
+        if (special && p.full_ok) return launch_rows_full(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
+        if (special) return launch_rows_stream(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         return launch_fft_bands(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
     };
     const bool special2 = d->variant != 1 && haar_select32_supported(p);

@@ -70,6 +70,7 @@ struct Plan {
     float* d_bin_const = nullptr; // per-bin twiddles of the pruned kernel (only when pruned_ok)
     bool pruned_ok = false;
     bool full_ok = false;         // k_rows_full.hip applies
+    bool stream_ok = false;       // k_rows_stream.hip applies (also uses d_claim)
     uint32_t* d_claim = nullptr;  // its per-XCD claim counters (8 words)
     // measurement knobs of the generic stage-1 kernel (LBAudioDetectiveSetKernelTuning): waves per workgroup
     // (0 = automatic) and whether the per-lane twiddle cache is used
@@ -97,6 +98,12 @@ hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const 
 bool rows_full_supported(const Plan& plan);
 hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
                             uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
+
+// specialised stage 1 for 4096-sample windows (k_rows_stream.hip): a wave walks the windows of a frame and keeps
+// the sub-transforms consecutive windows share.  Needs an even samples_per_clip (aligned sample pairs).
+bool rows_stream_supported(const Plan& plan);
+hipError_t launch_rows_stream(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
+                              uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
 
 // specialised stage 2 (k_haar_select32.hip): 128 x 32 frames, keep <= 128
 bool haar_select32_supported(const Plan& plan);

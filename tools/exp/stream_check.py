@@ -1,0 +1,42 @@
+"""Quick check + timing of the W = 4096 stage-1 kernels (configs[4])."""
+import sys, numpy as np, torch
+import lbaudiodetective_amd as lb
+from oracle import oracle as O
+SEED = 0x4C424144
+cfg = O.Config(48000, 4096)
+n = cfg.window + 64 * (128 * 2 + 17)
+pcm = O.synth_clips(SEED, 100, 3, 48000, n, True)
+det = lb.Detective().configure(sample_rate=48000, window=4096)
+ok = True
+for variant in (2, 1):
+    det.set_kernel_variant(variant)
+    clips = torch.from_numpy(pcm).cuda()
+    bits, raw, haar = det.fingerprint_clips_device(clips, taps=True)
+    torch.cuda.synchronize()
+    raw = raw.cpu().numpy()
+    for c in range(3):
+        obits, oraw, ohaar = O.fingerprint_pcm(pcm[c], cfg, taps=True)
+        same = np.array_equal(raw[c], oraw)
+        if not same:
+            ok = False
+            d = raw[c] != oraw
+            print(f"variant {variant} clip {c}: {d.sum()} of {d.size} row values differ; frames {np.unique(np.nonzero(d)[0])}, "
+                  f"rows {np.unique(np.nonzero(d)[1])[:20]}, bands {np.unique(np.nonzero(d)[2])}")
+            i = tuple(np.argwhere(d)[0])
+            print("   first", i, raw[c][i], oraw[i])
+        else:
+            print(f"variant {variant} clip {c}: rows bit-exact")
+if "--time" in sys.argv:
+    nclips = 10000
+    big = lb.synth_clips_device(SEED, 0, nclips, 48000, 48000, True)
+    for variant in (2, 1):
+        det.set_kernel_variant(variant)
+        out = det.fingerprint_clips_device(big)
+        torch.cuda.synchronize()
+        det.set_stage_timing(True)
+        for _ in range(5):
+            det.fingerprint_clips_device(big, out=out)
+        s1, s2, launches = det.stage_times()
+        det.set_stage_timing(False)
+        print(f"variant {variant}: stage 1 {s1 / launches:.3f} ms, stage 2 {s2 / launches:.3f} ms per {nclips} clips")
+sys.exit(0 if ok else 1)
