@@ -10,8 +10,10 @@
 // transforms 32 new residues instead of 64 and never re-reads old points:
 //
 //   phase 1  lane (n, h), n = lane & 31, h = lane >> 5: 16 points c[g + 64 h + 128 m'] from L2 -> D4 (DIT
-//            stages 1..4 in registers, compile-time twiddles) -> the halves trade D4s (v_permlane32_swap)
-//            and stage 5 leaves D5(g)[16 h + kk] in lane (n, h) -> stage 6 with the D5 of the previous step,
+//            stages 1..4 in registers, compile-time twiddles) -> the halves trade half of their D4s (one
+//            v_permlane32_swap per float, no copies: lane (n, 0) ends up with both inputs of the stage-5
+//            butterflies 0..7, lane (n, 1) with those of 8..15) and stage 5 leaves D5(g)[k], k in
+//            {8 h + j, 16 + 8 h + j}, in lane (n, h) -> stage 6 with the D5 of the previous step,
 //            E(g)[k] = P[k] +- W_64^k Nw[k], written to the wave's LDS transpose (row k, column n).
 //   phase 2  lane = one row k64: the 32-point cross transform over n (DIT stages 7..11, twiddles from a
 //            per-lane LDS table), pruned to the 12 outputs q in {0..5, 26..31} that bins < 384 and their
@@ -40,11 +42,13 @@ constexpr int kTDw = 64 * kRowDw;             // transpose of one window (one wa
 constexpr int kCrossTw = 27;                  // cross-stage twiddles a lane uses: 1 + 2 + 4 + 8 + 12
 constexpr int kQ = 6;                         // low outputs per row: bins a + 64 q < 384
 constexpr int kMaxBin = 64 * kQ;
-constexpr int kPowerDw = kMaxBin + 64;        // power terms of a window + one dummy word per lane
-constexpr int kLdsDw = kWaves * kTDw + 64 * kRowDw + kQ * 64 * 2 + 2 * 32 * 2;
+constexpr int kMaxTerms = 48;                 // bins of the widest band (the band sums are unrolled this far)
+constexpr int kPowerDw = kMaxBin + 64 + kMaxTerms;   // power terms of a window, one dummy word per lane, read overrun of the last band
+constexpr int kP1 = 24;                       // phase-1 twiddles per half: 8 of stage 5, 16 of stage 6
+constexpr int kLdsDw = kWaves * kTDw + 64 * kRowDw + kQ * 64 * 2 + 2 * kP1 * 2;
 constexpr int kLdsBytes = kLdsDw * 4;         // 160 256 B: one workgroup per CU
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-static_assert(kPowerDw <= kTDw, "power terms reuse the transpose area");
+static_assert(2 * kPowerDw <= kTDw, "the power terms of two windows reuse the transpose area");
 
 __device__ __forceinline__ constexpr int brev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
 __device__ __forceinline__ constexpr int brev5(int v) {
@@ -85,17 +89,15 @@ __device__ __forceinline__ cplx load_point(const void* p, int64_t idx) {
 template <int FMT, int T>
 __device__ __forceinline__ void load16(cplx (&x)[16], const void* p, int64_t idx) {
     if constexpr (T < 16) {
+#ifdef LBAD_EXP_NOLOADS
+        x[T] = mk((float)(idx & 1023) * 1e-3f, (float)T);
+#elif defined(LBAD_EXP_HOTLOADS)
+        x[T] = load_point<FMT>(p, (idx & 2047) + 128 * brev4(T));       // every wave re-reads the same 32 KB: L2 / L1 hits
+#else
         x[T] = load_point<FMT>(p, idx + 128 * brev4(T));     // slot T holds point m' = brev4(T)
+#endif
         load16<FMT, T + 1>(x, p, idx);
     }
-}
-
-__device__ __forceinline__ float swap_halves_u(float t, float x, float& v_out) {
-    // v_permlane32_swap vdst = t, src = x: lanes 32..63 of t trade with lanes 0..31 of x.  With t a copy of x
-    // every lane ends up with (t, x) = (the lower lane's value, the upper lane's value).
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t), __float_as_uint(x), false, false);
-    v_out = __uint_as_float(r[1]);
-    return __uint_as_float(r[0]);
 }
 
 __device__ __forceinline__ float dpp_pair_swap(float v) {      // lane l <-> lane l ^ 1
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
                                                                   uint32_t frames_per_clip, uint32_t n_frames,
                                                                   uint32_t frames_per_xcd, const float* __restrict__ tw,
                                                                   const uint32_t* __restrict__ band_tbl, uint32_t nbands,
-                                                                  uint32_t kmin, uint32_t kmax,
+                                                                  uint32_t kmin, uint32_t kmax, uint32_t n_batches,
                                                                   uint32_t* __restrict__ claim_ctr,
                                                                   float* __restrict__ frames) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     float* tbuf = smem + wave * kTDw;                       // this wave's transpose / power terms
     float* ctw = smem + kWaves * kTDw;                      // [lane][27 complex], row pitch kRowDw
     float2* stw = reinterpret_cast<float2*>(ctw + 64 * kRowDw);   // [q][lane]
-    float2* p1tw = stw + kQ * 64;                           // [h][32]: 16 stage-5 (sign folded) + 16 stage-6 twiddles
+    float2* p1tw = stw + kQ * 64;                           // [h][24]: stage 5 W_32^(8 h + j), stage 6 W_64^k(h, kk)
 
     // ---- once per workgroup: tables --------------------------------------------------------------------
     for (int i = threadIdx.x; i < 64 * kCrossTw; i += kThreads) {
@@ -154,18 +156,16 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         const uint32_t k = (uint32_t)(row_of_lane(l) + 64 * q);     // < 2048
         stw[i] = make_float2(tw[k], tw[kN + k]);
     }
-    for (int i = threadIdx.x; i < 64; i += kThreads) {
-        const int h = i >> 5, e = i & 31;
-        float wr, wi;
-        if (e < 16) {                                        // stage 5: W_32^kk, negated for the "-" half
-            wr = tw[e * (kW / 32)];
-            wi = tw[kN + e * (kW / 32)];
-            if (h) { wr = -wr; wi = -wi; }
-        } else {                                             // stage 6: W_64^(16 h + kk)
-            wr = tw[(16 * h + e - 16) * (kW / 64)];
-            wi = tw[kN + (16 * h + e - 16) * (kW / 64)];
+    for (int i = threadIdx.x; i < 2 * kP1; i += kThreads) {
+        const int h = i / kP1, e = i % kP1;
+        uint32_t ti;
+        if (e < 8) {
+            ti = (uint32_t)(8 * h + e) * (kW / 32);         // stage 5: W_32^(8 h + j)
+        } else {
+            const int kk = e - 8;
+            ti = (uint32_t)(8 * h + kk + (kk >= 8 ? 8 : 0)) * (kW / 64);   // stage 6: W_64^k, k = k(h, kk)
         }
-        p1tw[i] = make_float2(wr, wi);
+        p1tw[i] = make_float2(tw[ti], tw[kN + ti]);
     }
     __syncthreads();
 
@@ -173,16 +173,19 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     const int my_row = row_of_lane(lane);
     const bool special = lane < 2;                           // rows 0 and 32 pair with themselves
     const float inv_norm = 1.0f / (float)(kW / 4);
-    const float2* my_p1 = p1tw + 32 * h;
+    const float2* my_p1 = p1tw + kP1 * h;
     float* my_col = tbuf + n * 2;                            // column n of the transpose (row pitch kRowDw)
     const float* my_trow = tbuf + lane * kRowDw;             // the row this lane transforms (stored by destination lane)
     const float* my_ctw = ctw + lane * kRowDw;
-    // destination lane of row k (the inverse of row_of_lane): 0 -> 0, 32 -> 1, k < 32 -> 2 k, else 2 (64 - k) + 1.
-    // Lane (n, h) emits rows 16 h + kk -> lane 32 h + 2 kk, and rows 32 + 16 h + kk -> lane (h ? 33 : 65) - 2 kk
-    // (row 32 itself, h = 0 and kk = 0, -> lane 1).
-    float* col_p = my_col + 32 * h * kRowDw;
-    float* col_m = my_col + (h ? 33 : 65) * kRowDw;
-    float* col_m0 = my_col + (h ? 33 : 1) * kRowDw;
+    // Lane (n, h) holds D5[k] for k = k(h, kk) = 8 h + kk (kk < 8), 8 + 8 h + kk (kk >= 8) and emits rows k and
+    // k + 32.  A row is stored at the slot of the lane that transforms it (the inverse of row_of_lane: 0 -> 0,
+    // 32 -> 1, k < 32 -> 2 k, else 2 (64 - k) + 1), which is affine in kk within each group of eight.
+    // (bases chosen so that every store is base + a non-negative compile-time offset)
+    float* col_p0 = my_col + 16 * h * kRowDw;                //  k      -> lane 16 h + 2 kk               (kk < 8)
+    float* col_p1 = my_col + (16 + 16 * h) * kRowDw;         //  k      -> lane 16 + 16 h + 2 kk          (kk >= 8)
+    float* col_m0 = my_col + ((h ? 49 : 65) - 14) * kRowDw;  //  k + 32 -> lane (h ? 49 : 65) - 2 kk      (kk < 8), + (14 - 2 kk)
+    float* col_m1 = my_col + ((h ? 33 : 49) - 30) * kRowDw;  //  k + 32 -> lane (h ? 33 : 49) - 2 kk      (kk >= 8), + (30 - 2 kk)
+    float* col_m00 = my_col + (h ? 49 : 1) * kRowDw;         //  row 32 (h = 0, kk = 0) -> lane 1
     // which of this lane's six low bins a band reads, and where their power terms go
     uint32_t need = 0;
 #pragma unroll
@@ -190,14 +193,15 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         const uint32_t k = (uint32_t)(my_row + 64 * q);
         if (k >= kmin && k < kmax && k != 0) need |= 1u << q;
     }
-    float* vbuf = tbuf;
+    float* vbuf = tbuf;                                      // power terms: [2 windows][kPowerDw]
     float* dummy = tbuf + kMaxBin + lane;
-    uint32_t b_lo = 0, b_hi = 0;
+    uint32_t b_lo = 0, b_width = 0;                           // band lane & 31 (both halves: two windows per pass)
     float b_div = 1.0f;
-    if ((uint32_t)lane < nbands) {
-        b_lo = band_tbl[lane];
-        b_hi = band_tbl[nbands + lane];
-        b_div = __uint_as_float(band_tbl[2 * nbands + lane]);
+    if ((uint32_t)(lane & 31) < nbands) {
+        b_lo = band_tbl[lane & 31];
+        const uint32_t b_hi = band_tbl[nbands + (lane & 31)];
+        b_width = b_hi > b_lo ? b_hi - b_lo : 0;
+        b_div = __uint_as_float(band_tbl[2 * nbands + (lane & 31)]);
     }
 
     // workgroup b runs on XCD b % 8 (observed; speed only): every XCD owns a contiguous range of frames
@@ -216,19 +220,27 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         cplx x[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] = x_in[t];
+#ifndef LBAD_EXP_NOFFT16
         st16<1, 0>(x);
         st16<2, 0>(x);
         st16<3, 0>(x);
         st16<4, 0>(x);
-        // the halves trade their D4s: u = D4(g) from lane (n, 0), v = D4(g + 64) from lane (n, 1)
+#endif
+        // The halves trade D4s: after swapping x[j] (upper half) with x[8 + j] (lower half) every lane holds in
+        // (x[j], x[8 + j]) = (u, v) = (D4(g), D4(g + 64)) at index 8 h + j, the inputs of stage-5 butterfly 8 h + j.
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            float vx, vy;
-            const float ux = swap_halves_u(x[kk].x, x[kk].x, vx);
-            const float uy = swap_halves_u(x[kk].y, x[kk].y, vy);
-            const cplx u = mk(ux, uy), v = mk(vx, vy);
-            const float2 w = my_p1[kk];                                  // +-W_32^kk
-            out[kk] = madd(u, w.x, w.y, v);
+        for (int j = 0; j < 8; ++j) {
+#ifndef LBAD_EXP_NOSWAP
+            const auto rx = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[j].x), __float_as_uint(x[8 + j].x), false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[j].y), __float_as_uint(x[8 + j].y), false, false);
+            const cplx u = mk(__uint_as_float(rx[0]), __uint_as_float(ry[0]));
+            const cplx v = mk(__uint_as_float(rx[1]), __uint_as_float(ry[1]));
+#else
+            const cplx u = x[j], v = x[8 + j];
+#endif
+            const float2 w = my_p1[j];                                   // W_32^(8 h + j)
+            out[j] = madd(u, w.x, w.y, v);                               // D5[8 h + j]
+            out[8 + j] = msub(u, w.x, w.y, v);                           // D5[8 h + j + 16]
         }
     };
 
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         const uint32_t fi = frame - clip * frames_per_clip;
         // complex point 0 of the frame; lane (n, h) reads points g + 64 h + 128 m'
         const int64_t c0 = (int64_t)(((uint64_t)clip * samples_per_clip + (uint64_t)fi * 128 * kStride) >> 1) + n + 64 * h;
-        float* out_row = frames + (uint64_t)frame * 128 * nbands + lane;
+        float* out_row = frames + (uint64_t)frame * 128 * nbands + n;
 
         cplx xa[16], xb[16], P[16], Nw[16];
         load16<FMT, 0>(xa, pcm, c0);
@@ -247,21 +259,27 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         d5_block(xa, P);
 
         // one window: x holds the points of block `step`, xn receives those of block `step + 1`
-        auto window_step = [&](int step, cplx (&x)[16], cplx (&xn)[16], cplx (&Pp)[16], cplx (&Nn)[16]) {
+        auto window_step = [&](int step, cplx (&x)[16], cplx (&xn)[16], cplx (&Pp)[16], cplx (&Nn)[16], float (&pw_out)[kQ]) {
+            // the points of the next block: issued now, consumed a whole step later (the scheduler must not
+            // sink them towards their use to save registers: that would expose the memory latency)
             if (step < 128) load16<FMT, 0>(xn, pcm, c0 + 32 * (step + 1));
             d5_block(x, Nn);
-            // ---- stage 6 and the transpose: rows k = 16 h + kk and k + 32, column n; a row is stored at
-            //      the slot of the lane that will transform it (col_p / col_m, affine in kk) ------------------
+            // ---- stage 6 and the transpose: rows k(h, kk) and k + 32, column n ------------------------------
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const float2 w = my_p1[16 + kk];                         // W_64^(16 h + kk)
+                const float2 w = my_p1[8 + kk];                          // W_64^k
                 const cplx ep = madd(Pp[kk], w.x, w.y, Nn[kk]);
                 const cplx em = msub(Pp[kk], w.x, w.y, Nn[kk]);
-                *(lds_vf32x2*)(col_p + 2 * kk * kRowDw) = ep;
-                *(lds_vf32x2*)(kk == 0 ? col_m0 : col_m - 2 * kk * kRowDw) = em;
+                *(lds_vf32x2*)((kk < 8 ? col_p0 : col_p1) + 2 * kk * kRowDw) = ep;
+                *(lds_vf32x2*)(kk == 0 ? col_m00 : (kk < 8 ? col_m0 + (14 - 2 * kk) * kRowDw : col_m1 + (30 - 2 * kk) * kRowDw)) = em;
             }
             wave_sync();
 
+#ifdef LBAD_EXP_NOPHASE2
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) pw_out[q] = my_trow[q];
+            return;
+#endif
             // ---- phase 2: this lane's row, bit-reversed column order into the slots ----------------------
             cplx y[32];
 #pragma unroll
@@ -311,62 +329,98 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
                     if (jj >= 2) y[b + jj + 8] = msub(u, w.x, w.y, v);
                 }
             }
-            // cross stage 5, pruned: outputs q in {0..5} ("+") and {26..31} ("-" of pairs 10..15)
-            cplx lo[kQ], hi[kQ];
+            // cross stage 5, pruned: outputs q in {0..5} ("+") and {26..31} ("-" of pairs 10..15).  The high
+            // outputs first: bin k = row + 64 q needs Z[N - k] = output 31 - q of the PARTNER row, which sits in
+            // the neighbouring lane (pair 0: output 31 - q of row 32 itself, output 32 - q of row 0 itself).
+            cplx bsel[kQ];                                               // bsel[q] = Z[N - (row + 64 q)]
+            {
+                cplx hi[kQ];
+#pragma unroll
+                for (int j = 0; j < kQ; ++j) {
+                    const f32x2 wb = *reinterpret_cast<const f32x2*>(my_ctw + 2 * (21 + j));
+                    hi[j] = msub(y[10 + j], wb.x, wb.y, y[26 + j]);      // output 26 + j
+                }
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
+                    const int j = kQ - 1 - q;                            // output 31 - q
+                    cplx b;
+                    b.x = dpp_pair_swap(hi[j].x);
+                    b.y = dpp_pair_swap(hi[j].y);
+                    const cplx own = (lane & 1) ? hi[j] : hi[j + 1 < kQ ? j + 1 : j];   // (bin 0 of row 0 is never read)
+                    bsel[q] = special ? own : b;
+                }
+            }
+            // ---- the low outputs one at a time, each straight into the split pass.  Written on (re, im) pairs
+            //      so that it compiles to packed operations; each half is the oracle's fmaf / mul / add. ------
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 const f32x2 wa = *reinterpret_cast<const f32x2*>(my_ctw + 2 * (15 + q));
-                lo[q] = madd(y[q], wa.x, wa.y, y[q + 16]);
-                const f32x2 wb = *reinterpret_cast<const f32x2*>(my_ctw + 2 * (21 + q));
-                hi[q] = msub(y[10 + q], wb.x, wb.y, y[26 + q]);
-            }
-            // ---- split pass: bin k = row + 64 q needs Z[N - k] = output 31 - q of the partner row (pair 0:
-            //      output 31 - q of row 32 itself, output 32 - q of row 0 itself) --------------------------
-            float pw[kQ];
-#pragma unroll
-            for (int q = 0; q < kQ; ++q) {
-                const int j = kQ - 1 - q;                                // hi[j] = output 26 + j = 31 - q
-                cplx b;
-                b.x = dpp_pair_swap(hi[j].x);
-                b.y = dpp_pair_swap(hi[j].y);
-                const cplx own = (lane & 1) ? hi[j] : hi[j + 1 < kQ ? j + 1 : j];   // (bin 0 of row 0 is never read)
-                if (special) b = own;
-                const cplx a = lo[q];
+                const cplx a = madd(y[q], wa.x, wa.y, y[q + 16]);        // output q
+                const cplx b = bsel[q];
                 const float2 wk = stw[q * 64 + lane];
-                const float sr = a.x + b.x, si = a.y - b.y;
-                const float dr = a.x - b.x, di = a.y + b.y;
-                float re = __fmaf_rn(wk.x, di, __fmaf_rn(wk.y, dr, sr));
-                float im = __fmaf_rn(-wk.x, dr, __fmaf_rn(wk.y, di, si));
+                const cplx bc = mk(b.x, -b.y);                           // conj(b)
+                const cplx sm = a + bc;                                  // (sr, si) = (a.x + b.x, a.y - b.y)
+                const cplx df = a - bc;                                  // (dr, di) = (a.x - b.x, a.y + b.y)
+                // re = fma(wr, di, fma(wi, dr, sr)), im = fma(-wr, dr, fma(wi, di, si))
+                const cplx z = fma2(mk(wk.x, -wk.x), df.yx, fma2(mk(wk.y, wk.y), df, sm));
                 // "if (x > 0) x /= W/4" is min(x * 2^-10, x): one rounding for x > 0, x itself otherwise
-                re = fminf(__fmul_rn(re, inv_norm), re);
-                im = fminf(__fmul_rn(im, inv_norm), im);
-                pw[q] = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+                const cplx zs = z * mk(inv_norm, inv_norm);
+                const cplx zn = mk(fminf(zs.x, z.x), fminf(zs.y, z.y));
+                const cplx sq = zn * zn;
+                const float t = __fadd_rn(sq.x, sq.y);
+                pw_out[q] = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;  // LBAudioDetective.m:398-401, at the source
             }
-            wave_sync();                                                  // every row has been read
+        };
+
+        // Band means (LBAudioDetective.m:379-405) of TWO windows at a time: lanes 0..31 sum the bins of window
+        // w0, lanes 32..63 those of w0 + 1, lane & 31 = band.  The sum is sequential in bin order by
+        // definition; one pass of (load, select, add) instructions serves both windows.
+        auto band_sums = [&](const float (&pw0)[kQ], const float (&pw1)[kQ], int w0) {
+            wave_sync();                                                  // every row of the last window has been read
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
-                float* dst = (need >> q) & 1u ? vbuf + (my_row + 64 * q) : dummy;
-                *dst = pw[q];
+                float* d0 = (need >> q) & 1u ? vbuf + (my_row + 64 * q) : dummy;
+                d0[0] = pw0[q];
+                d0[kPowerDw] = pw1[q];
             }
             wave_sync();
-            // ---- band means in bin order (LBAudioDetective.m:379-405) -------------------------------------
-            float p = 0.0f;
-            for (uint32_t k0 = b_lo; k0 < b_hi; k0 += 8) {
-                float v[8];
+            const float* vb = vbuf + h * kPowerDw + b_lo;
+            float v[kMaxTerms];
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) v[q] = (k0 + q < b_hi) ? vbuf[k0 + q] : 0.0f;
+            for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
+                if (b < n_batches) {                                      // wave-uniform
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) v[q] = (v[q] == v[q] && fabsf(v[q]) != INFINITY) ? v[q] : 0.0f;
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[q]);
+                    for (uint32_t q = 0; q < 8; ++q) v[8 * b + q] = vb[8 * b + q];
+                }
             }
-            if ((uint32_t)lane < nbands) out_row[(uint64_t)(step - 1) * nbands] = __fdiv_rn(p, b_div);
+            float p = 0.0f;
+#pragma unroll
+            for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
+                if (b < n_batches) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, (8 * b + q < b_width) ? v[8 * b + q] : 0.0f);
+                }
+            }
+            if ((uint32_t)n < nbands) out_row[(uint64_t)(w0 + h) * nbands] = __fdiv_rn(p, b_div);
             wave_sync();                                                  // the power terms are consumed
         };
 
-        for (int step = 1; step <= 128; step += 2) {
-            window_step(step, xb, xa, P, Nw);
-            window_step(step + 1, xa, xb, Nw, P);
+        float pwa[kQ], pwb[kQ];
+        // one window per iteration (not unrolled: two steps interleaved by the scheduler need more registers
+        // than a wave has); the hand-over of the 64 + 6 values costs 70 moves per window
+        for (int step = 1; step <= 128; ++step) {
+            window_step(step, xb, xa, P, Nw, pwb);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                xb[t] = xa[t];
+                P[t] = Nw[t];
+            }
+            if ((step & 1) == 0) {
+                band_sums(pwa, pwb, step - 2);
+            } else {
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) pwa[q] = pwb[q];
+            }
         }
         frame = next_frame;
     }
@@ -375,8 +429,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 }  // namespace
 
 bool rows_stream_supported(const Plan& p) {
-    if (p.window != (uint32_t)kW || p.stride != (uint32_t)kStride || p.bands == 0 || p.bands > 64) return false;
+    if (p.window != (uint32_t)kW || p.stride != (uint32_t)kStride || p.bands == 0 || p.bands > 32) return false;
     if (p.table.kmax <= p.table.kmin || p.table.kmin < 1 || p.table.kmax > (uint32_t)kMaxBin) return false;
+    for (uint32_t b = 0; b < p.bands; ++b)
+        if (p.table.hi[b] > p.table.lo[b] && p.table.hi[b] - p.table.lo[b] > (uint32_t)kMaxTerms) return false;
     std::vector<float> re, im;
     make_twiddles(kW, re, im);
     for (int t = 0; t < 32; ++t)
@@ -399,11 +455,15 @@ static hipError_t launch_stream_fmt(const Plan& plan, const void* d_pcm, uint64_
     uint32_t wg_per_xcd = (uint32_t)device_cu_count() / 8;
     while (wg_per_xcd > 1 && (uint64_t)(wg_per_xcd - 1) * kWaves >= frames_per_xcd) --wg_per_xcd;
     (void)waves_per_xcd;
+    uint32_t widest = 0;
+    for (uint32_t b = 0; b < plan.bands; ++b)
+        if (plan.table.hi[b] > plan.table.lo[b] && plan.table.hi[b] - plan.table.lo[b] > widest)
+            widest = plan.table.hi[b] - plan.table.lo[b];
     hipError_t e = hipMemsetAsync(plan.d_claim, 0, 8 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rows_stream_kernel<FMT>, dim3(wg_per_xcd * 8), dim3(kThreads), kLdsBytes, stream, d_pcm,
                        samples_per_clip, frames_per_clip, (uint32_t)n_frames, frames_per_xcd, plan.d_tw, plan.d_bands,
-                       plan.bands, plan.table.kmin, plan.table.kmax, plan.d_claim, d_frames);
+                       plan.bands, plan.table.kmin, plan.table.kmax, (widest + 7) / 8, plan.d_claim, d_frames);
     return hipGetLastError();
 }
 

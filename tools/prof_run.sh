@@ -1,0 +1,21 @@
+#!/bin/bash
+# rocprofv3 passes over one configuration; run ON the GPU box from the repo root:
+#   tools/prof_run.sh <label> <prof_config.py arguments...>
+# kernel-trace/stats pass, then separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ sets), each with
+# --kernel-trace only; summaries land in gpurun_out/prof_<label>/summary.json
+label=$1; shift
+out=$PWD/gpurun_out/prof_$label
+mkdir -p $out
+export PYTHONPATH=$PWD
+repo=$PWD
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 $repo/tools/prof_config.py "$@" > $out/stats.log 2>&1
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 $repo/tools/prof_config.py "$@" > $out/pmc$i.log 2>&1
+done
+cd $repo
+python3 tools/prof_summarize.py $out > $out/summary.json
+cat $out/summary.json | head -80
