@@ -36,6 +36,11 @@ constexpr int kW = 4096;
 constexpr int kN = kW / 2;
 constexpr int kStride = 64;
 constexpr int kWaves = 8;
+#ifndef LBAD_EXP_CHUNK
+#define LBAD_EXP_CHUNK 16
+#endif
+constexpr int kChunk = LBAD_EXP_CHUNK;                    // windows a wave walks before it claims again (see the kernel)
+constexpr int kChunksPerFrame = 128 / kChunk;
 constexpr int kThreads = kWaves * 64;
 constexpr int kRowDw = 68;                    // 32 complex + 16 B: lanes 0..15 of a b128 read hit disjoint banks
 constexpr int kTDw = 64 * kRowDw;             // transpose of one window (one wave)
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     };
 
     // D5 of block `blk` of the frame that starts at complex point `c0`: this lane's half
-    auto d5_block = [&](const cplx (&x_in)[16], cplx (&out)[16]) {
+    auto d5_block = [&](const cplx (&x_in)[16], cplx (&out)[16], const float2 (&wt)[kP1]) {
         cplx x[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] = x_in[t];
@@ -238,36 +243,52 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #else
             const cplx u = x[j], v = x[8 + j];
 #endif
-            const float2 w = my_p1[j];                                   // W_32^(8 h + j)
+            const float2 w = wt[j];                                      // W_32^(8 h + j)
             out[j] = madd(u, w.x, w.y, v);                               // D5[8 h + j]
             out[8 + j] = msub(u, w.x, w.y, v);                           // D5[8 h + j + 16]
         }
     };
 
-    uint32_t frame = claim();
-    while (frame < f_end) {
-        const uint32_t next_frame = claim();                             // in flight for a whole frame
+    // The unit of work is a run of kChunk consecutive windows, claimed in order: the waves of an XCD are at any
+    // time inside a few dozen neighbouring frames, so the 16 KB sliding windows they read overlap and stay in
+    // the XCD's L2 (whole frames per wave put 4 MB of distinct windows against a 4 MB L2: every load missed).
+    // Price: one extra D5 block per run.
+    uint32_t chunk = claim();
+    while (chunk < f_end) {
+        const uint32_t next_chunk = claim();                             // in flight for a whole run
+        const uint32_t frame = chunk / kChunksPerFrame, part = chunk - frame * kChunksPerFrame;
         const uint32_t clip = frame / frames_per_clip;
         const uint32_t fi = frame - clip * frames_per_clip;
-        // complex point 0 of the frame; lane (n, h) reads points g + 64 h + 128 m'
-        const int64_t c0 = (int64_t)(((uint64_t)clip * samples_per_clip + (uint64_t)fi * 128 * kStride) >> 1) + n + 64 * h;
-        float* out_row = frames + (uint64_t)frame * 128 * nbands + n;
+        // complex point 0 of the run; lane (n, h) reads points g + 64 h + 128 m'
+        const int64_t c0 = (int64_t)(((uint64_t)clip * samples_per_clip + (uint64_t)(fi * 128 + part * kChunk) * kStride) >> 1) + n + 64 * h;
+        float* out_row = frames + ((uint64_t)frame * 128 + part * kChunk) * nbands + n;
 
         cplx xa[16], xb[16], P[16], Nw[16];
         load16<FMT, 0>(xa, pcm, c0);
         load16<FMT, 0>(xb, pcm, c0 + 32);
-        d5_block(xa, P);
+        {
+            float2 wt0[kP1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wt0[i] = my_p1[i];
+            d5_block(xa, P, wt0);
+        }
 
         // one window: x holds the points of block `step`, xn receives those of block `step + 1`
         auto window_step = [&](int step, cplx (&x)[16], cplx (&xn)[16], cplx (&Pp)[16], cplx (&Nn)[16], float (&pw_out)[kQ]) {
             // the points of the next block: issued now, consumed a whole step later (the scheduler must not
             // sink them towards their use to save registers: that would expose the memory latency)
-            if (step < 128) load16<FMT, 0>(xn, pcm, c0 + 32 * (step + 1));
-            d5_block(x, Nn);
+            if (step < kChunk) load16<FMT, 0>(xn, pcm, c0 + 32 * (step + 1));
+            // this half's stage-5 / stage-6 twiddles: all reads in flight before the arithmetic starts (left to
+            // itself the scheduler fetches each one right before its butterfly and waits for it, 24 times)
+            float2 wt[kP1];
+#pragma unroll
+            for (int i = 0; i < kP1; ++i) wt[i] = my_p1[i];
+            __builtin_amdgcn_sched_barrier(0);
+            d5_block(x, Nn, wt);
             // ---- stage 6 and the transpose: rows k(h, kk) and k + 32, column n ------------------------------
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
-                const float2 w = my_p1[8 + kk];                          // W_64^k
+                const float2 w = wt[8 + kk];                             // W_64^k
                 const cplx ep = madd(Pp[kk], w.x, w.y, Nn[kk]);
                 const cplx em = msub(Pp[kk], w.x, w.y, Nn[kk]);
                 *(lds_vf32x2*)((kk < 8 ? col_p0 : col_p1) + 2 * kk * kRowDw) = ep;
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         float pwa[kQ], pwb[kQ];
         // one window per iteration (not unrolled: two steps interleaved by the scheduler need more registers
         // than a wave has); the hand-over of the 64 + 6 values costs 70 moves per window
-        for (int step = 1; step <= 128; ++step) {
+        for (int step = 1; step <= kChunk; ++step) {
             window_step(step, xb, xa, P, Nw, pwb);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -422,7 +443,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
                 for (int q = 0; q < kQ; ++q) pwa[q] = pwb[q];
             }
         }
-        frame = next_frame;
+        chunk = next_chunk;
     }
 }
 
@@ -441,15 +462,17 @@ bool rows_stream_supported(const Plan& p) {
 }
 
 template <int FMT>
-static hipError_t launch_stream_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frames, uint64_t samples_per_clip,
+static hipError_t launch_stream_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frames_in, uint64_t samples_per_clip,
                                     uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    uint64_t n_frames = n_frames_in;
     static PerDevice attr;
     if (attr.changed(kLdsBytes)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_stream_kernel<FMT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         if (e != hipSuccess) return e;
     }
-    const uint32_t frames_per_xcd = (uint32_t)((n_frames + 7) / 8);
+    const uint32_t frames_per_xcd = (uint32_t)((n_frames + 7) / 8) * kChunksPerFrame;     // in runs of kChunk windows
+    n_frames *= kChunksPerFrame;
     const uint32_t waves_per_xcd = (uint32_t)device_cu_count() / 8 * kWaves;
     // no more workgroups than an XCD has frames to hand out (a wave that finds no frame exits at once)
     uint32_t wg_per_xcd = (uint32_t)device_cu_count() / 8;
@@ -471,7 +494,7 @@ hipError_t launch_rows_stream(const Plan& plan, const void* d_pcm, uint32_t fmt,
                               uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     const uint64_t n_frames = n_clips * frames_per_clip;
     if (n_frames == 0) return hipSuccess;
-    if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+    if (n_frames * kChunksPerFrame > 0x7fffffffull) return hipErrorInvalidValue;
     switch (fmt) {
         case 0: return launch_stream_fmt<0>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
         case 1: return launch_stream_fmt<1>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
