@@ -626,7 +626,7 @@ def test_corpus_save_load(lb, gpu, oracle, tmp_path):
 # ---------------------------------------------------------------------------------------------
 # integer PCM (conversion fused into the PCM load) and streaming
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["B_44k_1024", "A_default"])
+@pytest.mark.parametrize("name", ["B_44k_1024", "A_default", "C_48k_4096"])
 def test_integer_pcm_matches_float_path(lb, gpu, oracle, name):
     """LBAudioDetectiveConvertToFormat's job (D.m:413-437) done on the device: int16 / int32 clips give
     the bits of the float clips they convert to (sample / 32768, sample / 2^31)."""
@@ -667,6 +667,30 @@ def test_streaming_equals_whole_buffer(lb, gpu, oracle, chunks):
     assert st.fingerprint().equal_to_fingerprint(whole) or (whole.number_of_subfingerprints == 0 and emitted == 0)
     if emitted:
         assert np.array_equal(st.fingerprint().to_bools(), oracle.fingerprint_pcm(pcm, oracle.Config(44100, 1024)))
+
+
+def test_stream_kernel_shapes(lb, gpu, oracle):
+    """k_rows_stream.hip (4096-sample windows): several frames per clip, many clips (every wave walks many runs of
+    16 windows), clip lengths with a ragged tail; an odd clip length cannot be read as aligned sample pairs and
+    goes to the generic kernel (variant 2 refuses it)."""
+    cfg = oracle.Config(48000, 4096)
+    for n_clips, n in ((37, 4096 + 64 * (128 * 3 + 50)), (300, 4096 + 64 * 128), (2, 4096 + 64 * (128 * 9) + 2)):
+        pcm = oracle.synth_clips(SEED, 900, n_clips, 48000, n, True)
+        want = oracle.fingerprint_batch(pcm, cfg, nthreads=8)
+        for variant in (0, 2):
+            assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg, variant=variant), want), (n_clips, n, variant)
+    n = 4096 + 64 * 128 * 2 + 33                                            # odd
+    pcm = oracle.synth_clips(SEED, 950, 3, 48000, n, True)
+    assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg, variant=0), oracle.fingerprint_batch(pcm, cfg))
+    det = lb.Detective().configure(sample_rate=48000, window=4096)
+    det.set_kernel_variant(2)
+    with pytest.raises(lb.LBAudioDetectiveError):
+        det.fingerprint_clips_device(gpu.from_numpy(pcm).cuda())
+    # another band table on 4096-sample windows (44.1 kHz: bins 3..378), still inside the kernel's 384-bin reach
+    cfg2 = oracle.Config(44100, 4096)
+    pcm = oracle.synth_clips(SEED, 960, 5, 44100, 4096 + 64 * 128 * 2)
+    for variant in (0, 1):
+        assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg2, variant=variant), oracle.fingerprint_batch(pcm, cfg2)), variant
 
 
 # ---------------------------------------------------------------------------------------------

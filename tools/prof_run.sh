@@ -11,11 +11,22 @@ repo=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 $repo/tools/prof_config.py "$@" > $out/stats.log 2>&1
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
-           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE"; do
+# PROF_SETS=short: only the HBM-byte and LDS passes (the per-point passes of the LDS-tile sweep)
+if [ "$PROF_SETS" = "short" ]; then
+  sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_LDS")
+else
+  sets=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+        "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE")
+fi
+for set in "${sets[@]}"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 $repo/tools/prof_config.py "$@" > $out/pmc$i.log 2>&1
 done
 cd $repo
 python3 tools/prof_summarize.py $out > $out/summary.json
-cat $out/summary.json | head -80
+python3 - <<PY
+import json
+d=json.load(open('$out/summary.json'))
+for k,v in d['kernels'].items():
+    if 'avg_us' in v and v.get('avg_us',0)>50: print('$label', k, v.get('calls'), v.get('avg_us'), {c: v['counters'][c] for c in ('FETCH_SIZE','WRITE_SIZE','SQ_LDS_BANK_CONFLICT','SQ_LDS_IDX_ACTIVE') if c in v.get('counters',{})})
+PY
