@@ -84,6 +84,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = CPU dry run of launcher + key reduction (needs --clips 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the side measurements of the configs[0] settings and of configs[4]")
     ap.add_argument("--cpu-sample", type=int, default=0, help="clips for the CPU baseline (0 = 4000 per thread)")
     return ap.parse_args(argv)
 
@@ -299,6 +301,40 @@ def run_rank(args) -> int:
                               f"(scalar radix-2 restatement, not vDSP), {threads} OpenMP threads, {dt:.1f} s",
                 }
         del clips, packed
+        # ---- the other processing configurations of BASELINE.json (side measurements, one GPU) ---------------
+        if world == 1 and not args.no_other_configs:
+            from oracle import oracle as O
+            others = {}
+            for key, rate, window, seconds, n_o, stereo in (("configs0_settings", 5512, 2048, 9, 20_000, False),
+                                                            ("configs4", 48000, 4096, 1, 10_000, True)):
+                d2 = lb.Detective().configure(sample_rate=rate, window=window)
+                samples = rate * seconds
+                c2 = lb.synth_clips_device(SEED, 0, n_o, rate, samples, stereo)
+                p2 = d2.fingerprint_clips_device(c2)
+                torch.cuda.synchronize()
+                d2.set_stage_timing(True)
+                for _ in range(3):
+                    d2.fingerprint_clips_device(c2, out=p2)
+                s1, s2, ln = d2.stage_times()
+                d2.set_stage_timing(False)
+                per2 = int(p2.shape[1])
+                ab = algorithmic_bytes_per_clip(samples, window, STRIDE)
+                ms1, ms2 = s1 / ln, s2 / ln
+                want = O.fingerprint_batch(c2[:4].cpu().numpy(), O.Config(rate, window), nthreads=4)
+                got = lb.unpack_packed(p2[:4].cpu().numpy(), 200).reshape(4, per2, 200)
+                others[key] = {
+                    "workload": f"{n_o} clips x {seconds} s @ {rate} Hz{' stereo-summed' if stereo else ''}, {window}-pt FFT, stride 64",
+                    "stage1_ms": round(ms1, 3), "stage2_ms": round(ms2, 3),
+                    "audio_seconds_per_s": round(n_o * seconds / ((ms1 + ms2) * 1e-3), 1),
+                    "clips_per_s": round(n_o / ((ms1 + ms2) * 1e-3), 1),
+                    "stage1_algorithmic_GBps": round(ab * n_o / (ms1 * 1e-3) / 1e9, 2),
+                    "stage1_hbm_frac": round(ab * n_o / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "stage1_fp32_canonical_tflops": round(per2 * 128 * 2.5 * window * (window.bit_length() - 1) * n_o / (ms1 * 1e-3) / 1e12, 2),
+                    "parity": {"clips_checked": 4, "bit_exact": bool(np.array_equal(got, want))},
+                }
+                del c2, p2
+            if rank == 0:
+                result["other_configs"] = others
     else:
         result["config"] = {"workload": "fingerprint leg skipped (--clips 0)", "parallelism": f"x{n_gpus}"}
 
