@@ -407,6 +407,16 @@ def run_rank(args) -> int:
             for _ in range(reps):
                 best = sc.query(fq, key_out=key)                # scan + all-reduce + 8-byte read-back
             lat_ms = (time.perf_counter() - t1) * 1e3 / reps
+            api_lat_ms = None
+            if world == 1:
+                # the host-synchronous drop-in call (LBAudioDetectiveCorpusQuery): one launch, result polled in pinned memory
+                for _ in range(3):
+                    best_api = sc.local.query(fq)
+                t1 = time.perf_counter()
+                for _ in range(reps * 5):
+                    best_api = sc.local.query(fq)
+                api_lat_ms = (time.perf_counter() - t1) * 1e3 / (reps * 5)
+                assert best_api == best, (best_api, best)
             stats = torch.tensor([scan_ms, ar_ms or 0.0, lat_ms], dtype=torch.float64, device=dev)
             if world > 1:
                 dist.all_reduce(stats, op=dist.ReduceOp.MAX)
@@ -420,8 +430,9 @@ def run_rank(args) -> int:
                     "best_index": best[0], "best_score": best[1], "planted_index": planted, "planted_rank": planted_rank,
                     "found_planted": bool(best[0] == planted),
                     "scan_ms": round(scan_ms, 4), "allreduce_ms": (round(ar_max, 4) if world > 1 else None),
-                    "query_latency_ms": round(lat_ms, 4),
-                    "entries_per_s": round(total / (lat_ms * 1e-3), 1),
+                    "query_latency_ms": round(api_lat_ms if api_lat_ms is not None else lat_ms, 4),
+                    "query_latency_sharded_path_ms": round(lat_ms, 4),
+                    "entries_per_s": round(total / ((api_lat_ms if api_lat_ms is not None else lat_ms) * 1e-3), 1),
                     "scan_entries_per_s": round(total / (scan_ms * 1e-3), 1),
                     "achieved_GBps_algorithmic_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9, 2),
                     "hbm_frac_algorithmic_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

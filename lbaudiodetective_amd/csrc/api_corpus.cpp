@@ -49,6 +49,44 @@ OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint*
     return noErr;
 }
 
+// LBAudioDetectiveCorpusQuery on the specialised scan: one launch, the result arrives in pinned memory
+OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range, unsigned long long* key) {
+    if (!c->h_out) {
+        LBAD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_fast_key), (kScanSlots + 1) * sizeof(unsigned long long)));
+        LBAD_HIP(hipMemset(c->d_fast_key, 0, (kScanSlots + 1) * sizeof(unsigned long long)));
+        c->d_ticket = reinterpret_cast<unsigned int*>(c->d_fast_key + kScanSlots);
+        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16, hipHostMallocMapped | hipHostMallocCoherent));
+        c->h_out[0] = c->h_out[1] = 0;
+        LBAD_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_out_dev), c->h_out, 0));
+    }
+    if (range == 0) range = c->subfp_len;
+    std::vector<uint32_t> slots, block;
+    pack_fingerprint(q, slots);
+    build_plane_query(slots.data(), c->n_sub, range, block);
+    const unsigned long long seq = ++c->seq;
+    LBAD_HIP(launch_compare_planes_fast(c->d_planes, c->capacity, c->count, c->n_sub, block.data(), 0, nullptr,
+                                        c->d_fast_key, c->stream, c->d_ticket, c->h_out_dev, seq));
+    volatile unsigned long long* out = c->h_out;
+    for (uint64_t spins = 1; out[1] != seq; ++spins) {
+        if ((spins & 0xFFFFF) == 0) {                       // every million polls: is the stream still alive?
+            const hipError_t e = hipStreamQuery(c->stream);
+            if (e == hipSuccess) {                          // the kernel is done: its words are on their way or lost
+                LBAD_HIP(hipStreamSynchronize(c->stream));
+                if (out[1] != seq) return kLBAudioDetectiveDeviceError;
+            } else if (e != hipErrorNotReady) {
+                return hip_status(e, "corpus query", __LINE__);
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *key = out[0];
+    return noErr;
+}
+
 }  // namespace
 }  // namespace lbad
 
@@ -82,6 +120,10 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (c->d_query) (void)hipFree(c->d_query);
     if (c->h_query) (void)hipHostFree(c->h_query);
     if (c->d_key) (void)hipFree(c->d_key);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_fast_key) (void)hipFree(c->d_fast_key);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -101,6 +143,8 @@ OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef c, c
     if (c->count + inNumberOfEntries > c->capacity) return kLBAudioDetectiveArgumentInvalid;
     LBAD_HIP(lbad::launch_pack_planes(static_cast<const uint32_t*>(inPacked), inNumberOfEntries, c->n_sub, c->subfp_len,
                                       c->d_planes, c->capacity, c->count, static_cast<hipStream_t>(inStream)));
+    c->appended = true;
+    c->append_stream = static_cast<hipStream_t>(inStream);
     c->count += inNumberOfEntries;
     return noErr;
 }
@@ -279,9 +323,20 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 
 OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef inQuery, UInt32 inRange,
                                      SInt64* outIndex, Float32* outScore) {
     if (!c) return kLBAudioDetectiveArgumentInvalid;
+    unsigned long long key = 0;
+    if (inQuery && c->count > 0 && c->variant != 1 && inQuery->length == c->subfp_len &&
+        lbad::planes_fast_supported(c->subfp_len, c->n_sub, inQuery->count)) {
+        if (c->appended) {                                  // order behind appends issued on another stream, once
+            LBAD_HIP(hipStreamSynchronize(c->append_stream));
+            c->appended = false;
+        }
+        OSStatus st = lbad::query_fast(c, inQuery, inRange, &key);
+        if (st != noErr) return st;
+        LBAudioDetectiveCorpusDecodeKey(key, outIndex, outScore);
+        return noErr;
+    }
     OSStatus st = lbad::run_query(c, inQuery, inRange, 0, nullptr, c->d_key, nullptr);
     if (st != noErr) return st;
-    unsigned long long key = 0;
     LBAD_HIP(hipMemcpy(&key, c->d_key, sizeof(key), hipMemcpyDeviceToHost));
     LBAudioDetectiveCorpusDecodeKey(key, outIndex, outScore);
     return noErr;

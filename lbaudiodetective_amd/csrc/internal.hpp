@@ -142,9 +142,14 @@ hipError_t launch_compare_planes_generic(const uint4* d_planes, uint64_t plane_s
 bool planes_fast_supported(uint32_t subfp_len, uint32_t n_sub, uint32_t n_query);
 uint32_t planes_fast_const_words(uint32_t n_sub);
 void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, std::vector<uint32_t>& out);
+// d_ticket / host_out_dev / seq: optional tail for the host-synchronous query: d_key is then an array of
+// kScanSlots per-workgroup slots, the last workgroup reduces them and hands the key to pinned host memory;
+// pass nullptr to get the plain device-key behaviour
+constexpr uint32_t kScanSlots = 512;
 hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
                                       uint32_t n_sub, const uint32_t* d_qc, uint64_t index_base, float* d_scores,
-                                      unsigned long long* d_key, hipStream_t stream);
+                                      unsigned long long* d_key, hipStream_t stream, unsigned int* d_ticket = nullptr,
+                                      unsigned long long* host_out_dev = nullptr, unsigned long long seq = 0);
 uint32_t plane_query_words();
 hipError_t launch_compare_planes_batch(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries, uint32_t n_sub,
                                        const uint32_t* d_qblocks, uint32_t n_queries, uint64_t index_base,
@@ -215,4 +220,13 @@ struct LBAudioDetectiveCorpus {
     uint32_t* h_query = nullptr;  // pinned staging copy of it
     uint32_t query_cap = 0;       // in words
     unsigned long long* d_key = nullptr;
+    // host-synchronous query without memset / copy / stream synchronisation (api_corpus.cpp)
+    unsigned long long* d_fast_key = nullptr;    // zero between queries
+    unsigned int* d_ticket = nullptr;
+    unsigned long long* h_out = nullptr;         // pinned, host-coherent: [0] key, [1] sequence number
+    unsigned long long* h_out_dev = nullptr;     // its device address
+    unsigned long long seq = 0;
+    hipStream_t stream = nullptr;
+    bool appended = false;                       // entries were appended since the last polled query ...
+    hipStream_t append_stream = nullptr;         // ... on this stream
 };

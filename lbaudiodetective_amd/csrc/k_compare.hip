@@ -50,6 +50,65 @@ __device__ __forceinline__ void block_max_key(unsigned long long k, unsigned lon
     }
 }
 
+// Optional tail of a scan for the host-synchronous query.  Every workgroup stores its maximum in its own slot
+// and takes a ticket (one contended atomic per workgroup instead of two: with 2048 workgroups the atomicMax on
+// the single key word and the ticket cost ~25 us each, more than the scan of 1 M entries); the LAST workgroup
+// to arrive reduces the slots, hands the key to the host through a pinned, host-coherent word pair
+// {key, sequence number} and rearms the ticket.  The host polls the sequence number instead of paying a
+// memset, a stream synchronisation and an 8-byte copy.
+struct ScanFinish {
+    unsigned int* ticket;                   // device, zero between queries
+    unsigned long long* block_keys;         // device, one slot per workgroup
+    volatile unsigned long long* host_out;  // pinned host memory mapped into the device: [0] key, [1] sequence
+    unsigned long long seq;
+};
+
+__device__ __forceinline__ unsigned long long block_reduce_max(unsigned long long k) {
+    __shared__ unsigned long long s_m[kThreads / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off, 64);
+        k = o > k ? o : k;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = k;
+    __syncthreads();
+    unsigned long long m = s_m[0];
+#pragma unroll
+    for (int i = 1; i < kThreads / 64; ++i) m = s_m[i] > m ? s_m[i] : m;
+    return m;
+}
+
+__device__ __forceinline__ void block_max_key_finish(unsigned long long k, unsigned long long* out, const ScanFinish fin) {
+    if (fin.ticket == nullptr) {
+        block_max_key(k, out);
+        return;
+    }
+    __shared__ unsigned int s_last;
+    const unsigned long long m = block_reduce_max(k);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&fin.block_keys[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();                                    // the slot before the ticket
+        s_last = atomicAdd(fin.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) {
+        __threadfence();
+        unsigned long long best = 0ull;
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += kThreads) {
+            const unsigned long long v = __hip_atomic_load(&fin.block_keys[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            best = v > best ? v : best;
+        }
+        best = block_reduce_max(best);
+        if (threadIdx.x == 0) {
+            fin.host_out[0] = best;
+            __threadfence_system();
+            fin.host_out[1] = fin.seq;
+            atomicExch(fin.ticket, 0u);
+        }
+    }
+}
+
 // even-position bits of word w (bit positions 32w .. 32w+31 of the sub-fingerprint) that are
 // below 2 * pairs
 __device__ __forceinline__ uint32_t range_mask(uint32_t w, uint32_t pairs) {
@@ -257,7 +316,8 @@ template <int NSUB>
 __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* __restrict__ planes, uint64_t stride,
                                                                   uint64_t n_entries, const PlaneQueryArg qc,
                                                                   uint64_t index_base, float* __restrict__ scores,
-                                                                  unsigned long long* __restrict__ key_out) {
+                                                                  unsigned long long* __restrict__ key_out,
+                                                                  const ScanFinish fin) {
     using S = PlaneShape<NSUB>;
     unsigned long long best = 0ull;
     for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
@@ -292,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* _
         const unsigned long long k = make_key(match, index_base + e);
         best = k > best ? k : best;
     }
-    block_max_key(best, key_out);
+    block_max_key_finish(best, key_out, fin);
 }
 
 // Batch form: up to QB queries share one pass over the corpus (the scan is HBM-bound, so a handful of
@@ -354,19 +414,23 @@ __global__ __launch_bounds__(kThreads) void compare_planes_batch_kernel(const ui
 
 uint32_t grid_for(uint64_t n_entries) {
     const uint64_t blocks = (n_entries + kThreads - 1) / kThreads;
-    const uint64_t cap = 256ull * 8ull;  // 8 workgroups per CU, grid-stride the rest
+    // One or two workgroups per CU, grid-stride the rest.  Every workgroup ends in an atomic on ONE word (the key,
+    // or the ticket of the polled query); at 8 per CU those 2048 atomics took longer than the scan itself
+    // (1 M entries: 36.4 us at 2048 workgroups, 25.9 at 256; 10 M: 228.8 / 215.4 us at 2048 / 512, 257.6 at 256).
+    const uint64_t cap = n_entries <= (1ull << 21) ? 256ull : 512ull;
     return (uint32_t)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
 template <int NSUB>
 hipError_t launch_planes_n(const uint4* d_planes, uint64_t stride, uint64_t n_entries, const uint32_t* h_qc,
-                           uint64_t index_base, float* d_scores, unsigned long long* d_key, hipStream_t stream) {
+                           uint64_t index_base, float* d_scores, unsigned long long* d_key, hipStream_t stream,
+                           const ScanFinish& fin) {
     static_assert(PlaneShape<NSUB>::total <= kPlaneQueryWords, "query block does not fit the kernel argument");
     PlaneQueryArg arg;
     std::memset(&arg, 0, sizeof(arg));
     std::memcpy(arg.w, h_qc, PlaneShape<NSUB>::total * sizeof(uint32_t));
     hipLaunchKernelGGL(compare_planes_kernel<NSUB>, dim3(grid_for(n_entries)), dim3(kThreads), 0, stream, d_planes,
-                       stride, n_entries, arg, index_base, d_scores, d_key);
+                       stride, n_entries, arg, index_base, d_scores, d_key, fin);
     return hipGetLastError();
 }
 
@@ -469,17 +533,23 @@ void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, 
 // h_qc: HOST pointer to the block built by build_plane_query (it is passed as a kernel argument)
 hipError_t launch_compare_planes_fast(const uint4* d_planes, uint64_t plane_stride, uint64_t n_entries,
                                       uint32_t n_sub, const uint32_t* d_qc, uint64_t index_base, float* d_scores,
-                                      unsigned long long* d_key, hipStream_t stream) {
+                                      unsigned long long* d_key, hipStream_t stream, unsigned int* d_ticket,
+                                      unsigned long long* host_out_dev, unsigned long long seq) {
     if (n_entries == 0) return hipSuccess;
+    ScanFinish fin;
+    fin.ticket = d_ticket;
+    fin.block_keys = d_key;                 // polled mode: d_key is the per-workgroup slot array (kScanSlots words)
+    fin.host_out = host_out_dev;
+    fin.seq = seq;
     switch (n_sub) {
-        case 1: return launch_planes_n<1>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 2: return launch_planes_n<2>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 3: return launch_planes_n<3>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 4: return launch_planes_n<4>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 5: return launch_planes_n<5>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 6: return launch_planes_n<6>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 7: return launch_planes_n<7>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
-        case 8: return launch_planes_n<8>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream);
+        case 1: return launch_planes_n<1>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 2: return launch_planes_n<2>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 3: return launch_planes_n<3>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 4: return launch_planes_n<4>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 5: return launch_planes_n<5>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 6: return launch_planes_n<6>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 7: return launch_planes_n<7>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
+        case 8: return launch_planes_n<8>(d_planes, plane_stride, n_entries, d_qc, index_base, d_scores, d_key, stream, fin);
         default: return hipErrorNotSupported;
     }
 }
