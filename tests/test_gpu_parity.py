@@ -897,3 +897,25 @@ def test_compare_long_fingerprints_either_order(lb, gpu, oracle):
             got = np.float32(fx.compare_to_fingerprint(fy, rg))
             assert got.view(np.uint32) == want.view(np.uint32), (x.shape, y.shape, rg, got, want)
     assert A.compare_to_fingerprint(B, 200) > 0.8
+
+
+def test_polled_query_sees_appends_from_other_streams(lb, gpu, oracle):
+    """LBAudioDetectiveCorpusQuery hands its result over through pinned memory on the corpus's own stream; entries
+    appended on another stream just before must take part, and alternating corpora keep their own state."""
+    n = 3000
+    host = oracle.synth_corpus(CSEED, 0, n, 5, 200)
+    packed = lb.synth_corpus_device(CSEED, 0, n, 5, 200)
+    side = gpu.cuda.Stream()
+    a, b = lb.Corpus(200, 5, n), lb.Corpus(200, 5, n)
+    b.append_packed_device(packed[:100])
+    for upto in (500, 1500, n):
+        first = len(a)
+        with gpu.cuda.stream(side):
+            a.append_packed_device(packed[first:upto])
+        for probe in (first, upto - 1, 50):
+            q = lb.Fingerprint.from_bools(host[probe])
+            assert a.query(q) == (probe, 1.0), (upto, probe)                   # exact copy of an entry: found at once
+            want = oracle.corpus_best(host[probe], host[:100], 200)
+            assert b.query(q) == want
+    for _ in range(200):                                                        # many polls in a row: sequence numbers
+        assert a.query(lb.Fingerprint.from_bools(host[7])) == (7, 1.0)
