@@ -117,10 +117,19 @@ def test_batch_bits_bit_exact_44k(lb, gpu, oracle, variant):
     assert np.array_equal(got, want)
 
 
-def test_edge_inputs(lb, gpu, oracle):
-    cfg = oracle.Config(44100, 1024)
-    n = 1024 + 64 * 128
+@pytest.mark.parametrize("name", ["B_44k_1024", "A_default", "C_48k_4096"])
+def test_edge_inputs(lb, gpu, oracle, name):
+    """Degenerate PCM through every stage-1 kernel of the three BASELINE configurations (specialised and
+    generic): ties, overflow, denormals, and non-finite samples (LBAudioDetective.m:398-401 skips NaN / inf terms)."""
+    cfg = oracle.Config(**CONFIGS[name])
+    rate = int(cfg.sample_rate)
+    n = cfg.window + 64 * 128
     rng = np.random.default_rng(1)
+    nan_burst = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    nan_burst[3000:3003] = np.nan
+    one_inf = (rng.standard_normal(n) * 0.1).astype(np.float32)
+    one_inf[5001] = np.inf
+    one_inf[7000] = -np.inf
     cases = {
         "silence": np.zeros(n, np.float32),                                   # every key ties at 0
         "dc": np.full(n, 0.5, np.float32),
@@ -128,13 +137,18 @@ def test_edge_inputs(lb, gpu, oracle):
         "full_scale_square": np.where((np.arange(n) // 50) % 2 == 0, 1.0, -1.0).astype(np.float32),
         "tiny": (rng.standard_normal(n) * 1e-30).astype(np.float32),          # denormal-range energies
         "huge": (rng.standard_normal(n) * 1e18).astype(np.float32),           # energies overflow to inf
-        "sine": np.sin(2 * np.pi * 440 * np.arange(n) / 44100).astype(np.float32),
+        "sine": np.sin(2 * np.pi * 440 * np.arange(n) / rate).astype(np.float32),
+        "nan_burst": nan_burst,
+        "inf_samples": one_inf,
+        "max_float": np.full(n, np.finfo(np.float32).max, np.float32),
     }
     pcm = np.stack(list(cases.values()))
     for variant in (0, 1, 2):
-        got = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant)
-        for i, name in enumerate(cases):
-            assert np.array_equal(got[i], oracle.fingerprint_pcm(pcm[i], cfg)), f"{name} (variant {variant})"
+        got, raw, haar = _fingerprint_device(lb, gpu, pcm, cfg, variant=variant, taps=True)
+        for i, cname in enumerate(cases):
+            obits, oraw, ohaar = oracle.fingerprint_pcm(pcm[i], cfg, taps=True)
+            assert np.array_equal(raw[i], oraw, equal_nan=True), f"{name}/{cname}: band rows (variant {variant})"
+            assert np.array_equal(got[i], obits), f"{name}/{cname} (variant {variant})"
     assert not got[0].any()                                                   # silence -> all "00" pairs
 
 
