@@ -12,13 +12,36 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
 t0 = time.time()
 for t in range(trials):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 9)
     if kind == 1:      # stride 64 with 1024- / 2048-sample windows: the unpruned specialised kernel (k_rows_full.hip)
         cfg = O.Config(float(rng.choice([5512, 8000, 11025, 16000, 22050, 32000, 44100, 48000])), int(rng.choice([1024, 2048])),
                        64, int(rng.integers(1, 65)), 1)
         cfg.subfp_len = int(rng.integers(1, min(256, 128 * cfg.bands) + 1))
         n = cfg.window + 64 * 128 * int(rng.integers(1, 3)) + int(rng.integers(0, 8192))
         clips = int(rng.integers(1, 5))
+    elif kind in (6, 7):   # 4096-sample windows at stride 64: the streaming kernel (k_rows_stream.hip) or its fallbacks
+        cfg = O.Config(float(rng.choice([48000, 44100, 32000, 96000, 22050])), 4096, 64, int(rng.choice([32, 32, 32, 16, 31, 33, 64])), 1)
+        cfg.subfp_len = int(rng.integers(1, min(256, 128 * cfg.bands) + 1))
+        n = 4096 + 64 * 128 * int(rng.integers(1, 4)) + int(rng.integers(0, 8192))      # even and odd lengths
+        clips = int(rng.integers(1, 40))
+    elif kind == 8:      # upstream's file loop with a random end-of-file treatment
+        cfg = O.Config(float(rng.choice([5512, 8000, 11025, 44100])), int(2 ** rng.integers(6, 12)), int(rng.choice([16, 64, 100])),
+                       int(rng.integers(1, 65)), 1)
+        cfg.subfp_len = int(rng.integers(1, min(256, 128 * cfg.bands) + 1))
+        hop = int(rng.integers(1, 70))
+        n_client = int(rng.integers(1, 40000))
+        file_frames = int(rng.integers(cfg.window, cfg.window + cfg.stride * 128 * 4))
+        tail_mode = int(rng.integers(0, 3))
+        x = O.synth_clip(int(rng.integers(0, 2**31)), 5, 44100, n_client)
+        det = lb.Detective().configure(sample_rate=cfg.sample_rate, window=cfg.window, stride=cfg.stride, bands=cfg.bands,
+                                       subfp_len=cfg.subfp_len)
+        det.set_file_tail_mode(tail_mode)
+        got = det.process_file_stream(x, file_frames, hop).to_bools()
+        want = O.fingerprint_file_loop(x, file_frames, hop, cfg, tail_mode)
+        if got.shape != want.shape or not np.array_equal(got, want):
+            bad += 1
+            print("FILE LOOP MISMATCH", t, cfg.sample_rate, cfg.window, cfg.stride, cfg.bands, cfg.subfp_len, hop, n_client, file_frames, tail_mode, flush=True)
+        continue
     elif kind == 0:      # config B shape through the specialised kernels, odd clip counts / lengths / content
         cfg = O.Config(44100, 1024)
         n = 1024 + 64 * 128 * int(rng.integers(1, 4)) + int(rng.integers(0, 8192))
