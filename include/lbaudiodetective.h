@@ -249,10 +249,12 @@ OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef inDetective, const
 OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective, const void* inClips,
                                                 UInt32 inSampleFormat, UInt64 inNumberOfClips,
                                                 UInt64 inSamplesPerClip, Boolean* outBooleans);
-/* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band
- * count), 2 = specialised kernels (stride 64: pruned 1024-point FFT for bands that read only bins 0..21,
- * register-resident 1024- / 2048-point FFT for any band table; register Haar/select for 128 x 32 frames);
- * 2 returns ArgumentInvalid when the configuration has no specialised stage-1 kernel. */
+/* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band count),
+ * 2 = specialised kernels only (stride 64: pruned 1024-point FFT for bands that read only bins 0..21; streaming
+ * 2048- / 4096-point kernels that share the early FFT stages between consecutive windows (even clip lengths,
+ * <= 32 bands); register-resident 1024- / 2048-point FFT for any other band table; register Haar / select for
+ * 128 x 32 frames) -- ArgumentInvalid when the configuration has no specialised stage-1 kernel; 3 = like 2 but
+ * the register-resident 2048-point kernel instead of the streaming one (measurement). */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
 /* Measurement knobs of the generic stage-1 kernel (the LDS-tile sizing sweep of tools/sweep_lds_tiles.py):
  * waves per workgroup (0 = automatic; a value the configuration cannot hold falls back to automatic) and

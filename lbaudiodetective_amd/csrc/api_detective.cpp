@@ -36,7 +36,8 @@ static OSStatus plan_kernels(Plan& p) {
     }
     p.full_ok = rows_full_supported(p);
     p.stream_ok = rows_stream_supported(p);
-    if ((p.full_ok || p.stream_ok) && !p.d_claim) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
+    p.stream2_ok = rows_stream2_supported(p);
+    if ((p.full_ok || p.stream_ok || p.stream2_ok) && !p.d_claim) LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_claim), 8 * sizeof(uint32_t)));
     return noErr;
 }
 
@@ -141,17 +142,22 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     if (per > 0xFFFFFFFFull / kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
     // variant 0: specialised kernels when the configuration has them; 1: generic kernels; 2: specialised or error
     const bool stream_ok = p.stream_ok && (spc & 1) == 0;
-    bool special = p.pruned_ok || p.full_ok || stream_ok;
+    const bool stream2_ok = p.stream2_ok && (spc & 1) == 0 && d->variant != 3;
+    bool special = p.pruned_ok || p.full_ok || stream_ok || stream2_ok;
+    if (d->variant == 3) {                       // measurement: the non-streaming specialised kernel where both exist
+        if (!p.full_ok && !p.pruned_ok) return kLBAudioDetectiveArgumentInvalid;
+    }
     if (d->variant == 1) special = false;
-    if (d->variant == 2 && !special) return kLBAudioDetectiveArgumentInvalid;
+    if (d->variant >= 2 && !special) return kLBAudioDetectiveArgumentInvalid;
     auto stage1 = [&](const void* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
         if (special && p.pruned_ok)
             return launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
+        if (special && stream2_ok) return launch_rows_stream2(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         if (special && p.full_ok) return launch_rows_full(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         if (special) return launch_rows_stream(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         return launch_fft_bands(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
     };
-    const bool special2 = d->variant != 1 && haar_select32_supported(p);
+    const bool special2 = d->variant != 1 && haar_select32_supported(p);   // (variants 2 and 3 use it as well)
     auto stage2 = [&](float* frames_in, uint64_t nf, uint32_t* packed_out, float* haar_out) -> hipError_t {
         return special2 ? launch_haar_select32(p, frames_in, nf, packed_out, haar_out, stream)
                         : launch_haar_select(p, frames_in, nf, packed_out, haar_out, stream);
@@ -355,7 +361,7 @@ OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef d, UInt32 inAnaly
 }
 
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef d, UInt32 inVariant) {
-    if (inVariant > 2) return kLBAudioDetectiveArgumentInvalid;
+    if (inVariant > 3) return kLBAudioDetectiveArgumentInvalid;
     d->variant = inVariant;
     return noErr;
 }

@@ -71,6 +71,7 @@ struct Plan {
     bool pruned_ok = false;
     bool full_ok = false;         // k_rows_full.hip applies
     bool stream_ok = false;       // k_rows_stream.hip applies (also uses d_claim)
+    bool stream2_ok = false;      // k_rows_stream2.hip applies (preferred over k_rows_full.hip when the clip length is even)
     uint32_t* d_claim = nullptr;  // its per-XCD claim counters (8 words)
     // measurement knobs of the generic stage-1 kernel (LBAudioDetectiveSetKernelTuning): waves per workgroup
     // (0 = automatic) and whether the per-lane twiddle cache is used
@@ -104,6 +105,11 @@ hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, u
 bool rows_stream_supported(const Plan& plan);
 hipError_t launch_rows_stream(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
                               uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
+
+// the same plan for 2048-sample windows (k_rows_stream2.hip; the reference's default configuration)
+bool rows_stream2_supported(const Plan& plan);
+hipError_t launch_rows_stream2(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
+                               uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
 
 // specialised stage 2 (k_haar_select32.hip): 128 x 32 frames, keep <= 128
 bool haar_select32_supported(const Plan& plan);

@@ -24,13 +24,13 @@
 // A workgroup is 8 independent waves (two per SIMD) that share only the twiddle tables; there is no
 // workgroup barrier after start-up.  Frames are claimed from per-XCD counters, so the overlapping
 // spans of neighbouring frames meet in one L2.
-#include "internal.hpp"
-#include "fft64_lane.hpp"
+#include "stream_common.hpp"
 
 namespace lbad {
 namespace {
 
 using namespace lane64;
+using namespace stream;
 
 constexpr int kW = 4096;
 constexpr int kN = kW / 2;
@@ -54,71 +54,6 @@ constexpr int kLdsDw = kWaves * kTDw + 64 * kRowDw + kQ * 64 * 2 + 2 * kP1 * 2;
 constexpr int kLdsBytes = kLdsDw * 4;         // 160 256 B: one workgroup per CU
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 static_assert(2 * kPowerDw <= kTDw, "the power terms of two windows reuse the transpose area");
-
-__device__ __forceinline__ constexpr int brev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
-__device__ __forceinline__ constexpr int brev5(int v) {
-    return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
-}
-
-// 16-point DIT stages on registers (same butterflies as lane64::stage_blocks, 16 slots)
-template <int S, int BASE, int J>
-__device__ __forceinline__ void st16_j(cplx (&x)[16]) {
-    constexpr int half = 1 << (S - 1);
-    if constexpr (J < half) {
-        bfly<J*(64 >> S)>(x[BASE + J], x[BASE + J + half]);
-        st16_j<S, BASE, J + 1>(x);
-    }
-}
-template <int S, int BASE>
-__device__ __forceinline__ void st16(cplx (&x)[16]) {
-    if constexpr (BASE < 16) {
-        st16_j<S, BASE, 0>(x);
-        st16<S, BASE + (1 << S)>(x);
-    }
-}
-
-// one complex point = two consecutive samples
-template <int FMT>
-__device__ __forceinline__ cplx load_point(const void* p, int64_t idx) {
-    if constexpr (FMT == 0) {
-        return *reinterpret_cast<const f32x2*>(static_cast<const float*>(p) + 2 * idx);
-    } else if constexpr (FMT == 1) {
-        const short2 s = *reinterpret_cast<const short2*>(static_cast<const int16_t*>(p) + 2 * idx);
-        return mk((float)s.x * (1.0f / 32768.0f), (float)s.y * (1.0f / 32768.0f));
-    } else {
-        const int2 s = *reinterpret_cast<const int2*>(static_cast<const int32_t*>(p) + 2 * idx);
-        return mk((float)s.x * (1.0f / 2147483648.0f), (float)s.y * (1.0f / 2147483648.0f));
-    }
-}
-
-template <int FMT, int T>
-__device__ __forceinline__ void load16(cplx (&x)[16], const void* p, int64_t idx) {
-    if constexpr (T < 16) {
-#ifdef LBAD_EXP_NOLOADS
-        x[T] = mk((float)(idx & 1023) * 1e-3f, (float)T);
-#elif defined(LBAD_EXP_HOTLOADS)
-        x[T] = load_point<FMT>(p, (idx & 2047) + 128 * brev4(T));       // every wave re-reads the same 32 KB: L2 / L1 hits
-#else
-        x[T] = load_point<FMT>(p, idx + 128 * brev4(T));     // slot T holds point m' = brev4(T)
-#endif
-        load16<FMT, T + 1>(x, p, idx);
-    }
-}
-
-__device__ __forceinline__ float dpp_pair_swap(float v) {      // lane l <-> lane l ^ 1
-    return __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-}
-
-__device__ __forceinline__ void wave_sync() {
-    // LDS operations of one wave execute in order; this only stops the compiler from moving them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ cplx msub(cplx u, float wr, float wi, cplx v) {     // u - w v
-    return fma2(mk(-wr, -wr), v, fma2(mk(wi, -wi), v.yx, u));
-}
 
 // row of lane l: lanes 2 p, 2 p + 1 hold the partner rows (p, 64 - p); pair 0 is (0, 32)
 __device__ __forceinline__ int row_of_lane(int l) {
@@ -264,8 +199,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         float* out_row = frames + ((uint64_t)frame * 128 + part * kChunk) * nbands + n;
 
         cplx xa[16], xb[16], P[16], Nw[16];
-        load16<FMT, 0>(xa, pcm, c0);
-        load16<FMT, 0>(xb, pcm, c0 + 32);
+        load16<FMT, 128, 0>(xa, pcm, c0);
+        load16<FMT, 128, 0>(xb, pcm, c0 + 32);
         {
             float2 wt0[kP1];
 #pragma unroll
@@ -277,7 +212,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         auto window_step = [&](int step, cplx (&x)[16], cplx (&xn)[16], cplx (&Pp)[16], cplx (&Nn)[16], float (&pw_out)[kQ]) {
             // the points of the next block: issued now, consumed a whole step later (the scheduler must not
             // sink them towards their use to save registers: that would expose the memory latency)
-            if (step < kChunk) load16<FMT, 0>(xn, pcm, c0 + 32 * (step + 1));
+            if (step < kChunk) load16<FMT, 128, 0>(xn, pcm, c0 + 32 * (step + 1));
             // this half's stage-5 / stage-6 twiddles: all reads in flight before the arithmetic starts (left to
             // itself the scheduler fetches each one right before its butterfly and waits for it, 24 times)
             float2 wt[kP1];

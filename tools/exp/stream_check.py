@@ -1,14 +1,18 @@
-"""Quick check + timing of the W = 4096 stage-1 kernels (configs[4])."""
+"""Quick check + timing of the streaming stage-1 kernels: python tools/exp/stream_check.py [C|A] [--time]
+C = 48 kHz / 4096 (configs[4]), A = 5512 Hz / 2048 (the defaults)."""
 import sys, numpy as np, torch
 import lbaudiodetective_amd as lb
 from oracle import oracle as O
 SEED = 0x4C424144
-cfg = O.Config(48000, 4096)
-n = cfg.window + 64 * (128 * 2 + 17)
-pcm = O.synth_clips(SEED, 100, 3, 48000, n, True)
-det = lb.Detective().configure(sample_rate=48000, window=4096)
+which = "A" if "A" in sys.argv[1:] else "C"
+rate, window, stereo, secs, nbig = (48000, 4096, True, 1, 10000) if which == "C" else (5512, 2048, False, 9, 20000)
+cfg = O.Config(rate, window)
+n = cfg.window + 64 * (128 * 2 + 17) + 1
+n -= n & 1
+pcm = O.synth_clips(SEED, 100, 3, rate, n, stereo)
+det = lb.Detective().configure(sample_rate=rate, window=window)
 ok = True
-for variant in (2, 1):
+for variant in ((2, 3, 1) if which == "A" else (2, 1)):
     det.set_kernel_variant(variant)
     clips = torch.from_numpy(pcm).cuda()
     bits, raw, haar = det.fingerprint_clips_device(clips, taps=True)
@@ -27,9 +31,9 @@ for variant in (2, 1):
         else:
             print(f"variant {variant} clip {c}: rows bit-exact")
 if "--time" in sys.argv:
-    nclips = 10000
-    big = lb.synth_clips_device(SEED, 0, nclips, 48000, 48000, True)
-    for variant in (2, 1):
+    nclips = nbig
+    big = lb.synth_clips_device(SEED, 0, nclips, rate, rate * secs, stereo)
+    for variant in ((2, 3, 1) if which == "A" else (2, 1)):
         det.set_kernel_variant(variant)
         out = det.fingerprint_clips_device(big)
         torch.cuda.synchronize()

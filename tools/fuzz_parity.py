@@ -38,7 +38,8 @@ for t in range(trials):
         det.set_file_tail_mode(tail_mode)
         got = det.process_file_stream(x, file_frames, hop).to_bools()
         want = O.fingerprint_file_loop(x, file_frames, hop, cfg, tail_mode)
-        if got.shape != want.shape or not np.array_equal(got, want):
+        # (no frame at all: an empty fingerprint has no length yet, D.m:297)
+        if got.shape[0] != want.shape[0] or (want.shape[0] and not np.array_equal(got, want)):
             bad += 1
             print("FILE LOOP MISMATCH", t, cfg.sample_rate, cfg.window, cfg.stride, cfg.bands, cfg.subfp_len, hop, n_client, file_frames, tail_mode, flush=True)
         continue
