@@ -135,12 +135,14 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     }
     float* vbuf = tbuf;                                      // power terms: [2 windows][kPowerDw]
     float* dummy = tbuf + kMaxBin + lane;
-    uint32_t b_lo = 0, b_width = 0;                           // band lane & 31 (both halves: two windows per pass)
+    uint32_t b_lo = 0, b_full = 0, b_rem = 0;                 // band lane & 31 (both halves: two windows per pass)
     float b_div = 1.0f;
     if ((uint32_t)(lane & 31) < nbands) {
         b_lo = band_tbl[lane & 31];
         const uint32_t b_hi = band_tbl[nbands + (lane & 31)];
-        b_width = b_hi > b_lo ? b_hi - b_lo : 0;
+        const uint32_t b_width = b_hi > b_lo ? b_hi - b_lo : 0;
+        b_full = b_width >> 3;                                // whole batches of 8 terms
+        b_rem = b_width & 7;
         b_div = __uint_as_float(band_tbl[2 * nbands + (lane & 31)]);
     }
 
@@ -314,9 +316,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
                 const cplx a = madd(y[q], wa.x, wa.y, y[q + 16]);        // output q
                 const cplx b = bsel[q];
                 const float2 wk = stw[q * 64 + lane];
-                const cplx bc = mk(b.x, -b.y);                           // conj(b)
-                const cplx sm = a + bc;                                  // (sr, si) = (a.x + b.x, a.y - b.y)
-                const cplx df = a - bc;                                  // (dr, di) = (a.x - b.x, a.y + b.y)
+                cplx sm, df;                                             // a + conj(b) = (sr, si), a - conj(b) = (dr, di)
+                add_conj(a, b, sm, df);
                 // re = fma(wr, di, fma(wi, dr, sr)), im = fma(-wr, dr, fma(wi, di, si))
                 const cplx z = fma2(mk(wk.x, -wk.x), df.yx, fma2(mk(wk.y, wk.y), df, sm));
                 // "if (x > 0) x /= W/4" is min(x * 2^-10, x): one rounding for x > 0, x itself otherwise
@@ -341,7 +342,9 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
             }
             wave_sync();
             const float* vb = vbuf + h * kPowerDw + b_lo;
-            float v[kMaxTerms];
+            // A band of width w is w / 8 whole batches of 8 terms -- added under a lane mask, no per-term select --
+            // and one partial batch of w % 8 terms read from the lane's own offset.
+            float v[kMaxTerms], vt[7];
 #pragma unroll
             for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
                 if (b < n_batches) {                                      // wave-uniform
@@ -349,14 +352,18 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
                     for (uint32_t q = 0; q < 8; ++q) v[8 * b + q] = vb[8 * b + q];
                 }
             }
+#pragma unroll
+            for (uint32_t q = 0; q < 7; ++q) vt[q] = vb[8 * b_full + q];
             float p = 0.0f;
 #pragma unroll
             for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
-                if (b < n_batches) {
+                if (b < b_full) {                                         // per lane
 #pragma unroll
-                    for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, (8 * b + q < b_width) ? v[8 * b + q] : 0.0f);
+                    for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[8 * b + q]);
                 }
             }
+#pragma unroll
+            for (uint32_t q = 0; q < 7; ++q) p = __fadd_rn(p, q < b_rem ? vt[q] : 0.0f);
             if ((uint32_t)n < nbands) out_row[(uint64_t)(w0 + h) * nbands] = __fdiv_rn(p, b_div);
             wave_sync();                                                  // the power terms are consumed
         };

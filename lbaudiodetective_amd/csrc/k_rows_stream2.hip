@@ -122,12 +122,14 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
     const float* my_ctw = ctw + n * kRowDw;
     float* vbuf = tbuf + s * kPowerDw;                       // power terms of this lane's window, indexed by bin
     float* my_bins = vbuf + my_row;                          // this lane's bins row + 32 q (all stored, the bands pick)
-    uint32_t b_lo = 0, b_width = 0;
+    uint32_t b_lo = 0, b_full = 0, b_rem = 0;
     float b_div = 1.0f;
     if ((uint32_t)n < nbands) {
         b_lo = band_tbl[n];
         const uint32_t b_hi = band_tbl[nbands + n];
-        b_width = b_hi > b_lo ? b_hi - b_lo : 0;
+        const uint32_t b_width = b_hi > b_lo ? b_hi - b_lo : 0;
+        b_full = b_width >> 3;                               // whole batches of 8 terms
+        b_rem = b_width & 7;
         b_div = __uint_as_float(band_tbl[2 * nbands + n]);
     }
 
@@ -168,10 +170,12 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
             // the points of the next block go into the registers just vacated: issued now, consumed a whole
             // window later
             if (step < kChunk) load16<FMT, 64, 0>(x, pcm, c0 + 32 * (step + 1));
+#ifndef LBAD_EXP_NOPH1
             st16<1, 0>(Nw);
             st16<2, 0>(Nw);
             st16<3, 0>(Nw);
             st16<4, 0>(Nw);
+#endif
             // ---- stage 5 and the transpose -----------------------------------------------------------------
             emit_rows<0>(P, Nw, my_col);
             wave_sync();
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                 y[brev5(i)] = mk(q.x, q.y);
                 y[brev5(i + 1)] = mk(q.z, q.w);
             }
+#ifndef LBAD_EXP_NOCROSS
             {
                 int e = 0;
 #pragma unroll
@@ -201,12 +206,16 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                     e += half;
                 }
             }
+#endif
             wave_sync();                                                  // every row has been read
             // ---- split pass: bin k = row + 32 q needs Z[N - k] = output 31 - q of the partner row (pair 0:
             //      output 31 - q of row 16 itself, output 32 - q of row 0 itself), for the q some band reads.
             //      Written on (re, im) pairs: packed instructions. -----------------------------------------------
 #pragma unroll
             for (int q = QLO; q < QHI; ++q) {
+#ifdef LBAD_EXP_NOSPLIT
+                my_bins[32 * q] = y[q].x + y[31 - q].y;
+#else
                 {
                     const int j = 31 - q;
                     cplx b;
@@ -216,9 +225,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                     if (special) b = own;
                     const cplx a = y[q];
                     const float2 wk = stw[q * 32 + n];
-                    const cplx bc = mk(b.x, -b.y);                       // conj(b)
-                    const cplx sm = a + bc;                              // (sr, si)
-                    const cplx df = a - bc;                              // (dr, di)
+                    cplx sm, df;                                         // a + conj(b) = (sr, si), a - conj(b) = (dr, di)
+                    add_conj(a, b, sm, df);
                     // re = fma(wr, di, fma(wi, dr, sr)), im = fma(-wr, dr, fma(wi, di, si))
                     const cplx z = fma2(mk(wk.x, -wk.x), df.yx, fma2(mk(wk.y, wk.y), df, sm));
                     // "if (x > 0) x /= W/4" is min(x * 2^-9, x): one rounding for x > 0, x itself otherwise
@@ -228,12 +236,15 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                     const float t = __fadd_rn(sq.x, sq.y);
                     my_bins[32 * q] = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;   // LBAudioDetective.m:398-401, at the source
                 }
+#endif
             }
             wave_sync();
             // ---- band means in bin order (LBAudioDetective.m:379-405): lane = (band, window) -----------------
             {
+                // A band of width w is w / 8 whole batches of 8 terms -- added under a lane mask, no per-term
+                // select -- and one partial batch of w % 8 terms read from the lane's own offset.
                 const float* vb = vbuf + b_lo;
-                float v[kMaxTerms];
+                float v[kMaxTerms], vt[7];
 #pragma unroll
                 for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
                     if (b < n_batches) {                                  // wave-uniform
@@ -241,14 +252,22 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                         for (uint32_t q = 0; q < 8; ++q) v[8 * b + q] = vb[8 * b + q];
                     }
                 }
+#pragma unroll
+                for (uint32_t q = 0; q < 7; ++q) vt[q] = vb[8 * b_full + q];
                 float p = 0.0f;
+#ifdef LBAD_EXP_NOBANDS
+                p = v[0] + vt[0];
+#else
 #pragma unroll
                 for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
-                    if (b < n_batches) {
+                    if (b < b_full) {                                     // per lane
 #pragma unroll
-                        for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, (8 * b + q < b_width) ? v[8 * b + q] : 0.0f);
+                        for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[8 * b + q]);
                     }
                 }
+#pragma unroll
+                for (uint32_t q = 0; q < 7; ++q) p = __fadd_rn(p, q < b_rem ? vt[q] : 0.0f);
+#endif
                 if ((uint32_t)n < nbands) out_row[(uint64_t)(step - 1) * nbands] = __fdiv_rn(p, b_div);
             }
             wave_sync();                                                  // the power terms are consumed

@@ -73,6 +73,13 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// sm = a + conj(b), df = a - conj(b): one packed add each with the sign on one half of b (the compiler builds
+// conj(b) in registers first when this is written on the vector type)
+__device__ __forceinline__ void add_conj(const cplx a, const cplx b, cplx& sm, cplx& df) {
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(sm) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(df) : "v"(a), "v"(b));
+}
+
 __device__ __forceinline__ cplx msub(cplx u, float wr, float wi, cplx v) {     // u - w v
     return fma2(mk(-wr, -wr), v, fma2(mk(wi, -wi), v.yx, u));
 }

@@ -66,7 +66,8 @@ CONFIGS = {
     "bands_14": dict(sample_rate=22050, window=256, stride=277, bands=14, subfp_len=180),
     "bands_11": dict(sample_rate=16000, window=512, stride=64, bands=11, subfp_len=64),
 }
-# configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, C -> k_rows_stream.hip, the others -> k_rows_full.hip
+# configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, C -> k_rows_stream.hip, A -> k_rows_stream2.hip,
+# the others -> k_rows_full.hip
 SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64", "C_48k_4096"}
 
 
@@ -705,6 +706,30 @@ def test_stream_kernel_shapes(lb, gpu, oracle):
     pcm = oracle.synth_clips(SEED, 960, 5, 44100, 4096 + 64 * 128 * 2)
     for variant in (0, 1):
         assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg2, variant=variant), oracle.fingerprint_batch(pcm, cfg2)), variant
+
+
+def test_stream2_kernel_shapes(lb, gpu, oracle):
+    """k_rows_stream2.hip (2048-sample windows, the reference's default configuration): many clips and frames per
+    clip (every wave walks many pairs of runs), an odd number of runs, ragged tails; variant 3 is the
+    same configuration on k_rows_full.hip, an odd clip length goes there by itself.  A second band table
+    (11 025 Hz: bins 43..379) takes the kernel's full-range split pass instead of the default table's q = 2..23."""
+    cfg = oracle.Config(5512, 2048)
+    for n_clips, n in ((41, 2048 + 64 * (128 * 3 + 50)), (301, 2048 + 64 * 128), (1, 2048 + 64 * 128), (2, 2048 + 64 * (128 * 9) + 2)):
+        pcm = oracle.synth_clips(SEED, 1900, n_clips, 5512, n)
+        want = oracle.fingerprint_batch(pcm, cfg, nthreads=8)
+        for variant in (0, 2, 3):
+            assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg, variant=variant), want), (n_clips, n, variant)
+    n = 2048 + 64 * 128 * 2 + 33                                            # odd: no aligned sample pairs
+    pcm = oracle.synth_clips(SEED, 1950, 3, 5512, n)
+    for variant in (0, 2):
+        assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg, variant=variant), oracle.fingerprint_batch(pcm, cfg)), variant
+    cfg2 = oracle.Config(11025, 2048)
+    pcm = oracle.synth_clips(SEED, 1960, 5, 11025, 2048 + 64 * 128 * 2)
+    want = oracle.fingerprint_batch(pcm, cfg2)
+    for variant in (0, 1, 3):
+        got, raw, _ = _fingerprint_device(lb, gpu, pcm, cfg2, variant=variant, taps=True)
+        assert np.array_equal(got, want), variant
+        assert np.array_equal(raw[0], oracle.fingerprint_pcm(pcm[0], cfg2, taps=True)[1]), variant
 
 
 # ---------------------------------------------------------------------------------------------

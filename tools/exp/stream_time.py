@@ -4,16 +4,21 @@ import sys, torch
 import lbaudiodetective_amd._native as N
 import subprocess, os, json
 child = "--child" in sys.argv
-libs = [a for a in sys.argv[1:] if a != "--child"] or [N.LIB_PATH]
+cfg_a = "--A" in sys.argv                                   # 5512 Hz / 2048, 20 000 nine-second clips instead
+libs = [a for a in sys.argv[1:] if a not in ("--child", "--A")] or [N.LIB_PATH]
 if not child:
     for l in libs:
-        out = subprocess.run([sys.executable, __file__, l, "--child"], capture_output=True, text=True, timeout=120)
+        out = subprocess.run([sys.executable, __file__, l, "--child"] + (["--A"] if cfg_a else []), capture_output=True, text=True, timeout=120)
         print(os.path.basename(l), out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)
     sys.exit(0)
 N.LIB_PATH = libs[0]
 import lbaudiodetective_amd as lb
-det = lb.Detective().configure(sample_rate=48000, window=4096)
-big = lb.synth_clips_device(0x4C424144, 0, 10000, 48000, 48000, True)
+if cfg_a:
+    det = lb.Detective().configure(sample_rate=5512, window=2048)
+    big = lb.synth_clips_device(0x4C424144, 0, 20000, 5512, 5512 * 9, False)
+else:
+    det = lb.Detective().configure(sample_rate=48000, window=4096)
+    big = lb.synth_clips_device(0x4C424144, 0, 10000, 48000, 48000, True)
 out = det.fingerprint_clips_device(big)
 torch.cuda.synchronize()
 det.set_stage_timing(True)
