@@ -75,7 +75,7 @@ void run(const char* name, int threads, float* d_out, long long* d_cyc) {
 int main() {
     float* d_out; long long* d_cyc;
     hipMalloc(&d_out, 256 * 1024 * 4); hipMalloc(&d_cyc, 256 * 8);
-    for (int threads : {256, 512, 1024}) {
+    for (int threads : {256, 512, 768, 1024}) {
         run<0>("v_fma_f32 x16 indep", threads, d_out, d_cyc);
         run<1>("v_pk_fma_f32 x8 indep", threads, d_out, d_cyc);
         run<2>("v_fma_f32 dependent", threads, d_out, d_cyc);
