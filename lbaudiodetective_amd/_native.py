@@ -156,6 +156,7 @@ CONSTANTS = {
     "kLBAudioDetectiveDeviceUnavailable": OSStatus,
     "kLBAudioDetectiveDeviceError": OSStatus,
     "kLBAudioDetectiveUnsupportedFile": OSStatus,
+    "kLBAudioDetectiveMemFull": OSStatus,
 }
 
 _lib = None

@@ -141,8 +141,10 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     if (per == 0 || n_clips == 0) return noErr;
     if (per > 0xFFFFFFFFull / kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
     // variant 0: specialised kernels when the configuration has them; 1: generic kernels; 2: specialised or error
-    const bool stream_ok = p.stream_ok && (spc & 1) == 0;
-    const bool stream2_ok = p.stream2_ok && (spc & 1) == 0 && d->variant != 3;
+    // the streaming kernels read the clips as aligned sample PAIRS: every clip must start on a pair boundary
+    const bool pairs_ok = reinterpret_cast<uintptr_t>(d_pcm_raw) % (2 * elem) == 0 && ((spc & 1) == 0 || n_clips == 1);
+    const bool stream_ok = p.stream_ok && pairs_ok;
+    const bool stream2_ok = p.stream2_ok && pairs_ok && d->variant != 3;
     bool special = p.pruned_ok || p.full_ok || stream_ok || stream2_ok;
     if (d->variant == 3) {                       // measurement: the non-streaming specialised kernel where both exist
         if (!p.full_ok && !p.pruned_ok) return kLBAudioDetectiveArgumentInvalid;
@@ -289,6 +291,14 @@ static LBAudioDetectiveFingerprintRef fingerprint_from_bools(const LBAudioDetect
 }  // namespace lbad
 
 using lbad::ensure_plan;
+
+// Host allocations sized by caller or file data (decoded audio, resampler output, zero padding) can fail:
+// nothing may unwind through the C boundary.  memFullErr is MacErrors.h's -108.
+#define LBAD_GUARD_BEGIN try {
+#define LBAD_GUARD_END                                                    \
+    }                                                                     \
+    catch (const std::bad_alloc&) { return kLBAudioDetectiveMemFull; }    \
+    catch (const std::exception&) { return kLBAudioDetectiveArgumentInvalid; }
 
 extern "C" {
 
@@ -451,18 +461,23 @@ OSStatus LBAudioDetectiveFingerprintClipsDevice(LBAudioDetectiveRef d, const Flo
 
 OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef d, const Float32* inClips, UInt64 inNumberOfClips,
                                           UInt64 inSamplesPerClip, Boolean* outBooleans) {
+    LBAD_GUARD_BEGIN
     return LBAudioDetectiveFingerprintClipsFormat(d, inClips, 0, inNumberOfClips, inSamplesPerClip, outBooleans);
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef d, const void* inClips, UInt32 inSampleFormat,
                                                 UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
                                                 Boolean* outBooleans) {
+    LBAD_GUARD_BEGIN
     if (!d || !inClips || !outBooleans || inSampleFormat > 2) return kLBAudioDetectiveArgumentInvalid;
     return lbad::fingerprint_clips_host(d, inClips, inSampleFormat, inNumberOfClips, inSamplesPerClip, outBooleans);
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveProcessPCM(LBAudioDetectiveRef d, const Float32* inSamples, UInt64 inNumberOfSamples,
                                     LBAudioDetectiveFingerprintRef* outFingerprint) {
+    LBAD_GUARD_BEGIN
     if (!d || !outFingerprint || (!inSamples && inNumberOfSamples)) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
@@ -474,11 +489,13 @@ OSStatus LBAudioDetectiveProcessPCM(LBAudioDetectiveRef d, const Float32* inSamp
     }
     *outFingerprint = lbad::fingerprint_from_bools(d, bools.data(), per);
     return noErr;
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef d, const Float32* inSamples1, UInt64 inCount1,
                                     const Float32* inSamples2, UInt64 inCount2, UInt32 inComparisonRange,
                                     Float32* outMatch) {  // :442-464 on PCM
+    LBAD_GUARD_BEGIN
     if (inComparisonRange == 0) inComparisonRange = d->subfp_len;  // :443-445
     LBAudioDetectiveFingerprintRef fp1 = NULL, fp2 = NULL;
     OSStatus st = LBAudioDetectiveProcessPCM(d, inSamples1, inCount1, &fp1);
@@ -488,6 +505,7 @@ OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef d, const Float32* inSamp
     LBAudioDetectiveFingerprintDispose(fp1);
     LBAudioDetectiveFingerprintDispose(fp2);
     return st;
+    LBAD_GUARD_END
 }
 
 static OSStatus read_url(LBAudioDetectiveURLRef inFileURL, std::vector<float>& mono, double& rate) {
@@ -523,6 +541,7 @@ OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef d, UInt32 inMode) 
 OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate,
                                                    UInt32 inResamplerMode, Float32** outSamples, UInt64* outCount,
                                                    Float64* outSampleRate) {
+    LBAD_GUARD_BEGIN
     if (!inFileURL || !outSamples || !outCount || inResamplerMode > 2) return kLBAudioDetectiveArgumentInvalid;
     std::vector<float> mono, conv;
     double rate = 0.0;
@@ -541,6 +560,7 @@ OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFile
     *outCount = src->size();
     if (outSampleRate) *outSampleRate = rate;
     return noErr;
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
@@ -555,6 +575,7 @@ void LBAudioDetectiveFreeSamples(Float32* inSamples) { std::free(inSamples); }
 // client samples in (:287-288), and the chosen treatment of the windows that reach past the end.
 OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32* inClientSamples, UInt64 inClientCount,
                                            UInt64 inFileFrames, UInt32 inHop, LBAudioDetectiveFingerprintRef* outFingerprint) {
+    LBAD_GUARD_BEGIN
     if (!d || !outFingerprint || (!inClientSamples && inClientCount) || inHop == 0) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
@@ -603,10 +624,12 @@ OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32*
     if (st != noErr) return st;
     *outFingerprint = lbad::fingerprint_from_bools(d, bools.data(), frames);
     return noErr;
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
+    LBAD_GUARD_BEGIN
     if (!inFileURL) return kLBAudioDetectiveArgumentInvalid;  // :211-214
     std::vector<float> file, mono;
     double file_rate = 0.0;
@@ -624,6 +647,7 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetective
     uint32_t hop = (uint32_t)std::llround((double)d->stride * rate / file_rate);
     if (hop < 1) hop = 1;
     return LBAudioDetectiveProcessFileStream(d, mono.data(), mono.size(), file.size(), hop, outFingerprint);
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL1,
@@ -663,6 +687,7 @@ void LBAudioDetectiveStreamDispose(LBAudioDetectiveStreamRef inStream) {
 
 OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef s, const Float32* inSamples, UInt64 inNumberOfSamples,
                                     UInt32* outNewSubfingerprints) {
+    LBAD_GUARD_BEGIN
     if (outNewSubfingerprints) *outNewSubfingerprints = 0;
     if (!s || (!inSamples && inNumberOfSamples)) return kLBAudioDetectiveArgumentInvalid;
     LBAudioDetective* d = s->detective;
@@ -685,6 +710,7 @@ OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef s, const Float32* 
     s->pending.erase(s->pending.begin(), s->pending.begin() + (size_t)(ready * hop));
     if (outNewSubfingerprints) *outNewSubfingerprints = (UInt32)ready;
     return noErr;
+    LBAD_GUARD_END
 }
 
 LBAudioDetectiveFingerprintRef LBAudioDetectiveStreamCopyFingerprint(LBAudioDetectiveStreamRef s) {

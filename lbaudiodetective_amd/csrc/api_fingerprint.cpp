@@ -17,6 +17,7 @@ const UInt32 kLBAudioDetectiveDefaultSubfingerprintLength = 200; // LBAudioDetec
 const OSStatus kLBAudioDetectiveDeviceUnavailable = 0x6E6F6770;  // 'nogp'
 const OSStatus kLBAudioDetectiveDeviceError = 0x67706572;        // 'gper'
 const OSStatus kLBAudioDetectiveUnsupportedFile = 0x666D743F;    // 'fmt?'
+const OSStatus kLBAudioDetectiveMemFull = -108;                  // MacErrors.h memFullErr
 
 void LBAudioDetectivePackSubfingerprint(const Boolean* inBooleans, UInt32 inLength, UInt32* outWords) {
     for (UInt32 w = 0; w < LBAD_PACKED_WORDS; ++w) outWords[w] = 0;

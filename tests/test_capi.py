@@ -15,7 +15,7 @@ def _has_gpu():
 
 def test_exports_every_declared_symbol(lb):
     funcs, consts = lb._native.declared_symbols()
-    assert len(funcs) >= 60 and len(consts) == 8
+    assert len(funcs) >= 60 and len(consts) == 9
     raw = C.CDLL(lb.LIB_PATH)
     for name in funcs + consts:
         assert hasattr(raw, name), f"{name} declared in include/lbaudiodetective.h but not exported"

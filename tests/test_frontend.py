@@ -133,3 +133,35 @@ def test_fingerprint_string_round_trip(lb):
     for bad in ("01+0", "01a", "+01", "01++10"):
         with pytest.raises(ValueError):
             lb.Fingerprint.from_string(bad)
+
+
+def test_front_end_survives_mutated_files(tmp_path):
+    """tools/fuzz_audiofile.cpp: the CAF / WAV parser, the IMA4 decoder and the resampler built for the CPU with
+    AddressSanitizer + UBSan and fed mutated copies of the fixtures (chunk sizes, counts, formats, truncation).
+    A sanitizer report, an exception or an absurd allocation fails the run (the suite runs a short one; longer
+    runs: see the tool's header)."""
+    import shutil
+    import subprocess
+    import wave
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(__file__))
+    exe = tmp_path / "fuzz_audiofile"
+    src = [os.path.join(root, "tools", "fuzz_audiofile.cpp"), os.path.join(root, "lbaudiodetective_amd", "csrc", "audiofile.cpp")]
+    build = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                            "-I" + os.path.join(root, "lbaudiodetective_amd", "csrc"), *src, "-o", str(exe)],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(3000) * 8000).astype(np.int16)
+    seeds = [os.path.join(BIRDS, "BlackBird_eql.caf"), os.path.join(BIRDS, "BlackBird_rec.caf")]
+    for name, ch, width, rate in (("s16.wav", 2, 2, 44100), ("u8.wav", 1, 1, 8000)):
+        with wave.open(str(tmp_path / name), "wb") as w:
+            w.setnchannels(ch); w.setsampwidth(width); w.setframerate(rate)
+            w.writeframes(x.tobytes() if width == 2 else (x[:1000] >> 8).astype(np.int8).view(np.uint8).tobytes())
+        seeds.append(str(tmp_path / name))
+    run = subprocess.run([str(exe), "1200", "11", *seeds], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert "no sanitizer report" in run.stdout

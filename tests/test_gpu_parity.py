@@ -708,6 +708,19 @@ def test_stream_kernel_shapes(lb, gpu, oracle):
         assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg2, variant=variant), oracle.fingerprint_batch(pcm, cfg2)), variant
 
 
+def test_host_allocation_failure_is_a_status(lb, gpu, oracle):
+    """Buffers sized by the caller's numbers (here 2^50 file frames to zero-pad to) fail with memFullErr instead of
+    an exception crossing the C boundary; the detective keeps working."""
+    det = lb.Detective().configure(sample_rate=5512, window=2048)
+    x = oracle.synth_clip(SEED, 3, 5512, 30000)
+    with pytest.raises(lb.LBAudioDetectiveError) as e:
+        det.process_file_stream(x, 1 << 50, 64)
+    assert e.value.status == lb.constant("kLBAudioDetectiveMemFull") == -108
+    fp = det.process_file_stream(x, 30000, 8)
+    want = oracle.fingerprint_file_loop(x, 30000, 8, oracle.Config(5512, 2048), oracle.TAIL_NOTHING)    # the default tail mode
+    assert want.shape[0] > 0 and np.array_equal(fp.to_bools(), want)
+
+
 def test_stream2_kernel_shapes(lb, gpu, oracle):
     """k_rows_stream2.hip (2048-sample windows, the reference's default configuration): many clips and frames per
     clip (every wave walks many pairs of runs), an odd number of runs, ragged tails; variant 3 is the
@@ -723,6 +736,15 @@ def test_stream2_kernel_shapes(lb, gpu, oracle):
     pcm = oracle.synth_clips(SEED, 1950, 3, 5512, n)
     for variant in (0, 2):
         assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg, variant=variant), oracle.fingerprint_batch(pcm, cfg)), variant
+    # a single odd-length clip still starts on a pair boundary (streaming kernel); the same samples one float
+    # into an allocation do not (k_rows_full.hip): same bits either way
+    det = lb.Detective().configure(sample_rate=5512, window=2048)
+    one = gpu.from_numpy(pcm[:1].copy()).cuda()
+    shifted = gpu.zeros(n + 1, dtype=gpu.float32, device="cuda")
+    shifted[1:] = one[0]
+    want = oracle.fingerprint_batch(pcm[:1], cfg)
+    assert np.array_equal(_bits(lb, det.fingerprint_clips_device(one), cfg.subfp_len), want)
+    assert np.array_equal(_bits(lb, det.fingerprint_clips_device(shifted[1:].reshape(1, n)), cfg.subfp_len), want)
     cfg2 = oracle.Config(11025, 2048)
     pcm = oracle.synth_clips(SEED, 1960, 5, 11025, 2048 + 64 * 128 * 2)
     want = oracle.fingerprint_batch(pcm, cfg2)

@@ -1,0 +1,104 @@
+// Mutation fuzzer for the file front end (CAF / WAV parser, IMA4 decoder, resampler), built for the CPU with
+// the sanitizers:
+//   g++ -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -Ilbaudiodetective_amd/csrc \
+//       tools/fuzz_audiofile.cpp lbaudiodetective_amd/csrc/audiofile.cpp -o /tmp/fuzz_audiofile
+//   /tmp/fuzz_audiofile <iterations> <seed> file1.caf file2.wav ...
+// Every iteration copies one seed file, flips / overwrites / truncates / splices a few bytes (header fields
+// favoured), writes it to a scratch file and runs read_audio_file + resample on it.  Any sanitizer report,
+// uncaught exception or absurd allocation ends the run.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "audiofile.hpp"
+
+static std::vector<uint8_t> slurp(const char* path) {
+    std::vector<uint8_t> b;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return b;
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    b.resize(n > 0 ? (size_t)n : 0);
+    if (n > 0 && std::fread(b.data(), 1, b.size(), f) != b.size()) b.clear();
+    std::fclose(f);
+    return b;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s iterations seed files...\n", argv[0]);
+        return 2;
+    }
+    const long iters = std::atol(argv[1]);
+    std::mt19937_64 rng((uint64_t)std::atoll(argv[2]));
+    std::vector<std::vector<uint8_t>> seeds;
+    for (int i = 3; i < argc; ++i) {
+        auto b = slurp(argv[i]);
+        if (b.size() > (1u << 20)) b.resize(1u << 20);      // keep iterations fast: the parsers only see a prefix
+        if (!b.empty()) seeds.push_back(std::move(b));
+    }
+    if (seeds.empty()) return 2;
+    const std::string scratch = std::string("/tmp/fuzz_audiofile_") + std::to_string((long)rng() & 0xffffff) + ".bin";
+    long ok = 0, unsupported = 0;
+    static const uint32_t kInteresting[] = {0, 1, 2, 3, 8, 16, 24, 32, 33, 34, 63, 64, 65, 127, 128, 255, 256, 0x7fff, 0x8000,
+                                            0xffff, 0x10000, 0x7fffffff, 0x80000000u, 0xffffffffu};
+    for (long it = 0; it < iters; ++it) {
+        std::vector<uint8_t> b = seeds[rng() % seeds.size()];
+        const int n_mut = 1 + (int)(rng() % 6);
+        for (int m = 0; m < n_mut; ++m) {
+            const size_t hdr = b.size() < 4096 ? b.size() : 4096;
+            const size_t at = (rng() % 4) ? rng() % hdr : rng() % b.size();    // mostly in the chunk headers
+            switch (rng() % 6) {
+                case 0: b[at] ^= (uint8_t)(1u << (rng() % 8)); break;
+                case 1: b[at] = (uint8_t)rng(); break;
+                case 2: {                                                       // 32-bit field, either byte order
+                    const uint32_t v = kInteresting[rng() % (sizeof(kInteresting) / 4)];
+                    for (int i = 0; i < 4 && at + i < b.size(); ++i)
+                        b[at + i] = (uint8_t)((rng() & 1) ? v >> (8 * i) : v >> (24 - 8 * i));
+                    break;
+                }
+                case 3: b.resize(1 + rng() % b.size()); break;                 // truncate
+                case 4: {                                                       // splice a stretch from elsewhere
+                    const size_t from = rng() % b.size(), len = rng() % 64;
+                    for (size_t i = 0; i < len && at + i < b.size() && from + i < b.size(); ++i) b[at + i] = b[from + i];
+                    break;
+                }
+                default: {                                                      // 64-bit big-endian size field
+                    const uint64_t v = (rng() & 1) ? ~0ull : (uint64_t)kInteresting[rng() % (sizeof(kInteresting) / 4)] << (rng() % 33);
+                    for (int i = 0; i < 8 && at + i < b.size(); ++i) b[at + i] = (uint8_t)(v >> (56 - 8 * i));
+                }
+            }
+            if (b.empty()) b.push_back(0);
+        }
+        FILE* f = std::fopen(scratch.c_str(), "wb");
+        if (!f) return 2;
+        std::fwrite(b.data(), 1, b.size(), f);
+        std::fclose(f);
+        std::vector<float> mono, conv;
+        double rate = 0.0;
+        const lbad::AudioFileStatus st = lbad::read_audio_file(scratch.c_str(), mono, rate);
+        if (st == lbad::AudioFileStatus::Ok) {
+            ++ok;
+            if (mono.size() > (64u << 20)) {
+                std::fprintf(stderr, "iteration %ld: %zu samples from a %zu-byte file\n", it, mono.size(), b.size());
+                return 1;
+            }
+            if (mono.size() > 50000) mono.resize(50000);                      // bound the resampler's work
+            const double target = (rng() & 1) ? 5512.0 : 44100.0;
+            if (lbad::resample(mono, rate, target, (uint32_t)(rng() % 3), conv) && conv.size() > (256u << 20)) {
+                std::fprintf(stderr, "iteration %ld: resampler produced %zu samples\n", it, conv.size());
+                return 1;
+            }
+        } else {
+            ++unsupported;
+        }
+    }
+    std::remove(scratch.c_str());
+    std::printf("%ld iterations: %ld decoded, %ld rejected, no sanitizer report\n", iters, ok, unsupported);
+    return 0;
+}
