@@ -5,7 +5,8 @@
 //   /tmp/fuzz_audiofile <iterations> <seed> file1.caf file2.wav ...
 // Every iteration copies one seed file, flips / overwrites / truncates / splices a few bytes (header fields
 // favoured), writes it to a scratch file and runs read_audio_file + resample on it.  Any sanitizer report,
-// uncaught exception or absurd allocation ends the run.
+// uncaught exception or absurd allocation ends the run.  Round 2: 150 000 iterations (seed 2) over two bird fixtures
+// (ima4, 32-bit lpcm) and three WAV shapes: 139 002 decoded, 10 998 rejected, no report.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
