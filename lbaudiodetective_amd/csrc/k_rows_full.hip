@@ -306,7 +306,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         // otherwise (negative, zero of either sign, NaN)
         re = fminf(__fmul_rn(re, inv_norm), re);
         im = fminf(__fmul_rn(im, inv_norm), im);
-        return __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        const float t = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        return (t == t && fabsf(t) != INFINITY) ? t : 0.0f;             // LBAudioDetective.m:398-401, at the source
     };
     auto slot_work = [&](auto q_tag) {
         constexpr int Q = decltype(q_tag)::value;
@@ -384,14 +385,25 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
             const uint32_t ww = t / nbands, band = t - ww * nbands;
             const uint32_t lo = band_tbl[band], hi = band_tbl[nbands + band];
             div = __uint_as_float(band_tbl[2 * nbands + band]);
-            for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
+            // whole batches of eight terms need no per-term mask (a lane leaves the loop when its band runs out);
+            // the last w % 8 terms are read from the lane's own offset -- what lies behind a band (another band's
+            // terms, padding, the scratch words) is read and selected away, never added
+            const uint32_t width = hi > lo ? hi - lo : 0;
+            const float* vb = vbuf + ww * nread + (lo - kmin);
+            const uint32_t full = width >> 3, rem = width & 7;
+            for (uint32_t b = 0; b < full; ++b) {
                 float v[8];
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) v[q] = (k0 + q < hi) ? vbuf[ww * nread + (k0 + q - kmin)] : 0.0f;
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) v[q] = (v[q] == v[q] && fabsf(v[q]) != INFINITY) ? v[q] : 0.0f;
+                for (uint32_t q = 0; q < 8; ++q) v[q] = vb[8 * b + q];
 #pragma unroll
                 for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, v[q]);
+            }
+            if (rem) {
+                float v[7];
+#pragma unroll
+                for (uint32_t q = 0; q < 7; ++q) v[q] = vb[8 * full + q];
+#pragma unroll
+                for (uint32_t q = 0; q < 7; ++q) p = __fadd_rn(p, q < rem ? v[q] : 0.0f);
             }
         }
         out[i] = __fdiv_rn(p, div);
