@@ -241,7 +241,8 @@ __device__ __forceinline__ void dit_all(float2* z, const float2* cache, const fl
 
 // LDS floats per wave: N (+ skew) complex points, then one power term per bin the bands read
 template <int LOG2W> constexpr int point_floats() { return 2 * ((1 << (LOG2W - 1)) + ((1 << (LOG2W - 1)) >> 5)); }
-inline uint32_t bins_padded(uint32_t kmin, uint32_t kmax) { return (kmax - kmin + 63u) & ~63u; }
+// (+ 7: the band sums read a partial batch of up to seven terms from a lane's own offset, up to six past kmax)
+__host__ __device__ inline uint32_t bins_padded(uint32_t kmin, uint32_t kmax) { return (kmax - kmin + 7u + 63u) & ~63u; }
 
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
     // LDS: [per-lane twiddle cache][split-pass twiddles W^k, k in [kmin, kmax)][per wave: points, power terms]
     float2* cache = reinterpret_cast<float2*>(smem);
     constexpr int kCacheFloats = CACHED ? 2 * Passes<LOG2W>::cache_slots : 0;
-    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    const uint32_t nread = bins_padded(kmin, kmax);
     float2* split_tw = reinterpret_cast<float2*>(smem + kCacheFloats);
     float* zf = smem + kCacheFloats + 2 * nread + (size_t)wave * (kZf + nread);
     float2* z = reinterpret_cast<float2*>(zf);
@@ -340,7 +341,9 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
             if (re > 0.0f) re = __fmul_rn(re, inv_norm);
             if (im > 0.0f) im = __fmul_rn(im, inv_norm);
             const float pw = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
-            if (live) vbuf[k - kmin] = pw;
+            // a NaN / inf term is skipped by the band sums (LBAudioDetective.m:398-401): +0 here leaves a sum of
+            // squares -- never -0 -- unchanged, one select per bin instead of one per term read
+            if (live) vbuf[k - kmin] = (pw == pw && fabsf(pw) != INFINITY) ? pw : 0.0f;
         }
         wave_sync();
 
@@ -352,18 +355,26 @@ __global__ __launch_bounds__(WPB * 64) void fft_bands_kernel(
 #endif
             const float div = __uint_as_float(band_tbl[2 * nbands + b]);
             // the sum must run in bin order (float32 addition is not associative); the loads are issued
-            // in batches of 8 so that their LDS latency overlaps instead of serialising with the adds
-            // A skipped term (past the band, NaN, inf: LBAudioDetective.m:398-401) is replaced by +0, which
-            // leaves p -- a sum of squares, never -0 -- unchanged; that keeps the selects off the chain of adds.
+            // in batches of 8 so that their LDS latency overlaps instead of serialising with the adds.  Whole
+            // batches need no per-term mask (a lane leaves the loop when its band runs out); the last w % 8
+            // terms are read from the lane's own offset, what lies behind the band is selected away.
             float p = 0.0f;
-            for (uint32_t k0 = lo; k0 < hi; k0 += 8) {
+            const uint32_t width = hi > lo ? hi - lo : 0;
+            const float* vb = vbuf + (lo - kmin);
+            const uint32_t full = width >> 3, rem = width & 7;
+            for (uint32_t i = 0; i < full; ++i) {
                 float x[8];
 #pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) x[q] = (k0 + q < hi) ? vbuf[k0 + q - kmin] : 0.0f;
-#pragma unroll
-                for (uint32_t q = 0; q < 8; ++q) x[q] = (x[q] == x[q] && fabsf(x[q]) != INFINITY) ? x[q] : 0.0f;
+                for (uint32_t q = 0; q < 8; ++q) x[q] = vb[8 * i + q];
 #pragma unroll
                 for (uint32_t q = 0; q < 8; ++q) p = __fadd_rn(p, x[q]);
+            }
+            if (rem) {
+                float x[7];
+#pragma unroll
+                for (uint32_t q = 0; q < 7; ++q) x[q] = vb[8 * full + q];
+#pragma unroll
+                for (uint32_t q = 0; q < 7; ++q) p = __fadd_rn(p, q < rem ? x[q] : 0.0f);
             }
             frames[win * nbands + b] = __fdiv_rn(p, div);
         }
