@@ -18,146 +18,201 @@ namespace lbad {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr uint32_t kCandMax = 256;
+constexpr uint32_t kCand = 128;      // candidates ranked exhaustively (keep <= 128: sub-fingerprints of <= 256 Booleans)
 
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red) {
-    // wave reduce, then 4 partials through LDS
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    const int wave = threadIdx.x >> 6;
-    __syncthreads();  // protect s_red from the previous use
-    if ((threadIdx.x & 63) == 0) s_red[wave] = v;
-    __syncthreads();
-    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
-}
-
-// 1-D Haar of LBAudioDetectiveFrameDecomposeArray applied to `lines` independent lines of
-// length `len`; element e of line l sits at src[l * lstride + e * estride].
+// 1-D Haar of LBAudioDetectiveFrameDecomposeArray applied to `lines` independent lines of length `len`; element e
+// of line l sits at [l * lstride + e * estride] of every buffer.  The reference works in place through a scratch
+// copy (Frame.m:133-153); here the detail values of a level -- final once written -- go straight to `out`, and
+// the sums the next level consumes alternate between `scratch` and the part of `in` the previous level has
+// finished reading: one barrier and one store per value and level.  `in` is destroyed.
 // `root` = sqrtf(len) is computed on the host: the device's sqrt is the 1-ulp v_sqrt_f32 (sqrtf(14.0f)
 // comes out one ulp low, for example), whatever -fhip-fp32-correctly-rounded-divide-sqrt promises.
-__device__ void haar_lines(float* a, float* tmp, uint32_t lines, uint32_t len, uint32_t lstride, uint32_t estride,
-                           float root) {
+__device__ void haar_lines(float* in, float* out, float* scratch, uint32_t lines, uint32_t len, uint32_t lstride,
+                           uint32_t estride, float root) {
     const float root2 = __fsqrt_rn(2.0f);   // constant-folded by the compiler (correctly rounded)
-    for (uint32_t p = threadIdx.x; p < lines * len; p += kThreads) {
-        const uint32_t l = p / len, e = p % len;
-        const uint32_t at = l * lstride + e * estride;
-        a[at] = __fdiv_rn(a[at], root);
+    if (len == 1) {
+        for (uint32_t l = threadIdx.x; l < lines; l += kThreads) out[l * lstride] = __fdiv_rn(in[l * lstride], root);
+        __syncthreads();
+        return;
     }
-    __syncthreads();
-    uint32_t cnt = len;
-    while (cnt > 1) {
-        cnt >>= 1;
+    // `scratch` holds len / 2 values per line, packed
+    struct View { float* p; uint32_t ls, es; };
+    View src{in, lstride, estride}, dst{scratch, len >> 1, 1u};
+    bool first = true;
+    uint32_t have = len;                 // values of the running line: src[0 .. have)
+    while (have > 1) {
+        const uint32_t cnt = have >> 1;
         for (uint32_t p = threadIdx.x; p < lines * cnt; p += kThreads) {
             const uint32_t l = p / cnt, i = p % cnt;
-            const float ev = a[l * lstride + (2 * i) * estride];
-            const float od = a[l * lstride + (2 * i + 1) * estride];
-            tmp[l * lstride + i * estride] = __fdiv_rn(__fadd_rn(ev, od), root2);
-            tmp[l * lstride + (cnt + i) * estride] = __fdiv_rn(__fsub_rn(ev, od), root2);
+            float ev = src.p[l * src.ls + (2 * i) * src.es];
+            float od = src.p[l * src.ls + (2 * i + 1) * src.es];
+            if (first) {                                                // the pre-scale of Frame.m:137-139
+                ev = __fdiv_rn(ev, root);
+                od = __fdiv_rn(od, root);
+            }
+            const float sum = __fdiv_rn(__fadd_rn(ev, od), root2);
+            const float dif = __fdiv_rn(__fsub_rn(ev, od), root2);
+            out[l * lstride + (cnt + i) * estride] = dif;
+            if (cnt == 1) out[l * lstride] = sum;
+            else dst.p[l * dst.ls + i * dst.es] = sum;
+        }
+        if (have & 1u) {
+            // an odd count leaves its last value where it is for good (the reference copies 2 cnt values back)
+            for (uint32_t l = threadIdx.x; l < lines; l += kThreads) {
+                const float v = src.p[l * src.ls + (have - 1) * src.es];
+                out[l * lstride + (have - 1) * estride] = first ? __fdiv_rn(v, root) : v;
+            }
         }
         __syncthreads();
-        for (uint32_t p = threadIdx.x; p < lines * 2 * cnt; p += kThreads) {
-            const uint32_t l = p / (2 * cnt), i = p % (2 * cnt);
-            const uint32_t at = l * lstride + i * estride;
-            a[at] = tmp[at];
-        }
-        __syncthreads();
+        // this level has read src[0 .. have): the next one may write its sums there
+        const View t = src;
+        src = dst;
+        dst = t;
+        first = false;
+        have = cnt;
     }
 }
 
+// PER = coefficients per thread (128 x bands / 256, rounded up to 8 / 16 / 32): the select works on registers
+template <int PER>
 __global__ __launch_bounds__(kThreads) void haar_select_kernel(const float* __restrict__ frames, uint32_t bands,
                                                                float root_bands, uint32_t keep, uint32_t subfp_len,
                                                                uint32_t* __restrict__ packed,
                                                                float* __restrict__ haar_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const uint32_t n = kRowsPerFrame * bands;
-    float* a = smem;
-    float* tmp = smem + n;
-    __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_ckey[kCandMax];
-    __shared__ uint32_t s_cidx[kCandMax];
+    float* a = smem;                   // the frame, then the finished coefficients
+    float* b = smem + n;               // rows done, columns still to do
+    float* tmp = smem + 2 * n;         // running sums (n / 2 floats, packed per line)
+    __shared__ uint32_t s_red[8];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_cand[kCand];
+    __shared__ uint32_t s_rank[kCand];
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_bits[kPackedWords];
 
+    const int t = threadIdx.x;
     const uint64_t frame = blockIdx.x;
     const float* src = frames + frame * n;
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) a[i] = src[i];
-    if (threadIdx.x < kPackedWords) s_bits[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_ncand = 0;
+    for (uint32_t i = t; i < n; i += kThreads) a[i] = src[i];
+    if (t < (int)kPackedWords) s_bits[t] = 0;
+    if (t < (int)kCand) {
+        s_rank[t] = 0;
+        s_cand[t] = 0;                 // zero keys pad the list to a multiple of 8 for the ranking loop
+    }
+    if (t == 0) s_ncand = 0;
     __syncthreads();
 
-    haar_lines(a, tmp, kRowsPerFrame, bands, bands, 1, root_bands);                          // every row (Frame.m:114-116)
-    haar_lines(a, tmp, bands, kRowsPerFrame, 1, bands, __fsqrt_rn((float)kRowsPerFrame));    // every column (:118-131); folded
+    haar_lines(a, b, tmp, kRowsPerFrame, bands, bands, 1, root_bands);                          // every row (Frame.m:114-116)
+    haar_lines(b, a, tmp, bands, kRowsPerFrame, 1, bands, __fsqrt_rn((float)kRowsPerFrame));    // every column (:118-131); folded
 
     if (haar_out) {
         float* dst = haar_out + frame * n;
-        for (uint32_t i = threadIdx.x; i < n; i += kThreads) dst[i] = a[i];
+        for (uint32_t i = t; i < n; i += kThreads) dst[i] = a[i];
     }
+
+    // this thread's coefficients: flat index t + 256 j; a slot past the frame gets key 0 and is never selected
+    float v[PER];
+    uint32_t key[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t idx = (uint32_t)t + 256u * j;
+        v[j] = idx < n ? a[idx] : 0.0f;
+        key[j] = __float_as_uint(v[j]) & 0x7fffffffu;
+    }
+    auto block_count = [&](auto pred, int parity) -> uint32_t {
+        // per-wave counts are scalar popcounts of lane masks; one LDS word per wave, double-buffered
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) c += (uint32_t)__popcll(__ballot(pred(j)));
+        uint32_t* slot = s_red + 4 * parity;
+        if ((t & 63) == 0) slot[t >> 6] = c;
+        __syncthreads();
+        return slot[0] + slot[1] + slot[2] + slot[3];
+    };
 
     // ---- threshold search on key = |v| bits ------------------------------------------------
     uint32_t lo = 0, hi = 0x80000000u;  // count(key >= lo) >= keep > count(key >= hi)
     uint32_t cnt_lo = n;
     uint32_t idx_bound = n;             // among key == lo only flat indices < idx_bound are candidates
-    if (n > kCandMax) {
-        while (cnt_lo > kCandMax && hi - lo > 1) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            uint32_t c = 0;
-            for (uint32_t i = threadIdx.x; i < n; i += kThreads)
-                c += ((__float_as_uint(a[i]) & 0x7fffffffu) >= mid) ? 1u : 0u;
-            c = block_sum(c, s_red);
-            if (c >= keep) { lo = mid; cnt_lo = c; } else { hi = mid; }
+    int parity = 0;
+    while (cnt_lo > kCand && hi - lo > 1) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);     // >= 1: the padding keys never count
+        const uint32_t c = block_count([&](int j) { return key[j] >= mid; }, parity);
+        parity ^= 1;
+        if (c >= keep) { lo = mid; cnt_lo = c; } else { hi = mid; }
+    }
+    if (cnt_lo > kCand) {
+        // plateau: more than kCand coefficients share the threshold key `lo`.  Take every
+        // key > lo, and of the equal ones the lowest flat indices until `keep` is reached.
+        const uint32_t g = block_count([&](int j) { return key[j] > lo; }, parity);
+        parity ^= 1;
+        uint32_t ilo = 0, ihi = n;      // smallest bound with g + ties(idx < bound) >= keep
+        while (ilo < ihi) {
+            const uint32_t im = ilo + ((ihi - ilo) >> 1);
+            const uint32_t c = block_count([&](int j) { return key[j] == lo && (uint32_t)t + 256u * j < im && (uint32_t)t + 256u * j < n; }, parity);
+            parity ^= 1;
+            if (g + c >= keep) ihi = im; else ilo = im + 1;
         }
-        if (cnt_lo > kCandMax) {
-            // plateau: more than kCandMax coefficients share the threshold key `lo`.  Take every
-            // key > lo, and of the equal ones the lowest flat indices until `keep` is reached.
-            uint32_t g = 0;
-            for (uint32_t i = threadIdx.x; i < n; i += kThreads)
-                g += ((__float_as_uint(a[i]) & 0x7fffffffu) > lo) ? 1u : 0u;
-            g = block_sum(g, s_red);
-            uint32_t ilo = 0, ihi = n;  // smallest bound with g + ties(idx < bound) >= keep
-            while (ilo < ihi) {
-                const uint32_t im = ilo + ((ihi - ilo) >> 1);
-                uint32_t c = 0;
-                for (uint32_t i = threadIdx.x; i < n && i < im; i += kThreads)
-                    c += ((__float_as_uint(a[i]) & 0x7fffffffu) == lo) ? 1u : 0u;
-                c = block_sum(c, s_red);
-                if (g + c >= keep) ihi = im; else ilo = im + 1;
-            }
-            idx_bound = ilo;
-        }
+        idx_bound = ilo;
     }
 
-    // ---- gather candidates -----------------------------------------------------------------
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
-        const uint32_t key = __float_as_uint(a[i]) & 0x7fffffffu;
-        if (key > lo || (key == lo && i < idx_bound)) {
-            const uint32_t at = atomicAdd(&s_ncand, 1u);
-            s_ckey[at] = key;
-            s_cidx[at] = i;
+    // ---- gather candidates: composite = key << 15 | (8191 - idx) << 2 | sign code; one LDS atomic per wave ----
+    {
+        uint32_t wave_total = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t idx = (uint32_t)t + 256u * j;
+            const bool sel = idx < n && (key[j] > lo || (key[j] == lo && idx < idx_bound));
+            wave_total += (uint32_t)__popcll(__ballot(sel));
+        }
+        uint32_t base = 0;
+        if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t idx = (uint32_t)t + 256u * j;
+            const bool sel = idx < n && (key[j] > lo || (key[j] == lo && idx < idx_bound));
+            const unsigned long long m = __ballot(sel);
+            if (sel) {
+                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                const uint32_t sg = v[j] > 0.0f ? 1u : (v[j] < 0.0f ? 2u : 0u);
+                s_cand[at] = ((unsigned long long)key[j] << 15) | ((unsigned long long)(8191u - idx) << 2) | sg;
+            }
+            base += (uint32_t)__popcll(m);
         }
     }
     __syncthreads();
-    const uint32_t nc = s_ncand;
+    const uint32_t nc = s_ncand;       // <= kCand (n <= kCand: the whole frame)
 
-    // ---- rank candidates among themselves, emit sign pairs in rank order (Frame.m:182-190) ----
-    if (threadIdx.x < nc) {
-        const uint32_t mk = s_ckey[threadIdx.x], mi = s_cidx[threadIdx.x];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < nc; ++j) {
-            const uint32_t k = s_ckey[j], ii = s_cidx[j];
-            rank += (k > mk || (k == mk && ii < mi)) ? 1u : 0u;
+    // ---- rank (ties: lower flat index first, Frame.m:176-178 on a stable sort): 2 threads per candidate ----
+    {
+        const uint32_t i = t & 127, part = t >> 7;
+        if (i < nc) {
+            const unsigned long long mine = s_cand[i];
+            const uint32_t nblk = (nc + 7) >> 3, hblk = (nblk + 1) >> 1;
+            const uint32_t b0 = part ? hblk : 0, b1 = part ? nblk : hblk;
+            uint32_t r = 0;
+            for (uint32_t blk = b0; blk < b1; ++blk) {
+                const ulonglong2* q = reinterpret_cast<const ulonglong2*>(s_cand + 8 * blk);
+                const ulonglong2 c0 = q[0], c1 = q[1], c2 = q[2], c3 = q[3];
+                r += (c0.x > mine ? 1u : 0u) + (c0.y > mine ? 1u : 0u) + (c1.x > mine ? 1u : 0u) + (c1.y > mine ? 1u : 0u) +
+                     (c2.x > mine ? 1u : 0u) + (c2.y > mine ? 1u : 0u) + (c3.x > mine ? 1u : 0u) + (c3.y > mine ? 1u : 0u);
+            }
+            if (r) atomicAdd(&s_rank[i], r);
         }
+    }
+    __syncthreads();
+    if (t < (int)nc) {                 // sign pairs in rank order (Frame.m:182-190)
+        const uint32_t rank = s_rank[t];
         if (rank < keep) {
-            const float v = a[mi];
+            const uint32_t sg = (uint32_t)s_cand[t] & 3u;
             const uint32_t bpos = 2 * rank;
-            if (v > 0.0f) {
-                atomicOr(&s_bits[bpos >> 5], 1u << (bpos & 31));
-            } else if (v < 0.0f && bpos + 1 < subfp_len) {
-                atomicOr(&s_bits[(bpos + 1) >> 5], 1u << ((bpos + 1) & 31));
-            }
+            if (sg == 1u) atomicOr(&s_bits[bpos >> 5], 1u << (bpos & 31));
+            else if (sg == 2u && bpos + 1 < subfp_len) atomicOr(&s_bits[(bpos + 1) >> 5], 1u << ((bpos + 1) & 31));
         }
     }
     __syncthreads();
-    if (threadIdx.x < kPackedWords) packed[frame * kPackedWords + threadIdx.x] = s_bits[threadIdx.x];
+    if (t < (int)kPackedWords) packed[frame * kPackedWords + t] = s_bits[t];
 }
 
 }  // namespace
@@ -166,10 +221,22 @@ hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_fram
                               float* d_haar_out, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)2 * kRowsPerFrame * plan.bands * sizeof(float);
-    hipLaunchKernelGGL(haar_select_kernel, dim3((uint32_t)n_frames), dim3(kThreads), lds, stream, d_frames,
-                       plan.bands, std::sqrt((float)plan.bands), plan.keep, plan.subfp_len, d_packed, d_haar_out);
-    return hipGetLastError();
+    const size_t lds = (size_t)(5 * kRowsPerFrame * plan.bands / 2) * sizeof(float);      // frame, row-pass result, running sums
+    const uint32_t per = (kRowsPerFrame * plan.bands + kThreads - 1) / kThreads;
+    if (plan.keep > kCand || per > 32) return hipErrorInvalidValue;
+    auto launch = [&](auto kern) -> hipError_t {
+        static PerDevice attr;
+        if (attr.changed(lds) && lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((uint32_t)n_frames), dim3(kThreads), lds, stream, d_frames, plan.bands,
+                           std::sqrt((float)plan.bands), plan.keep, plan.subfp_len, d_packed, d_haar_out);
+        return hipGetLastError();
+    };
+    if (per <= 8) return launch(haar_select_kernel<8>);
+    if (per <= 16) return launch(haar_select_kernel<16>);
+    return launch(haar_select_kernel<32>);
 }
 
 }  // namespace lbad
