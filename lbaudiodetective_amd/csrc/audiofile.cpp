@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <system_error>
+#include <thread>
 
 namespace lbad {
 namespace {
@@ -274,20 +276,46 @@ bool resample(const std::vector<float>& in, double rate_in, double rate_out, uin
         table[i] = cutoff * (a < 1e-12 ? 1.0 : std::sin(a) / a) * win;
     }
     const double half = zero_crossings * scale;              // kernel half-width in input samples
-    for (uint64_t n = 0; n < n_out; ++n) {
-        const double pos = (double)n * ratio;
-        const long k0 = (long)std::ceil(pos - half), k1 = (long)std::floor(pos + half);
-        double acc = 0.0, wsum = 0.0;
-        for (long k = k0; k <= k1; ++k) {
-            const double t = std::fabs(((double)k - pos) / scale) * res;   // table coordinate
-            const size_t i = (size_t)t;
-            if (i + 1 >= table.size()) continue;
-            const double w = table[i] + (table[i + 1] - table[i]) * (t - (double)i);
-            wsum += w;
-            if (k >= 0 && (size_t)k < in.size()) acc += w * (double)in[(size_t)k];
+    // every output sample is independent: long inputs are split over the host's cores (same arithmetic per
+    // sample, so the result does not depend on the split)
+    auto span = [&](uint64_t n_begin, uint64_t n_end) {
+        for (uint64_t n = n_begin; n < n_end; ++n) {
+            const double pos = (double)n * ratio;
+            const long k0 = (long)std::ceil(pos - half), k1 = (long)std::floor(pos + half);
+            double acc = 0.0, wsum = 0.0;
+            for (long k = k0; k <= k1; ++k) {
+                const double t = std::fabs(((double)k - pos) / scale) * res;   // table coordinate
+                const size_t i = (size_t)t;
+                if (i + 1 >= table.size()) continue;
+                const double w = table[i] + (table[i + 1] - table[i]) * (t - (double)i);
+                wsum += w;
+                if (k >= 0 && (size_t)k < in.size()) acc += w * (double)in[(size_t)k];
+            }
+            out[n] = (float)(wsum != 0.0 ? acc / wsum : 0.0);
         }
-        out[n] = (float)(wsum != 0.0 ? acc / wsum : 0.0);
+    };
+    const double taps = (double)n_out * (2.0 * half + 1.0);
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers > 16) workers = 16;
+    if (taps < 2e6 || workers < 2) {
+        span(0, n_out);
+        return true;
     }
+    std::vector<std::thread> pool;
+    const uint64_t per = (n_out + workers - 1) / workers;
+    uint64_t next = per < n_out ? per : n_out;               // [0, next) is this thread's; first range not handed out
+    try {
+        for (unsigned w = 1; w < workers && next < n_out; ++w) {
+            const uint64_t e = next + per < n_out ? next + per : n_out;
+            pool.emplace_back(span, next, e);
+            next = e;
+        }
+    } catch (const std::system_error&) {
+        // no more threads to be had: this one does what is left
+    }
+    span(0, per < n_out ? per : n_out);
+    if (next < n_out) span(next, n_out);
+    for (std::thread& th : pool) th.join();
     return true;
 }
 
