@@ -277,6 +277,41 @@ static OSStatus fingerprint_clips_host(LBAudioDetective* d, const void* clips, u
     return noErr;
 }
 
+// The file front end's converter on the device (k_resample.hip): host samples in, host samples out, identical to
+// lbad::resample() on the same input.  The two kernel tables are uploaded once per detective.
+static OSStatus resample_on_device(LBAudioDetective* d, const std::vector<float>& in, double rate_in, double rate_out,
+                                   uint32_t mode, std::vector<float>& out) {
+    out.clear();
+    ResamplePlan rp;
+    if (!resample_plan(in.size(), rate_in, rate_out, mode, rp)) return kLBAudioDetectiveArgumentInvalid;
+    if (in.empty()) return noErr;
+    if (rp.copy) { out = in; return noErr; }
+    out.resize(rp.n_out);
+    if (rp.n_out == 0) return noErr;
+    OSStatus st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, in.size() * sizeof(float));
+    if (st != noErr) return st;
+    st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, rp.n_out * sizeof(float));
+    if (st != noErr) return st;
+    if (!d->io_stream) LBAD_HIP(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking));
+    hipStream_t stream = d->io_stream;
+    const double* d_table = nullptr;
+    uint64_t table_n = 0;
+    if (mode < 2) {
+        table_n = rp.table->size();
+        if (!d->d_rs_table[mode]) {
+            LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d->d_rs_table[mode]), table_n * sizeof(double)));
+            LBAD_HIP(hipMemcpyAsync(d->d_rs_table[mode], rp.table->data(), table_n * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
+        d_table = d->d_rs_table[mode];
+    }
+    LBAD_HIP(hipMemcpyAsync(d->d_rs_in, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice, stream));
+    LBAD_HIP(launch_resample(static_cast<const float*>(d->d_rs_in), in.size(), mode, rp.ratio, rp.scale, rp.half, rp.table_res,
+                             d_table, table_n, static_cast<float*>(d->d_rs_out), rp.n_out, stream));
+    LBAD_HIP(hipMemcpyAsync(out.data(), d->d_rs_out, rp.n_out * sizeof(float), hipMemcpyDeviceToHost, stream));
+    LBAD_HIP(hipStreamSynchronize(stream));
+    return noErr;
+}
+
 // :297-298,326-328 -- New(0), then the length is fixed when the first sub-fingerprint arrives
 static LBAudioDetectiveFingerprintRef fingerprint_from_bools(const LBAudioDetective* d, const Boolean* bools, uint64_t per) {
     LBAudioDetectiveFingerprintRef fp = LBAudioDetectiveFingerprintNew(0);
@@ -319,6 +354,10 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->d_io_pcm) (void)hipFree(inDetective->d_io_pcm);
     if (inDetective->d_io_packed) (void)hipFree(inDetective->d_io_packed);
     if (inDetective->h_io) (void)hipHostFree(inDetective->h_io);
+    if (inDetective->d_rs_in) (void)hipFree(inDetective->d_rs_in);
+    if (inDetective->d_rs_out) (void)hipFree(inDetective->d_rs_out);
+    for (double* t : inDetective->d_rs_table)
+        if (t) (void)hipFree(t);
     if (inDetective->io_stream) (void)hipStreamDestroy(inDetective->io_stream);
     for (hipEvent_t e : inDetective->ev) (void)hipEventDestroy(e);
     delete inDetective;
@@ -638,7 +677,8 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetective
     const double rate = d->format.mSampleRate;
     if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
     // ExtAudioFile converts to the client format (:229); here: decode on the host, then resample
-    if (!lbad::resample(file, file_rate, rate, d->resampler, mono)) return kLBAudioDetectiveArgumentInvalid;
+    st = lbad::resample_on_device(d, file, file_rate, rate, d->resampler, mono);
+    if (st != noErr) return st;
     if (d->hop_mode == 0) return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
 
     // hop_mode 1 -- what upstream does: the length (:236) and the seek offsets (:287-288) are

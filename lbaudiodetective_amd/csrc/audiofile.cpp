@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <system_error>
 #include <thread>
 
@@ -241,15 +242,56 @@ double bessel_i0(double x) {
 }
 }  // namespace
 
-bool resample(const std::vector<float>& in, double rate_in, double rate_out, uint32_t mode, std::vector<float>& out) {
-    out.clear();
+bool resample_plan(uint64_t n_in, double rate_in, double rate_out, uint32_t mode, ResamplePlan& plan) {
+    plan = ResamplePlan();
     if (mode > 2 || !(rate_in > 0.0) || !(rate_out > 0.0) || !std::isfinite(rate_in) || !std::isfinite(rate_out))
         return false;
     const double ratio = rate_in / rate_out;                 // input samples per output sample
     if (!(ratio >= 1.0 / 4096.0) || !(ratio <= 4096.0)) return false;
+    plan.mode = mode;
+    plan.ratio = ratio;
+    if (n_in == 0) return true;
+    if (rate_in == rate_out) {
+        plan.copy = true;
+        plan.n_out = n_in;
+        return true;
+    }
+    plan.n_out = (uint64_t)((double)n_in / ratio);
+    if (mode == 2) return true;
+    plan.scale = ratio > 1.0 ? ratio : 1.0;                  // kernel is stretched when decimating
+    const double cutoff = mode == 0 ? 0.92 : 1.0;
+    const int zero_crossings = mode == 0 ? 24 : 4;
+    const double beta = mode == 0 ? 9.0 : 3.0, i0b = bessel_i0(beta);
+    // kernel sampled 2048 times per unit of t in [0, zero_crossings], read with linear interpolation; the two
+    // tables are built once per process (4 ms for the long one)
+    const int res = 2048;
+    static std::vector<double> tables[2];
+    static std::once_flag built[2];
+    std::call_once(built[mode], [&] {
+        std::vector<double>& tb = tables[mode];
+        tb.resize((size_t)zero_crossings * res + 2);
+        for (size_t i = 0; i < tb.size(); ++i) {
+            const double t = (double)i / res;
+            const double u = t / zero_crossings;
+            const double win = u < 1.0 ? bessel_i0(beta * std::sqrt(1.0 - u * u)) / i0b : 0.0;
+            const double a = M_PI * cutoff * t;
+            tb[i] = cutoff * (a < 1e-12 ? 1.0 : std::sin(a) / a) * win;
+        }
+    });
+    plan.table = &tables[mode];
+    plan.table_res = res;
+    plan.half = zero_crossings * plan.scale;                 // kernel half-width in input samples
+    return true;
+}
+
+bool resample(const std::vector<float>& in, double rate_in, double rate_out, uint32_t mode, std::vector<float>& out) {
+    out.clear();
+    ResamplePlan plan;
+    if (!resample_plan(in.size(), rate_in, rate_out, mode, plan)) return false;
     if (in.empty()) return true;
-    if (rate_in == rate_out) { out = in; return true; }
-    const uint64_t n_out = (uint64_t)((double)in.size() / ratio);
+    if (plan.copy) { out = in; return true; }
+    const double ratio = plan.ratio;
+    const uint64_t n_out = plan.n_out;
     out.resize(n_out);
     if (mode == 2) {
         for (uint64_t n = 0; n < n_out; ++n) {
@@ -261,21 +303,10 @@ bool resample(const std::vector<float>& in, double rate_in, double rate_out, uin
         }
         return true;
     }
-    const double scale = ratio > 1.0 ? ratio : 1.0;          // kernel is stretched when decimating
-    const double cutoff = mode == 0 ? 0.92 : 1.0;
-    const int zero_crossings = mode == 0 ? 24 : 4;
-    const double beta = mode == 0 ? 9.0 : 3.0, i0b = bessel_i0(beta);
-    // kernel sampled 2048 times per unit of t in [0, zero_crossings], read with linear interpolation
-    const int res = 2048;
-    std::vector<double> table((size_t)zero_crossings * res + 2);
-    for (size_t i = 0; i < table.size(); ++i) {
-        const double t = (double)i / res;
-        const double u = t / zero_crossings;
-        const double win = u < 1.0 ? bessel_i0(beta * std::sqrt(1.0 - u * u)) / i0b : 0.0;
-        const double a = M_PI * cutoff * t;
-        table[i] = cutoff * (a < 1e-12 ? 1.0 : std::sin(a) / a) * win;
-    }
-    const double half = zero_crossings * scale;              // kernel half-width in input samples
+    const double scale = plan.scale;
+    const int res = plan.table_res;
+    const std::vector<double>& table = *plan.table;
+    const double half = plan.half;
     // every output sample is independent: long inputs are split over the host's cores (same arithmetic per
     // sample, so the result does not depend on the split)
     auto span = [&](uint64_t n_begin, uint64_t n_end) {

@@ -10,4 +10,18 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
 // Sample-rate conversion (documented stand-ins for Apple's converter): mode 0 long Kaiser sinc, 1 short
 // sinc, 2 linear interpolation.  False for an unknown mode or a rate ratio outside [1/4096, 4096].
 bool resample(const std::vector<float>& in, double rate_in, double rate_out, uint32_t mode, std::vector<float>& out);
+
+// What resample() evaluates, for the device version of the same arithmetic (k_resample.hip): output sample n is
+// taken at input position n * ratio; modes 0 / 1 sum the inputs within `half` samples of it, weighted by the
+// kernel table (`table_res` entries per unit of |k - pos| / scale, linear interpolation) and normalised by the sum
+// of the weights; mode 2 interpolates linearly.  `copy`: the rates are equal, the output is the input.
+struct ResamplePlan {
+    uint32_t mode = 0;
+    bool copy = false;
+    uint64_t n_out = 0;
+    double ratio = 1.0, scale = 1.0, half = 0.0;
+    int table_res = 0;
+    const std::vector<double>* table = nullptr;   // process-lifetime storage
+};
+bool resample_plan(uint64_t n_in, double rate_in, double rate_out, uint32_t mode, ResamplePlan& plan);
 }  // namespace lbad

@@ -122,6 +122,10 @@ hipError_t launch_file_tail(const Plan& plan, const float* d_pcm, uint64_t n_cli
                             uint32_t n_tail, const uint32_t* d_tbl, float* d_frames, hipStream_t stream);
 
 // generic matrix ops behind the Frame API
+// the file front end's sample-rate converter (k_resample.hip): audiofile.cpp's resample(), same arithmetic
+hipError_t launch_resample(const float* d_in, uint64_t n_in, uint32_t mode, double ratio, double scale, double half,
+                           int res, const double* d_table, uint64_t table_n, float* d_out, uint64_t n_out,
+                           hipStream_t stream);
 hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream);
 hipError_t launch_extract_generic(const float* d_m, uint32_t n, uint32_t n_wavelets, uint8_t* d_out,
                                   hipStream_t stream);
@@ -208,6 +212,12 @@ struct LBAudioDetective {
     void* h_io = nullptr;        // pinned staging for small calls
     size_t h_io_cap = 0;
     hipStream_t io_stream = nullptr;
+    // converter state of the file entry points: input / output samples and the two kernel tables, grown on demand
+    void* d_rs_in = nullptr;
+    size_t d_rs_in_cap = 0;
+    void* d_rs_out = nullptr;
+    size_t d_rs_out_cap = 0;
+    double* d_rs_table[2] = {nullptr, nullptr};
     // optional per-stage timing (hipEvents on the caller's stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2
