@@ -110,7 +110,8 @@ OSStatus LBAudioDetectiveSetWindowSize(LBAudioDetectiveRef inDetective, UInt32 i
 OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef inDetective, UInt32 inAnalysisStride); /* D.h:194 */
 /* File front end replacing ExtAudioFile: CAF ('lpcm' or Apple 'ima4') and RIFF/WAVE (PCM, IEEE
  * float), channels averaged to mono, converted to the processing sample rate by a documented
- * windowed-sinc resampler (Apple's converter is closed source), then fingerprinted on the GPU.
+ * windowed-sinc resampler (Apple's converter is closed source; decode on the host, conversion and
+ * everything after it on the GPU), then fingerprinted.
  * Other payloads return kLBAudioDetectiveUnsupportedFile, a missing file -43 (fnfErr). */
 OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint); /* D.h:218 */
@@ -192,7 +193,8 @@ OSStatus LBAudioDetectiveSetFileTailMode(LBAudioDetectiveRef inDetective, UInt32
  * 24 zero crossings, cut-off 0.92 Nyquist; 1 short sinc (4 zero crossings, cut-off at Nyquist: leaky);
  * 2 linear interpolation (no anti-alias filter). */
 OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef inDetective, UInt32 inMode);
-/* Decode a file to mono float32, optionally converted to inSampleRate (0 = keep the file's rate).
+/* Decode a file to mono float32, optionally converted to inSampleRate (0 = keep the file's rate): host code
+ * (no detective, no device), the samples LBAudioDetectiveProcessAudioURL's device converter produces.
  * The buffer is owned by the caller and released with LBAudioDetectiveFreeSamples. */
 OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
                                       UInt64* outCount, Float64* outSampleRate);
