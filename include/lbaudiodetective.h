@@ -255,7 +255,7 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective,
 /* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band count),
  * 2 = specialised kernels only (stride 64: pruned 1024-point FFT for bands that read only bins 0..21; streaming
  * 2048- / 4096-point kernels that share the early FFT stages between consecutive windows (clips that start on 8-byte boundaries: an even clip length or a single clip,
- * <= 32 bands); register-resident 1024- / 2048-point FFT for any other band table; register Haar / select for
+ * <= 32 bands); register-resident FFT of 256- to 2048-sample windows for any other band table; register Haar / select for
  * 128 x 32 frames) -- ArgumentInvalid when the configuration has no specialised stage-1 kernel; 3 = like 2 but
  * the register-resident 2048-point kernel instead of the streaming one (measurement). */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);

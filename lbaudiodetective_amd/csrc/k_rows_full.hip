@@ -235,9 +235,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     const int adj_a = r == 0 ? 32 - 32 * L : 0;      // pairs u >= L/2 of slot 0 are bins 32 + 64 (u - L/2)
     const int adj_b = r == 0 ? N / 2 : 0;            // pair 0 of slot 0: partner bin N/2 instead of N
 
-    float out[WPW];                  // band means of the previous unit, stored one iteration late
+    constexpr bool kLateStore = WPW <= 8;
+    float out[kLateStore ? WPW : 1];  // band means of the previous unit, stored one iteration late
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) out[i] = 0.0f;
+    for (int i = 0; i < (kLateStore ? WPW : 1); ++i) out[i] = 0.0f;
     float* out_base = nullptr;
     for (;;) {
     // ---- A: this unit's span has landed (own loads: vmcnt, the other waves': barrier) -------------------
@@ -258,9 +259,9 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     __syncthreads();
     if (next < xcd_end) span_to_lds<LOG2L, FMT>(pcm_raw, span_start(next), span, wave, lane);
     if (part == 0 && claimer) claimed = atomicAdd(my_ctr, 1u);
-    if (out_base) {
+    if (kLateStore && out_base) {
 #pragma unroll
-        for (int i = 0; i < WPW; ++i)
+        for (int i = 0; i < (kLateStore ? WPW : 1); ++i)
             if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
     }
     __builtin_amdgcn_s_setprio(0);     // arithmetic-heavy phase: let the co-resident wave's LDS work go first
@@ -341,13 +342,18 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         // keeps the outputs of all passes alive at once (several hundred bytes of scratch)
 #pragma unroll
         for (int i = 0; i < 2 * L; ++i) asm volatile("" : "+v"(pw[Q][i]));
+        // 512- / 256-sample windows have 8 / 16 slots of 4 / 2 values: without a hard fence the scheduler runs the
+        // transposes of several slots ahead of their split passes and spills
+        if constexpr (L <= 4) __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (R >= 2) slot_work(std::integral_constant<int, 0>{});
-    if constexpr (R >= 4) slot_work(std::integral_constant<int, 1>{});
-    if constexpr (R >= 8) {
-        slot_work(std::integral_constant<int, 2>{});
-        slot_work(std::integral_constant<int, 3>{});
-    }
+    auto all_slots = [&](auto self, auto q_tag) {
+        constexpr int Q = decltype(q_tag)::value;
+        if constexpr (Q < R / 2) {
+            slot_work(q_tag);
+            self(self, std::integral_constant<int, Q + 1>{});
+        }
+    };
+    all_slots(all_slots, std::integral_constant<int, 0>{});
 
     // ---- D: power terms -> LDS (every read of the last pass has returned: the values are in
     //         registers), band means in bin order -----------------------------------------------------
@@ -376,9 +382,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // (wave-local: LDS operations of one wave execute in order)
     // task t = lane + 64 i -> window t / nbands of the wave, band t % nbands; rows of a wave's windows are
     // consecutive, so the task's float sits at out_base[t]
-#pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-        const uint32_t t = lane + 64 * i;
+    auto band_mean = [&](uint32_t t) -> float {
         float p = 0.0f;
         float div = 1.0f;
         if (t < WPW * nbands) {
@@ -406,15 +410,26 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
                 for (uint32_t q = 0; q < 7; ++q) p = __fadd_rn(p, q < rem ? v[q] : 0.0f);
             }
         }
-        out[i] = __fdiv_rn(p, div);
+        return __fdiv_rn(p, div);
+    };
+    if constexpr (kLateStore) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) out[i] = band_mean(lane + 64 * i);
+    } else {
+        // 16 / 32 windows per wave (512- / 256-sample windows): the means would hold 16 / 32 registers through the
+        // next unit's FFT; they are stored at once instead
+        float* rows = frames + ((unit / kUnitsPerFrame) * 128 + part * S::UW + wave * WPW) * nbands;
+        for (uint32_t t = lane; t < WPW * nbands; t += 64) rows[t] = band_mean(t);
     }
     out_base = frames + ((unit / kUnitsPerFrame) * 128 + part * S::UW + wave * WPW) * nbands;
     if (next >= xcd_end) break;
     unit = next;
     }
+    if constexpr (kLateStore) {
 #pragma unroll
-    for (int i = 0; i < WPW; ++i)
-        if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
+        for (int i = 0; i < WPW; ++i)
+            if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
+    }
 }
 
 template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax) {
@@ -467,14 +482,17 @@ hipError_t launch_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64
 // bit-identical to the run-time master table and the LDS budget must allow two workgroups per CU
 bool rows_full_supported(const Plan& p) {
     if (p.stride != (uint32_t)kStride || p.bands > 64 || p.bands == 0) return false;
-    if (p.window != 1024 && p.window != 2048) return false;
+    if (p.window != 256 && p.window != 512 && p.window != 1024 && p.window != 2048) return false;
     if (p.table.kmax <= p.table.kmin) return false;
     std::vector<float> re, im;
     make_twiddles(p.window, re, im);
     const uint32_t step = p.window / 64;
     for (int t = 0; t < 32; ++t)
         if (re[step * t] != kTw64Re[t] || im[step * t] != kTw64Im[t]) return false;
-    const size_t lds = p.window == 1024 ? lds_bytes<3>(p.table.kmin, p.table.kmax) : lds_bytes<4>(p.table.kmin, p.table.kmax);
+    const size_t lds = p.window == 256    ? lds_bytes<1>(p.table.kmin, p.table.kmax)
+                       : p.window == 512  ? lds_bytes<2>(p.table.kmin, p.table.kmax)
+                       : p.window == 1024 ? lds_bytes<3>(p.table.kmin, p.table.kmax)
+                                          : lds_bytes<4>(p.table.kmin, p.table.kmax);
     return lds <= 80 * 1024;
 }
 
@@ -483,6 +501,8 @@ hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, u
     const uint64_t n_frames = n_clips * frames_per_clip;
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7ffffffull) return hipErrorInvalidValue;
+    if (plan.window == 256) return launch_full<1>(plan, d_pcm, fmt, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+    if (plan.window == 512) return launch_full<2>(plan, d_pcm, fmt, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
     if (plan.window == 1024) return launch_full<3>(plan, d_pcm, fmt, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
     return launch_full<4>(plan, d_pcm, fmt, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
 }

@@ -67,8 +67,8 @@ CONFIGS = {
     "bands_11": dict(sample_rate=16000, window=512, stride=64, bands=11, subfp_len=64),
 }
 # configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, C -> k_rows_stream.hip, A -> k_rows_stream2.hip,
-# the others -> k_rows_full.hip
-SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64", "C_48k_4096"}
+# the others (stride 64, 256 .. 2048 samples) -> k_rows_full.hip
+SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64", "C_48k_4096", "tiny_bands", "bands_11"}
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))

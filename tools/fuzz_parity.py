@@ -14,8 +14,8 @@ bad = 0
 t0 = time.time()
 for t in range(trials):
     kind = rng.integers(0, 9)
-    if kind == 1:      # stride 64 with 1024- / 2048-sample windows: k_rows_full.hip, or k_rows_stream2.hip (2048, even length, <= 32 bands)
-        cfg = O.Config(float(rng.choice([5512, 8000, 11025, 16000, 22050, 32000, 44100, 48000])), int(rng.choice([1024, 2048])),
+    if kind == 1:      # stride 64 with 256- .. 2048-sample windows: k_rows_full.hip, or k_rows_stream2.hip (2048, even length, <= 32 bands)
+        cfg = O.Config(float(rng.choice([5512, 8000, 11025, 16000, 22050, 32000, 44100, 48000])), int(rng.choice([256, 512, 1024, 2048])),
                        64, int(rng.integers(1, 65)), 1)
         cfg.subfp_len = int(rng.integers(1, min(256, 128 * cfg.bands) + 1))
         n = cfg.window + 64 * 128 * int(rng.integers(1, 3)) + int(rng.integers(0, 8192))
