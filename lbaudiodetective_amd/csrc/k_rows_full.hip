@@ -139,8 +139,8 @@ __device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, ui
 
 // Persistent workgroups, two per CU, as in k_rows_pruned.hip: every XCD owns a contiguous range of
 // frames, the first ones are static, the rest is claimed a frame at a time from a per-XCD counter; the
-// span of unit u + 1 streams into the span buffer as soon as every wave holds its points of unit u, and
-// the rows of u drain to HBM during u + 1.  The twiddle tables are built once per workgroup.
+// span of unit u + 1 streams into the span buffer as soon as every wave holds its points of unit u.  The
+// twiddle tables are built once per workgroup.
 template <int LOG2L, int FMT>
 __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint64_t samples_per_clip,
                                                                  uint32_t frames_per_clip, uint64_t n_units,
@@ -235,11 +235,6 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     const int adj_a = r == 0 ? 32 - 32 * L : 0;      // pairs u >= L/2 of slot 0 are bins 32 + 64 (u - L/2)
     const int adj_b = r == 0 ? N / 2 : 0;            // pair 0 of slot 0: partner bin N/2 instead of N
 
-    constexpr bool kLateStore = WPW <= 8;
-    float out[kLateStore ? WPW : 1];  // band means of the previous unit, stored one iteration late
-#pragma unroll
-    for (int i = 0; i < (kLateStore ? WPW : 1); ++i) out[i] = 0.0f;
-    float* out_base = nullptr;
     for (;;) {
     // ---- A: this unit's span has landed (own loads: vmcnt, the other waves': barrier) -------------------
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
@@ -259,11 +254,6 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     __syncthreads();
     if (next < xcd_end) span_to_lds<LOG2L, FMT>(pcm_raw, span_start(next), span, wave, lane);
     if (part == 0 && claimer) claimed = atomicAdd(my_ctr, 1u);
-    if (kLateStore && out_base) {
-#pragma unroll
-        for (int i = 0; i < (kLateStore ? WPW : 1); ++i)
-            if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
-    }
     __builtin_amdgcn_s_setprio(0);     // arithmetic-heavy phase: let the co-resident wave's LDS work go first
     stage_blocks<1, 0>(x);
     stage_blocks<2, 0>(x);
@@ -381,7 +371,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     }
     // (wave-local: LDS operations of one wave execute in order)
     // task t = lane + 64 i -> window t / nbands of the wave, band t % nbands; rows of a wave's windows are
-    // consecutive, so the task's float sits at out_base[t]
+    // consecutive, so the task's float sits at rows[t]
     auto band_mean = [&](uint32_t t) -> float {
         float p = 0.0f;
         float div = 1.0f;
@@ -412,23 +402,12 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         }
         return __fdiv_rn(p, div);
     };
-    if constexpr (kLateStore) {
-#pragma unroll
-        for (int i = 0; i < WPW; ++i) out[i] = band_mean(lane + 64 * i);
-    } else {
-        // 16 / 32 windows per wave (512- / 256-sample windows): the means would hold 16 / 32 registers through the
-        // next unit's FFT; they are stored at once instead
-        float* rows = frames + ((unit / kUnitsPerFrame) * 128 + part * S::UW + wave * WPW) * nbands;
-        for (uint32_t t = lane; t < WPW * nbands; t += 64) rows[t] = band_mean(t);
-    }
-    out_base = frames + ((unit / kUnitsPerFrame) * 128 + part * S::UW + wave * WPW) * nbands;
+    // (stored at once by a plain loop over the wave's tasks: holding the means back until the next unit's loads are
+    // out, as round 1 did, costs WPW registers through the FFT -- spills at 16 / 32 windows per wave -- and gains nothing)
+    float* rows = frames + ((unit / kUnitsPerFrame) * 128 + part * S::UW + wave * WPW) * nbands;
+    for (uint32_t t = lane; t < WPW * nbands; t += 64) rows[t] = band_mean(t);
     if (next >= xcd_end) break;
     unit = next;
-    }
-    if constexpr (kLateStore) {
-#pragma unroll
-        for (int i = 0; i < WPW; ++i)
-            if ((uint32_t)(lane + 64 * i) < WPW * nbands) out_base[lane + 64 * i] = out[i];
     }
 }
 
