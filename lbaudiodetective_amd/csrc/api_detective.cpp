@@ -118,8 +118,8 @@ struct FileTail {
 static hipError_t apply_file_tail(const Plan& p, const FileTail& t, const void* d_pcm, uint64_t rows, float* frames,
                                   hipStream_t stream) {
     if (t.first_short >= rows) return hipSuccess;
-    if (t.mode == 1)   // inNumberFrames == 0: empty band loops, 0 / width = +0.0f in every band (:382-404)
-        return hipMemsetAsync(frames + t.first_short * p.bands, 0, (rows - t.first_short) * p.bands * sizeof(float), stream);
+    if (t.mode == 1)   // inNumberFrames == 0: empty band loops, 0 / divisor in every band (:382-404): +0, NaN for a zero divisor
+        return launch_empty_rows(p, frames + t.first_short * p.bands, rows - t.first_short, stream);
     if (t.mode == 2)
         return launch_file_tail(p, static_cast<const float*>(d_pcm), t.n_client, p.stride, t.first_short,
                                 (uint32_t)(rows - t.first_short), t.d_tbl, frames, stream);

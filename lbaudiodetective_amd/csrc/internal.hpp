@@ -118,6 +118,7 @@ hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_
 
 // end-of-file chain of upstream's file loop, tail mode "stale" (k_file_tail.hip); d_tbl: per window
 // [n_read, lo[bands], hi[bands]]
+hipError_t launch_empty_rows(const Plan& p, float* d_rows, uint64_t n_rows, hipStream_t stream);
 hipError_t launch_file_tail(const Plan& plan, const float* d_pcm, uint64_t n_client, uint32_t hop, uint64_t first_short,
                             uint32_t n_tail, const uint32_t* d_tbl, float* d_frames, hipStream_t stream);
 

@@ -117,7 +117,24 @@ __global__ __launch_bounds__(kThreads) void file_tail_kernel(const float* __rest
     }
 }
 
+// Tail mode 1: a window whose read delivers nothing has inNumberFrames == 0, the band loops are empty and the row
+// is 0 / divisor in every band (LBAudioDetective.m:382-404) -- +0, or NaN for a band whose two edge indices coincide.
+__global__ __launch_bounds__(kThreads) void empty_rows_kernel(float* __restrict__ rows, uint64_t n_values, uint32_t bands,
+                                                              const uint32_t* __restrict__ band_tbl) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n_values) rows[i] = __fdiv_rn(0.0f, __uint_as_float(band_tbl[2 * bands + (uint32_t)(i % bands)]));
+}
+
 }  // namespace
+
+hipError_t launch_empty_rows(const Plan& p, float* d_rows, uint64_t n_rows, hipStream_t stream) {
+    const uint64_t n = n_rows * p.bands;
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(empty_rows_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_rows, n, p.bands, p.d_bands);
+    return hipGetLastError();
+}
 
 hipError_t launch_file_tail(const Plan& p, const float* d_pcm, uint64_t n_client, uint32_t hop, uint64_t first_short,
                             uint32_t n_tail, const uint32_t* d_tbl, float* d_frames, hipStream_t stream) {

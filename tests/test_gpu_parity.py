@@ -708,6 +708,23 @@ def test_stream_kernel_shapes(lb, gpu, oracle):
         assert np.array_equal(_fingerprint_device(lb, gpu, pcm, cfg2, variant=variant), oracle.fingerprint_batch(pcm, cfg2)), variant
 
 
+@pytest.mark.parametrize("case", [(8000.0, 128, 100, 24, 235, 50, 553, 38149), (44100.0, 512, 64, 21, 235, 23, 868, 26481),
+                                  (5512.0, 256, 100, 43, 233, 69, 630, 50412)])
+def test_file_loop_empty_rows_with_zero_divisors(lb, gpu, oracle, case):
+    """Tail mode 1 with a band table whose edge indices repeat: the rows of windows that read nothing are
+    0 / divisor (D.m:382-404), i.e. NaN where the divisor is zero, and with so many of them the NaNs decide the
+    ranking.  Found by the 150 000-trial fuzz run of round 2 (the rows used to be cleared to zero)."""
+    rate, window, stride, bands, subfp, hop, n_client, file_frames = case
+    cfg = oracle.Config(rate, window, stride, bands, 1)
+    cfg.subfp_len = subfp
+    x = oracle.synth_clip(13, 5, 44100, n_client)
+    det = lb.Detective().configure(sample_rate=rate, window=window, stride=stride, bands=bands, subfp_len=subfp)
+    det.set_file_tail_mode(1)
+    got = det.process_file_stream(x, file_frames, hop).to_bools()
+    want, raw, _ = oracle.fingerprint_file_loop(x, file_frames, hop, cfg, oracle.TAIL_NOTHING, taps=True)
+    assert np.isnan(raw).any() and got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_host_allocation_failure_is_a_status(lb, gpu, oracle):
     """Buffers sized by the caller's numbers (here 2^50 file frames to zero-pad to) fail with memFullErr instead of
     an exception crossing the C boundary; the detective keeps working."""
