@@ -5,15 +5,19 @@ import lbaudiodetective_amd._native as N
 import subprocess, os, json
 child = "--child" in sys.argv
 cfg_a = "--A" in sys.argv                                   # 5512 Hz / 2048, 20 000 nine-second clips instead
-libs = [a for a in sys.argv[1:] if a not in ("--child", "--A")] or [N.LIB_PATH]
+cfg_b = "--B" in sys.argv                                   # 44.1 kHz / 1024, 100 000 one-second clips (the bench workload)
+libs = [a for a in sys.argv[1:] if a not in ("--child", "--A", "--B")] or [N.LIB_PATH]
 if not child:
     for l in libs:
-        out = subprocess.run([sys.executable, __file__, l, "--child"] + (["--A"] if cfg_a else []), capture_output=True, text=True, timeout=120)
+        out = subprocess.run([sys.executable, __file__, l, "--child"] + (["--A"] if cfg_a else []) + (["--B"] if cfg_b else []), capture_output=True, text=True, timeout=120)
         print(os.path.basename(l), out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)
     sys.exit(0)
 N.LIB_PATH = libs[0]
 import lbaudiodetective_amd as lb
-if cfg_a:
+if cfg_b:
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    big = lb.synth_clips_device(0x4C424144, 0, 100000, 44100, 44100, False)
+elif cfg_a:
     det = lb.Detective().configure(sample_rate=5512, window=2048)
     big = lb.synth_clips_device(0x4C424144, 0, 20000, 5512, 5512 * 9, False)
 else:
