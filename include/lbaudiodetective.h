@@ -110,8 +110,8 @@ OSStatus LBAudioDetectiveSetWindowSize(LBAudioDetectiveRef inDetective, UInt32 i
 OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef inDetective, UInt32 inAnalysisStride); /* D.h:194 */
 /* File front end replacing ExtAudioFile: CAF ('lpcm' or Apple 'ima4') and RIFF/WAVE (PCM, IEEE
  * float), channels averaged to mono, converted to the processing sample rate by a documented
- * windowed-sinc resampler (Apple's converter is closed source; decode on the host, conversion and
- * everything after it on the GPU), then fingerprinted.
+ * windowed-sinc resampler (Apple's converter is closed source; the container is parsed on the host, payload
+ * decode, conversion and everything after it run on the GPU), then fingerprinted.
  * Other payloads return kLBAudioDetectiveUnsupportedFile, a missing file -43 (fnfErr). */
 OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint); /* D.h:218 */

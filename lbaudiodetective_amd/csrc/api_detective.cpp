@@ -277,23 +277,39 @@ static OSStatus fingerprint_clips_host(LBAudioDetective* d, const void* clips, u
     return noErr;
 }
 
-// The file front end's converter on the device (k_resample.hip): host samples in, host samples out, identical to
-// lbad::resample() on the same input.  The two kernel tables are uploaded once per detective.
-static OSStatus resample_on_device(LBAudioDetective* d, const std::vector<float>& in, double rate_in, double rate_out,
-                                   uint32_t mode, std::vector<float>& out) {
+// The file front end on the device: the payload's bytes go up, k_decode.hip turns them into mono float32 at the file's
+// rate, k_resample.hip converts to `rate_out`, the converted samples come back (upstream's file loop, which follows,
+// does its bookkeeping on the host).  Both kernels repeat the host functions' arithmetic (audiofile.cpp), so `out` is
+// what lbad::decode_payload + lbad::resample return for the same file.  The two kernel tables are uploaded once per
+// detective.
+static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& a, double rate_out, uint32_t mode,
+                                       std::vector<float>& out) {
     out.clear();
     ResamplePlan rp;
-    if (!resample_plan(in.size(), rate_in, rate_out, mode, rp)) return kLBAudioDetectiveArgumentInvalid;
-    if (in.empty()) return noErr;
-    if (rp.copy) { out = in; return noErr; }
+    if (!resample_plan(a.count, a.sample_rate, rate_out, mode, rp)) return kLBAudioDetectiveArgumentInvalid;
+    if (a.count == 0) return noErr;
     out.resize(rp.n_out);
     if (rp.n_out == 0) return noErr;
-    OSStatus st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, in.size() * sizeof(float));
+    OSStatus st = grow_device(&d->d_rs_bytes, &d->d_rs_bytes_cap, a.len);
     if (st != noErr) return st;
-    st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, rp.n_out * sizeof(float));
+    st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, a.total_frames * sizeof(float));
     if (st != noErr) return st;
+    if (!rp.copy) {
+        st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, rp.n_out * sizeof(float));
+        if (st != noErr) return st;
+    }
     if (!d->io_stream) LBAD_HIP(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking));
     hipStream_t stream = d->io_stream;
+    LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, a.file.data() + a.off, a.len, hipMemcpyHostToDevice, stream));
+    float* decoded = static_cast<float*>(d->d_rs_in);
+    LBAD_HIP(launch_decode((int)a.kind, static_cast<const uint8_t*>(d->d_rs_bytes), a.total_frames, a.channels, a.bits, a.is_float,
+                           a.little, decoded, stream));
+    const float* mono = decoded + a.first;                    // 'pakt' priming frames are skipped, the tail is cut by count
+    if (rp.copy) {
+        LBAD_HIP(hipMemcpyAsync(out.data(), mono, rp.n_out * sizeof(float), hipMemcpyDeviceToHost, stream));
+        LBAD_HIP(hipStreamSynchronize(stream));
+        return noErr;
+    }
     const double* d_table = nullptr;
     uint64_t table_n = 0;
     if (mode < 2) {
@@ -304,9 +320,8 @@ static OSStatus resample_on_device(LBAudioDetective* d, const std::vector<float>
         }
         d_table = d->d_rs_table[mode];
     }
-    LBAD_HIP(hipMemcpyAsync(d->d_rs_in, in.data(), in.size() * sizeof(float), hipMemcpyHostToDevice, stream));
-    LBAD_HIP(launch_resample(static_cast<const float*>(d->d_rs_in), in.size(), mode, rp.ratio, rp.scale, rp.half, rp.table_res,
-                             d_table, table_n, static_cast<float*>(d->d_rs_out), rp.n_out, stream));
+    LBAD_HIP(launch_resample(mono, a.count, mode, rp.ratio, rp.scale, rp.half, rp.table_res, d_table, table_n,
+                             static_cast<float*>(d->d_rs_out), rp.n_out, stream));
     LBAD_HIP(hipMemcpyAsync(out.data(), d->d_rs_out, rp.n_out * sizeof(float), hipMemcpyDeviceToHost, stream));
     LBAD_HIP(hipStreamSynchronize(stream));
     return noErr;
@@ -354,6 +369,7 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->d_io_pcm) (void)hipFree(inDetective->d_io_pcm);
     if (inDetective->d_io_packed) (void)hipFree(inDetective->d_io_packed);
     if (inDetective->h_io) (void)hipHostFree(inDetective->h_io);
+    if (inDetective->d_rs_bytes) (void)hipFree(inDetective->d_rs_bytes);
     if (inDetective->d_rs_in) (void)hipFree(inDetective->d_rs_in);
     if (inDetective->d_rs_out) (void)hipFree(inDetective->d_rs_out);
     for (double* t : inDetective->d_rs_table)
@@ -670,14 +686,21 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetective
                                          LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
     LBAD_GUARD_BEGIN
     if (!inFileURL) return kLBAudioDetectiveArgumentInvalid;  // :211-214
-    std::vector<float> file, mono;
-    double file_rate = 0.0;
-    OSStatus st = read_url(inFileURL, file, file_rate);
-    if (st != noErr) return st;
+#ifdef __OBJC__
+    const char* path = [[inFileURL path] fileSystemRepresentation];
+#else
+    const char* path = inFileURL;
+#endif
+    lbad::AudioPayload file;
+    const lbad::AudioFileStatus fs = lbad::parse_audio_file(path, file);
+    if (fs == lbad::AudioFileStatus::NotFound) return -43;  // fnfErr, what ExtAudioFileOpenURL reports
+    if (fs != lbad::AudioFileStatus::Ok) return kLBAudioDetectiveUnsupportedFile;
+    const double file_rate = file.sample_rate;
     const double rate = d->format.mSampleRate;
     if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
-    // ExtAudioFile converts to the client format (:229); here: decode on the host, then resample
-    st = lbad::resample_on_device(d, file, file_rate, rate, d->resampler, mono);
+    // ExtAudioFile decodes and converts to the client format (:229); here both happen on the device
+    std::vector<float> mono;
+    OSStatus st = lbad::convert_file_on_device(d, file, rate, d->resampler, mono);
     if (st != noErr) return st;
     if (d->hop_mode == 0) return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
 
@@ -686,7 +709,7 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetective
     // frames = analysisStride * rate / file_rate client samples and the window count comes from the file length.
     uint32_t hop = (uint32_t)std::llround((double)d->stride * rate / file_rate);
     if (hop < 1) hop = 1;
-    return LBAudioDetectiveProcessFileStream(d, mono.data(), mono.size(), file.size(), hop, outFingerprint);
+    return LBAudioDetectiveProcessFileStream(d, mono.data(), mono.size(), file.count, hop, outFingerprint);
     LBAD_GUARD_END
 }
 

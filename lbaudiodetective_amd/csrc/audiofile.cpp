@@ -118,10 +118,13 @@ bool decode_ima4(const uint8_t* data, size_t n_bytes, uint32_t channels, int64_t
 
 }  // namespace
 
-AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, double& sample_rate) {
+// Container parsing: which bytes of the file are the payload and how they decode.  The validity checks the
+// decoders relied on happen here, so that the host and the device decoder (k_decode.hip) see the same accepted set.
+AudioFileStatus parse_audio_file(const char* path, AudioPayload& out) {
+    out = AudioPayload();
     FILE* f = std::fopen(path, "rb");
     if (!f) return AudioFileStatus::NotFound;
-    std::vector<uint8_t> buf;
+    std::vector<uint8_t>& buf = out.file;
     std::fseek(f, 0, SEEK_END);
     const long sz = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
@@ -132,13 +135,22 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
     if (got != buf.size() || buf.size() < 12) return AudioFileStatus::Unsupported;
     const uint8_t* p = buf.data();
     const size_t n = buf.size();
+    auto pcm_ok = [&]() {
+        if (out.channels == 0 || out.bits == 0 || out.bits % 8 != 0 || out.bits > 64) return false;
+        if (out.is_float && out.bits != 32 && out.bits != 64) return false;
+        if (!out.is_float && out.bits != 8 && out.bits != 16 && out.bits != 24 && out.bits != 32) return false;
+        return true;
+    };
+    auto finish_pcm = [&]() {
+        const size_t frame = (size_t)out.channels * (out.bits / 8);
+        out.total_frames = out.len / frame;
+        out.first = 0;
+        out.count = out.total_frames;
+    };
 
     if (std::memcmp(p, "caff", 4) == 0) {
         size_t at = 8;
-        bool have_desc = false, is_float = false, little = false, ima4 = false;
-        uint32_t channels = 0, bits = 0;
-        int64_t valid_frames = -1;
-        int32_t priming = 0;
+        bool have_desc = false, ima4 = false;
         while (at + 12 <= n) {
             const uint8_t* ch = p + at;
             const int64_t csz = (int64_t)be64(ch + 4);
@@ -146,29 +158,43 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
             size_t len = csz < 0 ? n - body : (size_t)csz;
             if (body + len > n) len = n - body;
             if (std::memcmp(ch, "desc", 4) == 0 && len >= 32) {
-                sample_rate = be_f64(p + body);
+                out.sample_rate = be_f64(p + body);
                 ima4 = std::memcmp(p + body + 8, "ima4", 4) == 0;
                 if (!ima4 && std::memcmp(p + body + 8, "lpcm", 4) != 0) return AudioFileStatus::Unsupported;
                 if (ima4 && (be32(p + body + 20) != 64 || be32(p + body + 24) == 0 || be32(p + body + 24) > 64 ||
                              be32(p + body + 16) != 34u * be32(p + body + 24)))
                     return AudioFileStatus::Unsupported;
-                if (!(sample_rate > 0.0) || !std::isfinite(sample_rate)) return AudioFileStatus::Unsupported;
+                if (!(out.sample_rate > 0.0) || !std::isfinite(out.sample_rate)) return AudioFileStatus::Unsupported;
                 const uint32_t flags = be32(p + body + 12);
-                is_float = flags & 1u;
-                little = flags & 2u;
-                channels = be32(p + body + 24);
-                bits = be32(p + body + 28);
+                out.is_float = flags & 1u;
+                out.little = flags & 2u;
+                out.channels = be32(p + body + 24);
+                out.bits = be32(p + body + 28);
                 have_desc = true;
             } else if (std::memcmp(ch, "pakt", 4) == 0 && len >= 24) {
-                valid_frames = (int64_t)be64(p + body + 8);     // mNumberValidFrames
-                priming = (int32_t)be32(p + body + 16);          // mPrimingFrames
+                out.valid_frames = (int64_t)be64(p + body + 8);     // mNumberValidFrames
+                out.priming = (int32_t)be32(p + body + 16);          // mPrimingFrames
             } else if (std::memcmp(ch, "data", 4) == 0) {
                 if (!have_desc || len < 4) return AudioFileStatus::Unsupported;
-                if (ima4)
-                    return decode_ima4(p + body + 4, len - 4, channels, valid_frames, priming, mono)
-                               ? AudioFileStatus::Ok : AudioFileStatus::Unsupported;
-                return decode_pcm(p + body + 4, len - 4, channels, bits, is_float, little, mono)
-                           ? AudioFileStatus::Ok : AudioFileStatus::Unsupported;
+                out.off = body + 4;
+                out.len = len - 4;
+                if (ima4) {
+                    if (out.channels == 0) return AudioFileStatus::Unsupported;
+                    out.kind = AudioPayload::Ima4;
+                    const size_t packets = out.len / (34 * (size_t)out.channels);   // packets are interleaved per channel
+                    out.total_frames = (uint64_t)packets * 64;
+                    uint64_t first = out.priming > 0 ? (uint64_t)out.priming : 0;
+                    if (first > out.total_frames) first = out.total_frames;
+                    uint64_t count = out.total_frames - first;
+                    if (out.valid_frames > 0 && (uint64_t)out.valid_frames < count) count = (uint64_t)out.valid_frames;   // 'pakt' trims the tail
+                    out.first = first;
+                    out.count = count;
+                    return AudioFileStatus::Ok;
+                }
+                if (!pcm_ok()) return AudioFileStatus::Unsupported;
+                out.kind = AudioPayload::Pcm;
+                finish_pcm();
+                return AudioFileStatus::Ok;
             }
             at = body + len;
         }
@@ -177,8 +203,7 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
 
     if (std::memcmp(p, "RIFF", 4) == 0 && std::memcmp(p + 8, "WAVE", 4) == 0) {
         size_t at = 12;
-        bool have_fmt = false, is_float = false;
-        uint32_t channels = 0, bits = 0;
+        bool have_fmt = false;
         while (at + 8 <= n) {
             const uint8_t* ch = p + at;
             size_t len = le32(ch + 4);
@@ -186,36 +211,61 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
             if (body + len > n) len = n - body;
             if (std::memcmp(ch, "fmt ", 4) == 0 && len >= 16) {
                 uint16_t tag = le16(p + body);
-                channels = le16(p + body + 2);
-                sample_rate = (double)le32(p + body + 4);
-                if (!(sample_rate > 0.0)) return AudioFileStatus::Unsupported;
-                bits = le16(p + body + 14);
+                out.channels = le16(p + body + 2);
+                out.sample_rate = (double)le32(p + body + 4);
+                if (!(out.sample_rate > 0.0)) return AudioFileStatus::Unsupported;
+                out.bits = le16(p + body + 14);
                 if (tag == 0xFFFE && len >= 26) tag = le16(p + body + 24);  // WAVE_FORMAT_EXTENSIBLE
                 if (tag != 1 && tag != 3) return AudioFileStatus::Unsupported;
-                is_float = tag == 3;
+                out.is_float = tag == 3;
+                out.little = true;
                 have_fmt = true;
             } else if (std::memcmp(ch, "data", 4) == 0) {
                 if (!have_fmt) return AudioFileStatus::Unsupported;
-                // 8-bit WAV is unsigned
-                if (!is_float && bits == 8) {
-                    if (channels == 0) return AudioFileStatus::Unsupported;
-                    const size_t frames = len / channels;
-                    mono.resize(frames);
-                    for (size_t i = 0; i < frames; ++i) {
-                        double acc = 0;
-                        for (uint32_t c = 0; c < channels; ++c) acc += ((int)p[body + i * channels + c] - 128) / 128.0;
-                        mono[i] = (float)(acc / channels);
-                    }
+                out.off = body;
+                out.len = len;
+                if (!out.is_float && out.bits == 8) {                       // 8-bit WAV is unsigned
+                    if (out.channels == 0) return AudioFileStatus::Unsupported;
+                    out.kind = AudioPayload::WavU8;
+                    finish_pcm();
                     return AudioFileStatus::Ok;
                 }
-                return decode_pcm(p + body, len, channels, bits, is_float, true, mono) ? AudioFileStatus::Ok
-                                                                                       : AudioFileStatus::Unsupported;
+                if (!pcm_ok()) return AudioFileStatus::Unsupported;
+                out.kind = AudioPayload::Pcm;
+                finish_pcm();
+                return AudioFileStatus::Ok;
             }
             at = body + len + (len & 1);
         }
         return AudioFileStatus::Unsupported;
     }
     return AudioFileStatus::Unsupported;
+}
+
+bool decode_payload(const AudioPayload& a, std::vector<float>& mono) {
+    const uint8_t* data = a.file.data() + a.off;
+    switch (a.kind) {
+        case AudioPayload::Ima4: return decode_ima4(data, a.len, a.channels, a.valid_frames, a.priming, mono);
+        case AudioPayload::Pcm: return decode_pcm(data, a.len, a.channels, a.bits, a.is_float, a.little, mono);
+        case AudioPayload::WavU8: {
+            mono.resize(a.count);
+            for (size_t i = 0; i < a.count; ++i) {
+                double acc = 0;
+                for (uint32_t c = 0; c < a.channels; ++c) acc += ((int)data[i * a.channels + c] - 128) / 128.0;
+                mono[i] = (float)(acc / a.channels);
+            }
+            return true;
+        }
+        default: return false;
+    }
+}
+
+AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, double& sample_rate) {
+    AudioPayload a;
+    const AudioFileStatus st = parse_audio_file(path, a);
+    if (st != AudioFileStatus::Ok) return st;
+    sample_rate = a.sample_rate;
+    return decode_payload(a, mono) ? AudioFileStatus::Ok : AudioFileStatus::Unsupported;
 }
 
 

@@ -1,5 +1,6 @@
 // audiofile.hpp -- uncompressed CAF / WAV reader (stand-in for ExtAudioFile)
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -7,6 +8,24 @@ namespace lbad {
 enum class AudioFileStatus { Ok, NotFound, Unsupported };
 // Reads the whole file as mono float32 at the file's own sample rate.
 AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, double& sample_rate);
+
+// The same in two steps, for the device decoder (k_decode.hip): the file's bytes with the payload located and
+// described, then the decode.  Decoded mono frame i of the result is frame first + i of the payload's
+// total_frames (CAF 'pakt' priming / valid-frame trimming); count frames in all.
+struct AudioPayload {
+    enum Kind { None = 0, Ima4 = 1, Pcm = 2, WavU8 = 3 };
+    Kind kind = None;
+    std::vector<uint8_t> file;        // the whole file
+    size_t off = 0, len = 0;          // payload bytes within it
+    uint32_t channels = 0, bits = 0;
+    bool is_float = false, little = false;
+    int64_t valid_frames = -1;
+    int32_t priming = 0;
+    double sample_rate = 0.0;
+    uint64_t total_frames = 0, first = 0, count = 0;
+};
+AudioFileStatus parse_audio_file(const char* path, AudioPayload& out);
+bool decode_payload(const AudioPayload& payload, std::vector<float>& mono);
 // Sample-rate conversion (documented stand-ins for Apple's converter): mode 0 long Kaiser sinc, 1 short
 // sinc, 2 linear interpolation.  False for an unknown mode or a rate ratio outside [1/4096, 4096].
 bool resample(const std::vector<float>& in, double rate_in, double rate_out, uint32_t mode, std::vector<float>& out);

@@ -123,6 +123,9 @@ hipError_t launch_file_tail(const Plan& plan, const float* d_pcm, uint64_t n_cli
                             uint32_t n_tail, const uint32_t* d_tbl, float* d_frames, hipStream_t stream);
 
 // generic matrix ops behind the Frame API
+// the file front end's payload decoders (k_decode.hip: audiofile.cpp's decode_ima4 / decode_pcm, same arithmetic)
+hipError_t launch_decode(int kind, const uint8_t* d_data, uint64_t total_frames, uint32_t channels, uint32_t bits,
+                         bool is_float, bool little, float* d_out, hipStream_t stream);
 // the file front end's sample-rate converter (k_resample.hip): audiofile.cpp's resample(), same arithmetic
 hipError_t launch_resample(const float* d_in, uint64_t n_in, uint32_t mode, double ratio, double scale, double half,
                            int res, const double* d_table, uint64_t table_n, float* d_out, uint64_t n_out,
@@ -214,7 +217,9 @@ struct LBAudioDetective {
     size_t h_io_cap = 0;
     hipStream_t io_stream = nullptr;
     // converter state of the file entry points: input / output samples and the two kernel tables, grown on demand
-    void* d_rs_in = nullptr;
+    void* d_rs_bytes = nullptr;       // the file's payload as read
+    size_t d_rs_bytes_cap = 0;
+    void* d_rs_in = nullptr;          // decoded mono samples at the file's rate
     size_t d_rs_in_cap = 0;
     void* d_rs_out = nullptr;
     size_t d_rs_out_cap = 0;

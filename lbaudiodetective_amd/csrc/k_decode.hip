@@ -1,0 +1,122 @@
+// k_decode.hip -- payload decoders of the file front end on the device: Apple IMA4 packets and linear PCM -> mono float32.
+//
+// What ExtAudioFile does for upstream before the first window is read (LBAudioDetective.m:224-237).  audiofile.cpp
+// holds the host versions (decode_ima4 / decode_pcm / the unsigned 8-bit WAV loop); these are the same operations in
+// the same order per output frame, so a file decoded here has the host decoder's samples bit for bit: IMA4 is integer
+// arithmetic followed by one float division by 32768 per channel and a float sum over the channels in channel order;
+// PCM is one conversion per sample and a double sum over the channels divided by the channel count.
+#include "internal.hpp"
+
+namespace lbad {
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ const int kImaIndex[16] = {-1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8};
+__device__ const int kImaStep[89] = {7,     8,     9,     10,    11,    12,    13,    14,    16,    17,    19,    21,    23,
+                                     25,    28,    31,    34,    37,    41,    45,    50,    55,    60,    66,    73,    80,
+                                     88,    97,    107,   118,   130,   143,   157,   173,   190,   209,   230,   253,   279,
+                                     307,   337,   371,   408,   449,   494,   544,   598,   658,   724,   796,   876,   963,
+                                     1060,  1166,  1282,  1411,  1552,  1707,  1878,  2066,  2272,  2499,  2749,  3024,  3327,
+                                     3660,  4026,  4428,  4871,  5358,  5894,  6484,  7132,  7845,  8630,  9493,  10442, 11487,
+                                     12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767};
+
+// one thread per packet position: its `channels` interleaved 34-byte packets (2-byte big-endian header = 9-bit
+// predictor + 7-bit step index, 64 4-bit codes, low nibble first), accumulated into the 64 output frames channel by
+// channel as the host loop does (0.0f + v == v, so the first channel may store)
+__global__ __launch_bounds__(kThreads) void ima4_kernel(const uint8_t* __restrict__ data, uint64_t packets, uint32_t channels,
+                                                        float* __restrict__ out) {
+    const uint64_t p = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= packets) return;
+    float* o = out + p * 64;
+    for (uint32_t c = 0; c < channels; ++c) {
+        const uint8_t* pk = data + (p * channels + c) * 34;
+        const int header = (pk[0] << 8) | pk[1];
+        int predictor = (int)(short)(header & 0xFF80);
+        int index = header & 0x7F;
+        if (index > 88) index = 88;
+        for (int i = 0; i < 64; ++i) {
+            const int nib = (i & 1) ? (pk[2 + (i >> 1)] >> 4) : (pk[2 + (i >> 1)] & 0x0F);
+            const int step = kImaStep[index];
+            int diff = step >> 3;
+            if (nib & 4) diff += step;
+            if (nib & 2) diff += step >> 1;
+            if (nib & 1) diff += step >> 2;
+            predictor += (nib & 8) ? -diff : diff;
+            if (predictor > 32767) predictor = 32767;
+            if (predictor < -32768) predictor = -32768;
+            index += kImaIndex[nib];
+            if (index < 0) index = 0;
+            if (index > 88) index = 88;
+            const float v = __fdiv_rn((float)predictor, 32768.0f);
+            o[i] = c == 0 ? v : __fadd_rn(o[i], v);
+        }
+    }
+    if (channels > 1)
+        for (int i = 0; i < 64; ++i) o[i] = __fdiv_rn(o[i], (float)channels);
+}
+
+// one sample of `bits` width at p -> float in [-1, 1)  (audiofile.cpp: sample_to_float)
+__device__ __forceinline__ float sample_to_float(const uint8_t* p, uint32_t bits, bool is_float, bool little) {
+    uint8_t b[8];
+    const uint32_t bytes = bits / 8;
+    for (uint32_t i = 0; i < bytes; ++i) b[i] = little ? p[i] : p[bytes - 1 - i];  // b is little-endian now
+    if (is_float) {
+        if (bits == 32) return __uint_as_float((uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24);
+        unsigned long long u = 0;
+        for (int i = 0; i < 8; ++i) u |= (unsigned long long)b[i] << (8 * i);
+        return (float)__longlong_as_double((long long)u);
+    }
+    int v = 0;
+    switch (bits) {
+        case 8: return __fdiv_rn((float)(signed char)b[0], 128.0f);
+        case 16: v = (short)(b[0] | b[1] << 8); return __fdiv_rn((float)v, 32768.0f);
+        case 24: v = (int)((uint32_t)b[0] << 8 | (uint32_t)b[1] << 16 | (uint32_t)b[2] << 24) >> 8; return __fdiv_rn((float)v, 8388608.0f);
+        case 32: v = (int)((uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24); return (float)((double)v / 2147483648.0);
+        default: return 0.0f;
+    }
+}
+
+// one thread per frame; `wav_u8`: the unsigned 8-bit WAV form ((s - 128) / 128.0 in double, always averaged)
+__global__ __launch_bounds__(kThreads) void pcm_kernel(const uint8_t* __restrict__ data, uint64_t frames, uint32_t channels,
+                                                       uint32_t bits, int is_float, int little, int wav_u8,
+                                                       float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= frames) return;
+    if (wav_u8) {
+        double acc = 0;
+        for (uint32_t c = 0; c < channels; ++c) acc += ((int)data[i * channels + c] - 128) / 128.0;
+        out[i] = (float)(acc / channels);
+        return;
+    }
+    const uint32_t bytes = bits / 8;
+    const uint8_t* p = data + i * ((uint64_t)channels * bytes);
+    if (channels == 1) {
+        out[i] = sample_to_float(p, bits, is_float, little);
+    } else {  // average the channels (the client format upstream is mono, LBAudioDetective.m:125)
+        double acc = 0.0;
+        for (uint32_t c = 0; c < channels; ++c) acc += sample_to_float(p + c * bytes, bits, is_float, little);
+        out[i] = (float)(acc / channels);
+    }
+}
+
+}  // namespace
+
+// kind: AudioPayload::Kind (1 IMA4, 2 PCM, 3 unsigned 8-bit WAV); d_out holds total_frames floats
+hipError_t launch_decode(int kind, const uint8_t* d_data, uint64_t total_frames, uint32_t channels, uint32_t bits,
+                         bool is_float, bool little, float* d_out, hipStream_t stream) {
+    if (total_frames == 0) return hipSuccess;
+    const uint64_t units = kind == 1 ? total_frames / 64 : total_frames;
+    const uint64_t blocks = (units + kThreads - 1) / kThreads;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (kind == 1)
+        hipLaunchKernelGGL(ima4_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_data, units, channels, d_out);
+    else if (kind == 2 || kind == 3)
+        hipLaunchKernelGGL(pcm_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_data, units, channels, bits,
+                           is_float ? 1 : 0, little ? 1 : 0, kind == 3 ? 1 : 0, d_out);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace lbad
