@@ -997,3 +997,23 @@ def test_polled_query_sees_appends_from_other_streams(lb, gpu, oracle):
             assert b.query(q) == want
     for _ in range(200):                                                        # many polls in a row: sequence numbers
         assert a.query(lb.Fingerprint.from_bools(host[7])) == (7, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# the randomized sweeps of tools/ in miniature (the long runs are recorded in each tool's docstring)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,trials", [("fuzz_parity.py", 250), ("fuzz_compare.py", 120), ("fuzz_frame.py", 400),
+                                         ("fuzz_stream.py", 120), ("fuzz_files.py", 200)])
+def test_randomized_sweeps(tool, trials):
+    """Each sweep compares the device path with the oracle on inputs nobody picked by hand and exits non-zero on the
+    first kind of mismatch: fingerprint configurations and shapes (all stage-1 / stage-2 kernels, the file loop), the
+    compare leg, the Frame API, streaming and host batches, files of every payload format through the device decoder
+    and converter."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = subprocess.run([sys.executable, os.path.join(root, "tools", tool), str(trials), "20261002"], capture_output=True, text=True,
+                         timeout=600, cwd=root, env={**os.environ, "PYTHONPATH": root})
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-1500:])
+    assert f"{trials} trials, 0 mismatches" in run.stdout
