@@ -312,15 +312,30 @@ typedef struct LBAudioDetectiveCorpus* LBAudioDetectiveCorpusRef;
  * Booleans; inCapacity entries of HBM are reserved up front. */
 LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLength, UInt32 inSubfingerprintsPerEntry,
                                                     UInt64 inCapacity);
+/* Ragged corpus: every entry has its own number (>= 1) of sub-fingerprints -- what the upstream best-match
+ * loop actually compares (LBAudioDetectiveTests.m:57-91: one original against ten sequences, all of different
+ * lengths; LBAudioDetectiveFingerprint.m:123-146 swaps the two sides and slides the shorter along the longer).
+ * inSubfingerprintLength <= 200.  HBM for inSubfingerprintCapacity sub-fingerprints (32 bytes each) and
+ * inEntryCapacity entries is reserved up front.  Every query entry point below accepts such a corpus and a query
+ * of ANY number of sub-fingerprints; the scan is one launch (k_sliding.hip). */
+LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprintLength, UInt64 inEntryCapacity,
+                                                          UInt64 inSubfingerprintCapacity);
+/* Append inNumberOfEntries entries to a ragged corpus: inPacked = device pointer to the entries' sub-fingerprints
+ * back to back in the packed layout (sum(inCounts) x LBAD_PACKED_BYTES), inCounts = HOST array of the entries'
+ * sub-fingerprint counts (each >= 1).  Asynchronous on inStream once the counts are read. */
+OSStatus LBAudioDetectiveCorpusAppendRaggedPackedDevice(LBAudioDetectiveCorpusRef inCorpus, const void* inPacked,
+                                                        const UInt32* inCounts, UInt64 inNumberOfEntries, void* inStream);
+/* sub-fingerprints stored, over all entries */
+UInt64 LBAudioDetectiveCorpusGetSubfingerprintTotal(LBAudioDetectiveCorpusRef inCorpus);
 void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef inCorpus);
 UInt64 LBAudioDetectiveCorpusGetCount(LBAudioDetectiveCorpusRef inCorpus);
-/* bytes of HBM one entry occupies in the scan layout */
+/* bytes of HBM one entry occupies in the scan layout (ragged corpus: bytes per sub-fingerprint) */
 UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef inCorpus);
 /* Append entries from device memory in the packed batch layout
  * (inNumberOfEntries x perEntry x LBAD_PACKED_BYTES). */
 OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef inCorpus, const void* inPacked,
                                                   UInt64 inNumberOfEntries, void* inStream);
-/* Append one host fingerprint (must have exactly perEntry sub-fingerprints). */
+/* Append one host fingerprint (exactly perEntry sub-fingerprints; any number >= 1 for a ragged corpus). */
 OSStatus LBAudioDetectiveCorpusAppendFingerprint(LBAudioDetectiveCorpusRef inCorpus,
                                                  LBAudioDetectiveFingerprintRef inFingerprint);
 /* Best-match loop of LBAudioDetectiveTests.m:57-91 over the corpus: the query is the fixed
@@ -361,6 +376,11 @@ OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef inCorp
 OSStatus LBAudioDetectiveSynthClipsDevice(UInt32 inSeed, UInt64 inFirstClip, UInt64 inNumberOfClips,
                                           UInt32 inSampleRateHz, UInt32 inSamplesPerClip, UInt32 inStereoSum,
                                           Float32* outClips, void* inStream);
+/* Ragged form: entry e = sub-fingerprints [inOffsets[e], inOffsets[e + 1]) of the output (inOffsets: DEVICE
+ * array of inNumberOfEntries + 1 uint32, inOffsets[0] = 0); sub-fingerprint s of entry e is lbo_synth_entry's. */
+OSStatus LBAudioDetectiveSynthRaggedCorpusDevice(UInt32 inSeed, UInt64 inFirstEntry, UInt64 inNumberOfEntries,
+                                                 const UInt32* inOffsets, UInt64 inTotalSubfingerprints,
+                                                 UInt32 inSubfingerprintLength, void* outPacked, void* inStream);
 /* Packed batch layout (entries x perEntry x LBAD_PACKED_BYTES); matches lbo_synth_entry. */
 OSStatus LBAudioDetectiveSynthCorpusDevice(UInt32 inSeed, UInt64 inFirstEntry, UInt64 inNumberOfEntries,
                                            UInt32 inSubfingerprintsPerEntry, UInt32 inSubfingerprintLength,

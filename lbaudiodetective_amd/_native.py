@@ -122,6 +122,11 @@ _SIGNATURES = {
     "LBAudioDetectivePackSubfingerprint": (None, [C.c_void_p, UInt32, C.c_void_p]),
     "LBAudioDetectiveUnpackSubfingerprint": (None, [C.c_void_p, UInt32, C.c_void_p]),
     "LBAudioDetectiveCorpusNew": (Ref, [UInt32, UInt32, UInt64]),
+    "LBAudioDetectiveCorpusNewRagged": (Ref, [UInt32, UInt64, UInt64]),
+    "LBAudioDetectiveCorpusAppendRaggedPackedDevice": (OSStatus, [Ref, C.c_void_p, C.c_void_p, UInt64, C.c_void_p]),
+    "LBAudioDetectiveCorpusGetSubfingerprintTotal": (UInt64, [Ref]),
+    "LBAudioDetectiveSynthRaggedCorpusDevice": (OSStatus, [UInt32, UInt64, UInt64, C.c_void_p, UInt64, UInt32, C.c_void_p,
+                                                           C.c_void_p]),
     "LBAudioDetectiveCorpusDispose": (None, [Ref]),
     "LBAudioDetectiveCorpusGetCount": (UInt64, [Ref]),
     "LBAudioDetectiveCorpusGetEntryStrideBytes": (UInt32, [Ref]),

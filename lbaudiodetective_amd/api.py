@@ -436,6 +436,27 @@ class Corpus:
         self.subfingerprints_per_entry = subfingerprints_per_entry
         self.capacity = capacity
 
+    @classmethod
+    def ragged(cls, subfingerprint_length: int, entry_capacity: int, subfingerprint_capacity: int) -> "Corpus":
+        """LBAudioDetectiveCorpusNewRagged: entries of any length (the shape of LBAudioDetectiveTests.m:57-91)."""
+        ref = N.lib().LBAudioDetectiveCorpusNewRagged(subfingerprint_length, entry_capacity, subfingerprint_capacity)
+        if not ref:
+            raise LBAudioDetectiveError(1, "CorpusNewRagged (unsupported length, zero capacity or no HIP device)")
+        return cls(subfingerprint_length, 0, entry_capacity, _ref=ref)
+
+    @property
+    def subfingerprint_total(self) -> int:
+        return int(self._L.LBAudioDetectiveCorpusGetSubfingerprintTotal(self._ref))
+
+    def append_ragged_packed_device(self, packed, counts, stream=None):
+        """packed: torch uint8 [sum(counts), 32] on the device; counts: the entries' sub-fingerprint counts (host)."""
+        assert packed.is_cuda and packed.is_contiguous()
+        cnt = np.ascontiguousarray(counts, dtype=np.uint32)
+        assert int(cnt.sum()) == packed.shape[0]
+        _check(self._L.LBAudioDetectiveCorpusAppendRaggedPackedDevice(self._ref, packed.data_ptr(), cnt.ctypes.data,
+                                                                     cnt.size, _stream_ptr(stream)),
+               "CorpusAppendRaggedPackedDevice")
+
     def dispose(self):
         if self._ref:
             self._L.LBAudioDetectiveCorpusDispose(self._ref)
@@ -540,6 +561,23 @@ def synth_clips_device(seed: int, first: int, n_clips: int, sample_rate_hz: int,
     _check(N.lib().LBAudioDetectiveSynthClipsDevice(seed & 0xFFFFFFFF, first, n_clips, sample_rate_hz, n_samples,
                                                     int(stereo_sum), out.data_ptr(), _stream_ptr(stream)),
            "SynthClipsDevice")
+    return out
+
+
+def synth_ragged_corpus_device(seed: int, first: int, counts, subfp_len: int, stream=None):
+    """Synthetic ragged corpus on the device: entry first + e has counts[e] sub-fingerprints (lbo_synth_entry's);
+    returns packed uint8 [sum(counts), 32]."""
+    import torch
+    cnt = np.ascontiguousarray(counts, dtype=np.uint32)
+    off = np.zeros(cnt.size + 1, np.uint32)
+    np.cumsum(cnt, out=off[1:])
+    total = int(off[-1])
+    d_off = torch.from_numpy(off.view(np.int32)).cuda()
+    out = torch.empty((total, N.PACKED_BYTES), dtype=torch.uint8, device="cuda")
+    _check(N.lib().LBAudioDetectiveSynthRaggedCorpusDevice(seed & 0xFFFFFFFF, first, cnt.size, d_off.data_ptr(), total,
+                                                           subfp_len, out.data_ptr(), _stream_ptr(stream)),
+           "SynthRaggedCorpusDevice")
+    torch.cuda.current_stream().synchronize() if stream is None else stream.synchronize()   # d_off is a temporary
     return out
 
 

@@ -9,13 +9,46 @@
 namespace lbad {
 namespace {
 
+// make room for `words` words in the corpus' query staging pair (device + pinned)
+OSStatus reserve_query(LBAudioDetectiveCorpus* c, size_t words) {
+    if (c->query_cap >= words) return noErr;
+    if (c->d_query) (void)hipFree(c->d_query);
+    if (c->h_query) (void)hipHostFree(c->h_query);
+    c->d_query = nullptr;
+    c->h_query = nullptr;
+    c->query_cap = 0;
+    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_query), words * sizeof(uint32_t)));
+    LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_query), words * sizeof(uint32_t), hipHostMallocDefault));
+    c->query_cap = (uint32_t)words;
+    return noErr;
+}
+
+// ragged corpus: the sliding scan of k_sliding.hip (any query length, any entry lengths)
+OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
+                          uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
+    std::vector<uint32_t> block;
+    build_sliding_query(q->data.data(), q->count, c->subfp_len, range, block);
+    OSStatus st = reserve_query(c, block.size());
+    if (st != noErr) return st;
+    LBAD_HIP(hipStreamSynchronize(stream));   // the pinned staging block is reused by every query
+    std::memcpy(c->h_query, block.data(), block.size() * sizeof(uint32_t));
+    LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, block.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
+    if (d_scores) LBAD_HIP(hipMemsetAsync(d_scores, 0, c->count * sizeof(float), stream));
+    LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, c->subfp_len, c->d_query,
+                                    q->count, range, index_base, reinterpret_cast<unsigned int*>(d_scores), key_dst,
+                                    stream));
+    return noErr;
+}
+
 // stage the query on the device and launch the scan; key_dst is a device pointer
 OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
                    uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
     if (!c || !q || !key_dst) return kLBAudioDetectiveArgumentInvalid;
     if (q->length != c->subfp_len || q->count == 0) return kLBAudioDetectiveArgumentInvalid;
-    if ((size_t)q->count * kPackedWords * 4 > 48 * 1024) return kLBAudioDetectiveArgumentInvalid;
+    if (!c->ragged && (size_t)q->count * kPackedWords * 4 > 48 * 1024) return kLBAudioDetectiveArgumentInvalid;
     if (range == 0) range = c->subfp_len;  // LBAudioDetective.m:443-445
+    if (c->ragged) return run_query_ragged(c, q, range, index_base, d_scores, key_dst, stream);
     std::vector<uint32_t> slots;
     pack_fingerprint(q, slots);
     bool fast = planes_fast_supported(c->subfp_len, c->n_sub, q->count);
@@ -114,8 +147,76 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLengt
     return c;
 }
 
+LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprintLength, UInt64 inEntryCapacity,
+                                                          UInt64 inSubfingerprintCapacity) {
+    if (inEntryCapacity == 0 || inEntryCapacity > 0xFFFFFFFFull) return NULL;   // the key carries a 32-bit index
+    if (inSubfingerprintCapacity < inEntryCapacity || inSubfingerprintCapacity > 0xFFFFFFFFull) return NULL;
+    if (!lbad::sliding_supported(inSubfingerprintLength)) return NULL;
+    if (!lbad::device_ready()) {
+        fprintf(stderr, "lbaudiodetective: no HIP device, cannot create a corpus\n");
+        return NULL;
+    }
+    LBAudioDetectiveCorpus* c = new (std::nothrow) LBAudioDetectiveCorpus();
+    if (!c) return NULL;
+    c->ragged = true;
+    c->subfp_len = inSubfingerprintLength;
+    c->capacity = inEntryCapacity;
+    c->rec_capacity = inSubfingerprintCapacity;
+    c->h_off.assign(1, 0u);
+    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_recs), (size_t)inSubfingerprintCapacity * 32), "hipMalloc corpus", __LINE__) != noErr ||
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_off), (size_t)(inEntryCapacity + 1) * 4), "hipMalloc offsets", __LINE__) != noErr ||
+        lbad::hip_status(hipMemset(c->d_off, 0, 4), "offsets", __LINE__) != noErr ||
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr) {
+        LBAudioDetectiveCorpusDispose(c);
+        return NULL;
+    }
+    return c;
+}
+
+UInt64 LBAudioDetectiveCorpusGetSubfingerprintTotal(LBAudioDetectiveCorpusRef c) {
+    if (!c) return 0;
+    return c->ragged ? c->n_pos : c->count * c->n_sub;
+}
+
+OSStatus LBAudioDetectiveCorpusAppendRaggedPackedDevice(LBAudioDetectiveCorpusRef c, const void* inPacked,
+                                                        const UInt32* inCounts, UInt64 inNumberOfEntries, void* inStream) {
+    if (!c || !c->ragged || (inNumberOfEntries && (!inPacked || !inCounts))) return kLBAudioDetectiveArgumentInvalid;
+    if (inNumberOfEntries == 0) return noErr;
+    if (c->count + inNumberOfEntries > c->capacity) return kLBAudioDetectiveArgumentInvalid;
+    LBAD_GUARD_BEGIN
+    uint64_t total = 0;
+    uint32_t longest = c->ne_max;
+    for (UInt64 e = 0; e < inNumberOfEntries; ++e) {
+        if (inCounts[e] == 0) return kLBAudioDetectiveArgumentInvalid;   // an entry has at least one sub-fingerprint
+        total += inCounts[e];
+        if (inCounts[e] > longest) longest = inCounts[e];
+    }
+    if (c->n_pos + total > c->rec_capacity) return kLBAudioDetectiveArgumentInvalid;
+    const size_t at = c->h_off.size() - 1;            // == c->count
+    c->h_off.resize(at + inNumberOfEntries + 1);
+    for (UInt64 e = 0; e < inNumberOfEntries; ++e) c->h_off[at + e + 1] = c->h_off[at + e] + inCounts[e];
+    hipStream_t stream = static_cast<hipStream_t>(inStream);
+    OSStatus st = lbad::hip_status(hipMemcpyAsync(c->d_off + at, c->h_off.data() + at, (inNumberOfEntries + 1) * 4,
+                                                  hipMemcpyHostToDevice, stream), "offsets H2D", __LINE__);
+    if (st == noErr)
+        st = lbad::hip_status(lbad::launch_pack_records(static_cast<const uint32_t*>(inPacked), total, c->d_off + at,
+                                                        inNumberOfEntries, (uint32_t)c->count, c->d_recs, stream),
+                              "pack records", __LINE__);
+    if (st != noErr) {
+        c->h_off.resize(at + 1);
+        return st;
+    }
+    c->count += inNumberOfEntries;
+    c->n_pos += total;
+    c->ne_max = longest;
+    return noErr;
+    LBAD_GUARD_END
+}
+
 void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (!c) return;
+    if (c->d_recs) (void)hipFree(c->d_recs);
+    if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_planes) (void)hipFree(c->d_planes);
     if (c->d_query) (void)hipFree(c->d_query);
     if (c->h_query) (void)hipHostFree(c->h_query);
@@ -129,7 +230,10 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
 
 UInt64 LBAudioDetectiveCorpusGetCount(LBAudioDetectiveCorpusRef c) { return c ? c->count : 0; }
 
-UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef c) { return c ? c->n_planes * 16u : 0; }
+UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef c) {
+    if (!c) return 0;
+    return c->ragged ? 32u : c->n_planes * 16u;   // ragged: bytes per sub-fingerprint record
+}
 
 OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef c, UInt32 inVariant) {
     if (!c || inVariant > 2) return kLBAudioDetectiveArgumentInvalid;
@@ -139,7 +243,7 @@ OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef c, UIn
 
 OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef c, const void* inPacked,
                                                   UInt64 inNumberOfEntries, void* inStream) {
-    if (!c || (!inPacked && inNumberOfEntries)) return kLBAudioDetectiveArgumentInvalid;
+    if (!c || c->ragged || (!inPacked && inNumberOfEntries)) return kLBAudioDetectiveArgumentInvalid;
     if (c->count + inNumberOfEntries > c->capacity) return kLBAudioDetectiveArgumentInvalid;
     LBAD_HIP(lbad::launch_pack_planes(static_cast<const uint32_t*>(inPacked), inNumberOfEntries, c->n_sub, c->subfp_len,
                                       c->d_planes, c->capacity, c->count, static_cast<hipStream_t>(inStream)));
@@ -150,13 +254,16 @@ OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef c, c
 }
 
 OSStatus LBAudioDetectiveCorpusAppendFingerprint(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef fp) {
-    if (!c || !fp || fp->count != c->n_sub || fp->length != c->subfp_len) return kLBAudioDetectiveArgumentInvalid;
+    if (!c || !fp || fp->length != c->subfp_len) return kLBAudioDetectiveArgumentInvalid;
+    if (c->ragged ? fp->count == 0 : fp->count != c->n_sub) return kLBAudioDetectiveArgumentInvalid;
     std::vector<uint32_t> slots;
     lbad::pack_fingerprint(fp, slots);
     uint32_t* d = nullptr;
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d), slots.size() * 4));
     OSStatus st = lbad::hip_status(hipMemcpy(d, slots.data(), slots.size() * 4, hipMemcpyHostToDevice), "copy", __LINE__);
-    if (st == noErr) st = LBAudioDetectiveCorpusAppendPackedDevice(c, d, 1, NULL);
+    const UInt32 n = fp->count;
+    if (st == noErr) st = c->ragged ? LBAudioDetectiveCorpusAppendRaggedPackedDevice(c, d, &n, 1, NULL)
+                                    : LBAudioDetectiveCorpusAppendPackedDevice(c, d, 1, NULL);
     if (st == noErr) st = lbad::hip_status(hipStreamSynchronize(nullptr), "sync", __LINE__);
     (void)hipFree(d);
     return st;
@@ -257,10 +364,102 @@ struct CorpusFileHeader {
 };
 }  // namespace
 
+// ragged corpus file: header, the entries' sub-fingerprint counts, the records
+namespace {
+struct RaggedFileHeader {
+    char magic[8];            // "LBADCRP2"
+    uint32_t subfp_len, reserved;
+    uint64_t count, n_pos;
+};
+
+OSStatus save_ragged(LBAudioDetectiveCorpus* c, FILE* f) {
+    RaggedFileHeader h;
+    std::memcpy(h.magic, "LBADCRP2", 8);
+    h.subfp_len = c->subfp_len; h.reserved = 0; h.count = c->count; h.n_pos = c->n_pos;
+    if (std::fwrite(&h, sizeof(h), 1, f) != 1) return kLBAudioDetectiveDeviceError;
+    std::vector<uint32_t> counts(c->count);
+    for (uint64_t e = 0; e < c->count; ++e) counts[e] = c->h_off[e + 1] - c->h_off[e];
+    if (c->count && std::fwrite(counts.data(), 4, c->count, f) != c->count) return kLBAudioDetectiveDeviceError;
+    const size_t piece = 1u << 20;                        // records per staging piece (32 MiB)
+    std::vector<uint4> host(2 * (c->n_pos < piece ? (size_t)c->n_pos : piece));
+    for (uint64_t at = 0; at < c->n_pos; at += piece) {
+        const size_t n = (size_t)(c->n_pos - at < piece ? c->n_pos - at : piece);
+        OSStatus st = lbad::hip_status(hipMemcpy(host.data(), c->d_recs + 2 * at, n * 32, hipMemcpyDeviceToHost),
+                                       "corpus records D2H", __LINE__);
+        if (st != noErr) return st;
+        if (std::fwrite(host.data(), 32, n, f) != n) return kLBAudioDetectiveDeviceError;
+    }
+    return noErr;
+}
+
+LBAudioDetectiveCorpusRef load_ragged(FILE* f, long file_size, uint64_t capacity) {
+    RaggedFileHeader h;
+    if (file_size < (long)sizeof(h) || std::fread(&h, sizeof(h), 1, f) != 1) return NULL;
+    // untrusted header: the file must really hold what it announces before anything is allocated from it
+    if (!lbad::sliding_supported(h.subfp_len) || h.count > 0xFFFFFFFFull || h.n_pos > 0xFFFFFFFFull || h.n_pos < h.count)
+        return NULL;
+    if ((uint64_t)(file_size - (long)sizeof(h)) < h.count * 4 + h.n_pos * 32) return NULL;
+    std::vector<uint32_t> counts;
+    try { counts.resize(h.count); } catch (const std::bad_alloc&) { return NULL; }
+    if (h.count && std::fread(counts.data(), 4, h.count, f) != h.count) return NULL;
+    uint64_t total = 0;
+    for (uint64_t e = 0; e < h.count; ++e) {
+        if (counts[e] == 0) return NULL;
+        total += counts[e];
+    }
+    if (total != h.n_pos) return NULL;
+    const uint64_t cap = capacity > h.count ? capacity : (h.count ? h.count : 1);
+    // room for records in proportion to the entry capacity
+    uint64_t rec_cap = h.count ? (h.n_pos * cap + h.count - 1) / h.count : cap * 64;
+    if (rec_cap < cap) rec_cap = cap;
+    if (rec_cap > 0xFFFFFFFFull) rec_cap = 0xFFFFFFFFull;
+    LBAudioDetectiveCorpusRef c = LBAudioDetectiveCorpusNewRagged(h.subfp_len, cap, rec_cap);
+    if (!c) return NULL;
+    bool ok = true;
+    const size_t piece = 1u << 20;
+    uint4* host = static_cast<uint4*>(std::malloc(32 * (h.n_pos < piece ? (size_t)(h.n_pos ? h.n_pos : 1) : piece)));
+    if (!host) ok = false;
+    for (uint64_t at = 0; ok && at < h.n_pos; at += piece) {
+        const size_t n = (size_t)(h.n_pos - at < piece ? h.n_pos - at : piece);
+        ok = std::fread(host, 32, n, f) == n &&
+             lbad::hip_status(hipMemcpy(c->d_recs + 2 * at, host, n * 32, hipMemcpyHostToDevice), "corpus records H2D",
+                              __LINE__) == noErr;
+    }
+    std::free(host);
+    if (ok) {
+        try {
+            c->h_off.resize(h.count + 1);
+        } catch (const std::bad_alloc&) { ok = false; }
+    }
+    if (ok) {
+        c->h_off[0] = 0;
+        for (uint64_t e = 0; e < h.count; ++e) {
+            c->h_off[e + 1] = c->h_off[e] + counts[e];
+            if (counts[e] > c->ne_max) c->ne_max = counts[e];
+        }
+        ok = lbad::hip_status(hipMemcpy(c->d_off, c->h_off.data(), (h.count + 1) * 4, hipMemcpyHostToDevice),
+                              "corpus offsets H2D", __LINE__) == noErr;
+    }
+    if (!ok) {
+        LBAudioDetectiveCorpusDispose(c);
+        return NULL;
+    }
+    c->count = h.count;
+    c->n_pos = h.n_pos;
+    return c;
+}
+}  // namespace
+
 OSStatus LBAudioDetectiveCorpusSave(LBAudioDetectiveCorpusRef c, const char* inPath) {
     if (!c || !inPath) return kLBAudioDetectiveArgumentInvalid;
     FILE* f = std::fopen(inPath, "wb");
     if (!f) return -43;
+    if (c->ragged) {
+        OSStatus rst = kLBAudioDetectiveMemFull;
+        try { rst = save_ragged(c, f); } catch (const std::bad_alloc&) {}
+        std::fclose(f);
+        return rst;
+    }
     CorpusFileHeader h;
     std::memcpy(h.magic, "LBADCRP1", 8);
     h.subfp_len = c->subfp_len; h.n_sub = c->n_sub; h.n_planes = c->n_planes; h.reserved = 0; h.count = c->count;
@@ -285,6 +484,14 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 
     // count * n_planes planes before anything is allocated from it
     std::fseek(f, 0, SEEK_END);
     const long file_size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    char magic[8] = {0};
+    if (file_size >= 8 && std::fread(magic, 8, 1, f) == 1 && std::memcmp(magic, "LBADCRP2", 8) == 0) {
+        std::fseek(f, 0, SEEK_SET);
+        c = load_ragged(f, file_size, inCapacity);
+        std::fclose(f);
+        return c;
+    }
     std::fseek(f, 0, SEEK_SET);
     bool ok = file_size >= (long)sizeof(h) && std::fread(&h, sizeof(h), 1, f) == 1 &&
               std::memcmp(h.magic, "LBADCRP1", 8) == 0 && h.subfp_len > 0 &&

@@ -342,13 +342,6 @@ static LBAudioDetectiveFingerprintRef fingerprint_from_bools(const LBAudioDetect
 
 using lbad::ensure_plan;
 
-// Host allocations sized by caller or file data (decoded audio, resampler output, zero padding) can fail:
-// nothing may unwind through the C boundary.  memFullErr is MacErrors.h's -108.
-#define LBAD_GUARD_BEGIN try {
-#define LBAD_GUARD_END                                                    \
-    }                                                                     \
-    catch (const std::bad_alloc&) { return kLBAudioDetectiveMemFull; }    \
-    catch (const std::exception&) { return kLBAudioDetectiveArgumentInvalid; }
 
 extern "C" {
 
@@ -798,6 +791,18 @@ OSStatus LBAudioDetectiveSynthCorpusDevice(UInt32 inSeed, UInt64 inFirstEntry, U
         return kLBAudioDetectiveArgumentInvalid;
     if (!lbad::device_ready()) return kLBAudioDetectiveDeviceUnavailable;
     LBAD_HIP(lbad::launch_synth_corpus(inSeed, inFirstEntry, inNumberOfEntries, inSubfingerprintsPerEntry,
+                                       inSubfingerprintLength, static_cast<uint32_t*>(outPacked),
+                                       static_cast<hipStream_t>(inStream)));
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveSynthRaggedCorpusDevice(UInt32 inSeed, UInt64 inFirstEntry, UInt64 inNumberOfEntries,
+                                                 const UInt32* inOffsets, UInt64 inTotalSubfingerprints,
+                                                 UInt32 inSubfingerprintLength, void* outPacked, void* inStream) {
+    if (!outPacked || !inOffsets || inSubfingerprintLength == 0 || inSubfingerprintLength > LBAD_MAX_SUBFINGERPRINT_LENGTH)
+        return kLBAudioDetectiveArgumentInvalid;
+    if (!lbad::device_ready()) return kLBAudioDetectiveDeviceUnavailable;
+    LBAD_HIP(lbad::launch_synth_ragged(inSeed, inFirstEntry, inNumberOfEntries, inOffsets, inTotalSubfingerprints,
                                        inSubfingerprintLength, static_cast<uint32_t*>(outPacked),
                                        static_cast<hipStream_t>(inStream)));
     return noErr;

@@ -5,6 +5,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <new>
+#include <stdexcept>
 #include <vector>
 
 #include "../../include/lbaudiodetective.h"
@@ -23,6 +25,14 @@ OSStatus hip_status(hipError_t e, const char* what, int line);
         OSStatus st__ = ::lbad::hip_status((expr), #expr, __LINE__);     \
         if (st__ != noErr) return st__;                                  \
     } while (0)
+
+// Host allocations sized by caller or file data (decoded audio, resampler output, zero padding) can fail:
+// nothing may unwind through the C boundary.  memFullErr is MacErrors.h's -108.
+#define LBAD_GUARD_BEGIN try {
+#define LBAD_GUARD_END                                                    \
+    }                                                                     \
+    catch (const std::bad_alloc&) { return kLBAudioDetectiveMemFull; }    \
+    catch (const std::exception&) { return kLBAudioDetectiveArgumentInvalid; }
 
 bool device_ready();
 // Per-device facts and one-time set-up, keyed by the CURRENT device (a process may use several).
@@ -170,6 +180,21 @@ hipError_t launch_compare_planes_batch(const uint4* d_planes, uint64_t plane_str
                                        unsigned long long* d_keys, hipStream_t stream);
 void pack_fingerprint(const struct ::LBAudioDetectiveFingerprint* fp, std::vector<uint32_t>& out);
 
+// ragged corpus (k_sliding.hip): a stream of 32-byte sub-fingerprint records, entries of any length back to back
+bool sliding_supported(uint32_t subfp_len);
+uint32_t sliding_query_words(uint32_t n_query);
+void build_sliding_query(const Boolean* bools, uint32_t n_query, uint32_t subfp_len, uint32_t range,
+                         std::vector<uint32_t>& out);
+// d_off_new: ABSOLUTE record positions of the n_new new entries (n_new + 1 values, the first one = first_pos)
+hipError_t launch_pack_records(const uint32_t* d_slots, uint64_t n_new_pos, const uint32_t* d_off_new, uint64_t n_new,
+                               uint32_t first_entry, uint4* d_recs, hipStream_t stream);
+hipError_t launch_synth_ragged(uint32_t seed, uint64_t first_entry, uint64_t n_entries, const uint32_t* d_off,
+                               uint64_t n_pos, uint32_t subfp_len, uint32_t* d_out, hipStream_t stream);
+hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries,
+                                  uint32_t ne_max, uint32_t subfp_len, const uint32_t* d_qblk, uint32_t n_query,
+                                  uint32_t range, uint64_t index_base, unsigned int* d_score_bits,
+                                  unsigned long long* d_key, hipStream_t stream);
+
 // synthetic data
 hipError_t launch_synth_clips(uint32_t seed, uint64_t first, uint64_t n_clips, uint32_t rate_hz, uint32_t n_samples,
                               uint32_t stereo, float* d_out, hipStream_t stream);
@@ -251,4 +276,12 @@ struct LBAudioDetectiveCorpus {
     hipStream_t stream = nullptr;
     bool appended = false;                       // entries were appended since the last polled query ...
     hipStream_t append_stream = nullptr;         // ... on this stream
+    // ragged form (LBAudioDetectiveCorpusNewRagged): entries of any length as a stream of 32-byte records
+    bool ragged = false;
+    uint4* d_recs = nullptr;                     // 2 x uint4 per record
+    uint64_t rec_capacity = 0;                   // records
+    uint64_t n_pos = 0;                          // records stored
+    uint32_t* d_off = nullptr;                   // capacity + 1 record positions (entry e = [off[e], off[e + 1]))
+    std::vector<uint32_t> h_off;                 // count + 1
+    uint32_t ne_max = 0;                         // longest entry
 };

@@ -585,6 +585,33 @@ void lbo_corpus_best(const uint8_t* query, uint32_t n_query, const uint8_t* corp
     *best_score = best;
 }
 
+/* The same loop over a corpus whose entries have their own sub-fingerprint counts -- the shape upstream's test
+ * really has (LBAudioDetectiveTests.m:57-91: ten sequences of different lengths; Fingerprint.m:123-146 swaps and
+ * slides).  corpus = the entries' Booleans back to back, counts[e] sub-fingerprints each; scores_out (optional)
+ * receives every entry's match. */
+void lbo_corpus_best_ragged(const uint8_t* query, uint32_t n_query, const uint8_t* corpus, const uint32_t* counts,
+                            uint64_t n_entries, uint32_t subfp_len, uint32_t range, int nthreads,
+                            int64_t* best_index, float* best_score, float* scores_out) {
+    float* scores = scores_out ? scores_out : (float*)malloc(sizeof(float) * (n_entries ? n_entries : 1));
+    uint64_t* start = (uint64_t*)malloc(sizeof(uint64_t) * (n_entries + 1));
+    start[0] = 0;
+    for (uint64_t e = 0; e < n_entries; ++e) start[e + 1] = start[e] + counts[e];
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t e = 0; e < (int64_t)n_entries; ++e)
+        scores[e] = lbo_compare_fp(query, n_query, corpus + (size_t)start[e] * subfp_len, counts[e], subfp_len, range);
+    float best = 0.0f;                                               /* Tests.m:60 */
+    int64_t idx = -1;
+    for (uint64_t e = 0; e < n_entries; ++e)
+        if (best < scores[e]) { best = scores[e]; idx = (int64_t)e; }   /* Tests.m:80-83 */
+    free(start);
+    if (!scores_out) free(scores);
+    *best_index = idx;
+    *best_score = best;
+}
+
 /* ------------------------------------------------------------------------------------------
  * synthetic inputs (integer arithmetic only, so a device generator can match bit for bit)
  * ---------------------------------------------------------------------------------------- */
@@ -659,4 +686,10 @@ void lbo_synth_entry(uint32_t seed, uint64_t entry, uint32_t n_sub, uint32_t sub
             if (2 * p + 1 < subfp_len) row[2 * p + 1] = neg;
         }
     }
+}
+
+/* sub-fingerprint count of entry `entry` of the synthetic ragged corpus: lo..hi, uniform */
+uint32_t lbo_synth_ragged_count(uint32_t seed, uint64_t entry, uint32_t lo, uint32_t hi) {
+    const uint32_t r = mix32(seed ^ 0x52414747u ^ mix32((uint32_t)entry) ^ (uint32_t)(entry >> 32) * 0x632BE5ABu);
+    return lo + r % (hi - lo + 1u);
 }

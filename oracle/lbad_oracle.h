@@ -136,6 +136,12 @@ void lbo_corpus_best(const uint8_t* query, uint32_t n_query, const uint8_t* corp
                      uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len, uint32_t range,
                      int nthreads, int64_t* best_index, float* best_score);
 
+/* lbo_corpus_best for entries with their own sub-fingerprint counts (corpus = all entries' Booleans back to back);
+ * scores_out (optional, n_entries floats) receives every entry's match. */
+void lbo_corpus_best_ragged(const uint8_t* query, uint32_t n_query, const uint8_t* corpus, const uint32_t* counts,
+                            uint64_t n_entries, uint32_t subfp_len, uint32_t range, int nthreads,
+                            int64_t* best_index, float* best_score, float* scores_out);
+
 /* Deterministic integer synthetic PCM (bench/test input, not a reference function). */
 void lbo_synth_sine_table(int16_t* table1024);
 void lbo_synth_clip(uint32_t seed, uint64_t clip, double sample_rate, uint32_t n_samples,
@@ -143,6 +149,9 @@ void lbo_synth_clip(uint32_t seed, uint64_t clip, double sample_rate, uint32_t n
 /* Synthetic corpus entry: n_sub x subfp_len Booleans. */
 void lbo_synth_entry(uint32_t seed, uint64_t entry, uint32_t n_sub, uint32_t subfp_len,
                      uint8_t* out);
+/* Sub-fingerprint count of entry `entry` of the synthetic RAGGED corpus (uniform in lo..hi); its Booleans are
+ * lbo_synth_entry(seed, entry, count, ...). */
+uint32_t lbo_synth_ragged_count(uint32_t seed, uint64_t entry, uint32_t lo, uint32_t hi);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,9 @@ def lib():
     sig("lbo_compare_fp", C.c_float, [u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, C.c_uint32])
     sig("lbo_corpus_best", None, [u8p, C.c_uint32, u8p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                   C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)])
+    sig("lbo_corpus_best_ragged", None, [u8p, C.c_uint32, u8p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
+                                         C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_void_p])
+    sig("lbo_synth_ragged_count", C.c_uint32, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32])
     sig("lbo_synth_sine_table", None, [i16p])
     sig("lbo_synth_clip", None, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_int, f32p])
     sig("lbo_synth_entry", None, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, u8p])
@@ -263,6 +266,53 @@ def corpus_best(query: np.ndarray, corpus: np.ndarray, range_: int, nthreads: in
     lib().lbo_corpus_best(query.reshape(-1), query.shape[0], corpus.reshape(-1), n_entries, n_sub, L, range_,
                           nthreads, C.byref(bi), C.byref(bs))
     return int(bi.value), float(bs.value)
+
+
+def corpus_best_ragged(query: np.ndarray, entries, range_: int, nthreads: int = 1, want_scores: bool = False):
+    """Best-match loop over entries of different lengths: `entries` is a list of [n_e, L] Boolean arrays (or a
+    tuple (flat [sum n_e, L] array, counts))."""
+    query = np.ascontiguousarray(query, np.uint8)
+    if isinstance(entries, tuple):
+        flat, counts = entries
+        flat = np.ascontiguousarray(flat, np.uint8)
+        counts = np.ascontiguousarray(counts, np.uint32)
+    else:
+        counts = np.array([e.shape[0] for e in entries], np.uint32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(e, np.uint8) for e in entries], axis=0))
+    L = query.shape[1]
+    bi, bs = C.c_int64(-1), C.c_float(0.0)
+    scores = np.zeros(len(counts), np.float32) if want_scores else None
+    lib().lbo_corpus_best_ragged(query.reshape(-1), query.shape[0], flat.reshape(-1) if flat.size else np.zeros(1, np.uint8),
+                                 counts if counts.size else np.zeros(1, np.uint32), len(counts), L, range_, nthreads,
+                                 C.byref(bi), C.byref(bs), scores.ctypes.data_as(C.c_void_p) if want_scores else None)
+    return (int(bi.value), float(bs.value), scores) if want_scores else (int(bi.value), float(bs.value))
+
+
+def synth_ragged_counts(seed: int, first: int, count: int, lo: int, hi: int) -> np.ndarray:
+    """Sub-fingerprint counts of entries first .. first + count - 1 of the synthetic ragged corpus (vectorised
+    restatement of lbo_synth_ragged_count; checked against it in tests/test_oracle.py)."""
+    def mix32(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+        x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+        x ^= x >> np.uint32(16)
+        return x
+    e = np.arange(first, first + count, dtype=np.uint64)
+    lo32 = (e & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi32 = (e >> np.uint64(32)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        r = mix32(np.uint32(seed & 0xFFFFFFFF) ^ np.uint32(0x52414747) ^ mix32(lo32) ^ (hi32 * np.uint32(0x632BE5AB)))
+    return (np.uint32(lo) + r % np.uint32(hi - lo + 1)).astype(np.uint32)
+
+
+def synth_ragged_entries(seed: int, first: int, counts: np.ndarray, subfp_len: int) -> np.ndarray:
+    """Booleans of the entries first .. first + len(counts) - 1, back to back: [sum counts, subfp_len]."""
+    out = np.zeros((int(counts.sum()), subfp_len), np.uint8)
+    at = 0
+    for i, n in enumerate(counts):
+        lib().lbo_synth_entry(seed & 0xFFFFFFFF, first + i, int(n), subfp_len, out[at:at + int(n)].reshape(-1))
+        at += int(n)
+    return out
 
 
 def synth_sine_table() -> np.ndarray:

@@ -1,0 +1,208 @@
+"""GPU parity of the ragged corpus (entries of any length, query of any length) against the CPU oracle.
+
+The reference's corpus-shaped caller compares ONE file against ten of DIFFERENT lengths
+(LBAudioDetectiveTests.m:57-91) and LBAudioDetectiveFingerprintCompareToFingerprint swaps and slides for any
+n1 != n2 (LBAudioDetectiveFingerprint.m:119-149).  Scores are compared as float32 bit patterns, indices exactly.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CSEED = 0x4C424145
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rand_fp(rng, n, L, p_zero=0.03, p_both=0.0):
+    """n sub-fingerprints of L Booleans: sign pairs 10 / 01, some 00, optionally the 11 no extraction produces."""
+    pairs = (L + 1) // 2
+    pos = rng.random((n, pairs)) < 0.5
+    zero = rng.random((n, pairs)) < p_zero
+    both = rng.random((n, pairs)) < p_both
+    f = np.zeros((n, 2 * pairs), np.uint8)
+    f[:, 0::2] = (pos & ~zero) | both
+    f[:, 1::2] = (~pos & ~zero) | both
+    return np.ascontiguousarray(f[:, :L])
+
+
+def _ragged_corpus(lb, gpu, entries, L):
+    counts = np.array([e.shape[0] for e in entries], np.uint32)
+    c = lb.Corpus.ragged(L, len(entries), int(counts.sum()))
+    flat = np.concatenate(entries, axis=0)
+    packed = np.zeros((flat.shape[0], 8), np.uint32)
+    for i, row in enumerate(flat):
+        packed[i] = lb.pack_subfingerprint(row)
+    c.append_ragged_packed_device(gpu.from_numpy(packed.view(np.uint8).reshape(-1, 32)).cuda(), counts)
+    return c, counts
+
+
+def _check_query(lb, oracle, corpus, entries, q, rg):
+    bi, bs, want = oracle.corpus_best_ragged(q, entries, rg if rg else q.shape[1], want_scores=True)
+    fq = lb.Fingerprint.from_bools(q)
+    got = corpus.scores_device(fq, rg).cpu().numpy()
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert bad.size == 0, (q.shape, rg, bad[:5], got[bad[:5]], want[bad[:5]], [entries[i].shape[0] for i in bad[:5]])
+    idx, score = corpus.query(fq, rg)
+    assert idx == bi and np.float32(score).view(np.uint32) == np.float32(bs).view(np.uint32), (idx, score, bi, bs)
+
+
+@pytest.mark.parametrize("L", [200, 199, 33, 2, 1, 64])
+def test_ragged_random_shapes(lb, gpu, oracle, L):
+    """Random entries of 1..70 sub-fingerprints against queries shorter, equal and longer, all ranges; 11 pairs
+    and empty sub-fingerprints included; every entry's score and the top-1 equal the oracle's."""
+    rng = np.random.default_rng(1000 + L)
+    n_entries = 300
+    lens = rng.integers(1, 71, n_entries)
+    lens[:8] = [1, 2, 70, 21, 21, 20, 22, 64]
+    entries = [_rand_fp(rng, int(n), L, p_zero=0.05, p_both=0.02) for n in lens]
+    entries[9][:] = 0                                                    # an entry without any set Boolean
+    entries[10][1::2] = 0
+    corpus, _ = _ragged_corpus(lb, gpu, entries, L)
+    assert len(corpus) == n_entries and corpus.subfingerprint_total == int(lens.sum())
+    for nq in (1, 2, 5, 21, 48, 64, 70):
+        q = _rand_fp(rng, nq, L, p_zero=0.05, p_both=0.02)
+        src = entries[int(rng.integers(0, n_entries))]
+        k = min(nq, src.shape[0])
+        q[:k] = src[:k]                                                  # partly a copy of some entry
+        q[::2, : max(1, L // 5)] ^= 1
+        for rg in sorted({0, L, max(1, L // 2), 1, 7, L + 50, max(1, L - 1)}):
+            _check_query(lb, oracle, corpus, entries, q, rg)
+
+
+def test_ragged_long_query_against_long_entries(lb, gpu, oracle):
+    """Both sides long (a window reaches back 64 records or more): the per-entry kernel; and entries beyond the
+    saturation of the record's 12-bit position fields."""
+    rng = np.random.default_rng(77)
+    lens = [5000, 90, 64, 65, 4096, 200, 1, 130]
+    entries = [_rand_fp(rng, n, 200) for n in lens]
+    corpus, _ = _ragged_corpus(lb, gpu, entries, 200)
+    for nq in (64, 65, 100, 130, 300, 5, 48):
+        q = _rand_fp(rng, nq, 200)
+        src = entries[0]
+        k = min(nq, 60)
+        q[:k] = src[4500:4500 + k]
+        for rg in (0, 64):
+            _check_query(lb, oracle, corpus, entries, q, rg)
+
+
+def test_ragged_ties_zero_and_append(lb, gpu, oracle):
+    """Lowest index wins ties across entries of different lengths (T.m:80 strict '<'); a corpus that scores 0
+    selects nothing; entries appended one fingerprint at a time and in batches give the same corpus."""
+    rng = np.random.default_rng(5)
+    a = _rand_fp(rng, 30, 200)
+    entries = [_rand_fp(rng, 12, 200), a.copy(), _rand_fp(rng, 40, 200), np.concatenate([_rand_fp(rng, 7, 200), a]), a.copy()]
+    c = lb.Corpus.ragged(200, 16, 400)
+    for e in entries[:2]:
+        c.append_fingerprint(lb.Fingerprint.from_bools(e))
+    rest = entries[2:]
+    packed = np.stack([lb.pack_subfingerprint(r) for e in rest for r in e]).view(np.uint8).reshape(-1, 32)
+    c.append_ragged_packed_device(gpu.from_numpy(packed).cuda(), [e.shape[0] for e in rest])
+    q = a[5:26]
+    assert c.query(lb.Fingerprint.from_bools(q)) == (1, 1.0)
+    _check_query(lb, oracle, c, entries, q, 0)
+    zero = np.zeros((3, 200), np.uint8)
+    assert c.query(lb.Fingerprint.from_bools(zero)) == (-1, 0.0)
+    with pytest.raises(lb.LBAudioDetectiveError):
+        c.append_packed_device(gpu.zeros((1, 5, 32), dtype=gpu.uint8, device="cuda"))   # uniform append on a ragged corpus
+    with pytest.raises(lb.LBAudioDetectiveError):
+        lb.Corpus.ragged(256, 4, 16)                                                    # length above 200
+
+
+def test_ragged_save_load(lb, gpu, oracle, tmp_path):
+    rng = np.random.default_rng(9)
+    entries = [_rand_fp(rng, int(n), 200) for n in rng.integers(1, 60, 50)]
+    c, _ = _ragged_corpus(lb, gpu, entries, 200)
+    p = str(tmp_path / "ragged.lbad")
+    c.save(p)
+    d = lb.Corpus.load(p, 200, 0, 80)
+    assert len(d) == 50 and d.subfingerprint_total == c.subfingerprint_total
+    q = _rand_fp(rng, 21, 200)
+    q[:15] = entries[33][2:17]
+    _check_query(lb, oracle, d, entries, q, 0)
+    d.append_fingerprint(lb.Fingerprint.from_bools(q))                   # a loaded corpus keeps growing
+    assert d.query(lb.Fingerprint.from_bools(q)) == (50, 1.0)
+
+
+def test_birds_ten_archives_in_one_corpus(lb, gpu, oracle):
+    """Upstream's best-match loop as corpus queries on its own fixtures (LBAudioDetectiveTests.m:57-91).  The ten
+    archive recordings (48 .. 115 sub-fingerprints each) live in ONE corpus and each of the 50 sequences is one
+    query whose per-entry scores are a column of the test's 10 x 10 matrix; then the literal arrangement: the ten
+    sequences of a test are the corpus and each original is the query, top-1 = the test's `maxMatch` / `failed`.
+    Both equal the pairwise LBAudioDetectiveFingerprintCompareToFingerprint calls and the oracle bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import birds_matrix as bm
+    suffixes = [bm.ESSAY["tests"][t]["suffix"] for t in bm.TESTS]
+    names = bm.BIRDS + [b + s for s in suffixes for b in bm.BIRDS]
+    fps = bm.fingerprints_gpu(names, 1, 1, 0)
+    archives = [fps[b] for b in bm.BIRDS]
+    assert len({a.shape[0] for a in archives}) > 1                       # really of different lengths
+    corpus, _ = _ragged_corpus(lb, gpu, archives, 200)
+    pairwise = bm.matrices("gpu")                                        # 100 pairwise calls per test
+    for t, s in zip(bm.TESTS, suffixes):
+        seqs = [fps[b + s] for b in bm.BIRDS]
+        m = np.zeros((10, 10), np.float32)
+        for j, q in enumerate(seqs):                                     # 50 queries in all
+            fq = lb.Fingerprint.from_bools(q)
+            m[:, j] = corpus.scores_device(fq).cpu().numpy()
+            bi, bs, want = oracle.corpus_best_ragged(q, archives, 200, want_scores=True)
+            assert np.array_equal(m[:, j].view(np.uint32), want.view(np.uint32)), (t, j)
+            assert corpus.query(fq) == (bi, bs)
+        assert np.array_equal(m.astype(np.float64) * 100.0, pairwise[t]), t
+        seq_corpus, _ = _ragged_corpus(lb, gpu, seqs, 200)
+        for i, a in enumerate(archives):
+            want_i = int(np.argmax(pairwise[t][i])) if pairwise[t][i].max() > 0 else -1
+            idx, score = seq_corpus.query(lb.Fingerprint.from_bools(a))
+            assert idx == want_i and np.float64(np.float32(score)) * 100.0 == pairwise[t][i].max(), (t, i)
+    assert bm.check(pairwise) == []
+
+
+@pytest.mark.parametrize("n", [1_000_000])
+def test_full_size_ragged_corpus(lb, gpu, oracle, n):
+    """1 M synthetic entries of 20..70 sub-fingerprints (45 M records, 1.44 GB), query of 21 cut out of entry
+    777 777 with 7 % of its pairs flipped.  Bit-equal to the oracle on a 20 000-entry sample of per-entry scores;
+    at full size: the planted entry wins, a twin appended behind it loses the tie to the lower index, shards
+    queried separately reduce to the same key."""
+    counts = oracle.synth_ragged_counts(CSEED, 0, n, 20, 70)
+    assert all(int(counts[i]) == oracle.lib().lbo_synth_ragged_count(CSEED, i, 20, 70) for i in (0, 1, 777_777, n - 1))
+    total = int(counts.sum())
+    packed = lb.synth_ragged_corpus_device(CSEED, 0, counts, 200)
+    corpus = lb.Corpus.ragged(200, n + 1, total + 80)
+    corpus.append_ragged_packed_device(packed, counts)
+    planted = 777_777
+    src = oracle.synth_entry(CSEED, planted, int(counts[planted]), 200)
+    q = src[3:24].copy()
+    rng = np.random.default_rng(3)
+    flip = rng.random((21, 100)) < 0.07
+    pos = q[:, 0::2].copy()
+    q[:, 0::2] = np.where(flip, q[:, 1::2], pos)
+    q[:, 1::2] = np.where(flip, pos, q[:, 1::2])
+    fq = lb.Fingerprint.from_bools(q)
+    scores = corpus.scores_device(fq).cpu().numpy()
+    # sample: the first 10 000, the planted entry's neighbourhood, the last 5 000
+    for lo, hi in ((0, 10_000), (planted - 2_500, planted + 2_500), (n - 5_000, n)):
+        ent = oracle.synth_ragged_entries(CSEED, lo, counts[lo:hi], 200)
+        _, _, want = oracle.corpus_best_ragged(q, (ent, counts[lo:hi]), 200, nthreads=8, want_scores=True)
+        assert np.array_equal(scores[lo:hi].view(np.uint32), want.view(np.uint32)), (lo, hi)
+    idx, score = corpus.query(fq)
+    assert idx == planted and np.float32(score).view(np.uint32) == scores[planted].view(np.uint32)
+    assert int(np.argmax(scores)) == planted and 0.9 < score < 0.96
+    # twin of the planted entry behind everything: equal score, the lower index wins (T.m:80)
+    corpus.append_fingerprint(lb.Fingerprint.from_bools(src))
+    assert corpus.query(fq) == (planted, score)
+    # four shards of the same data, keys max-reduced like the sharded query does
+    off = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])
+    keys = gpu.zeros(4, dtype=gpu.int64, device="cuda")
+    bounds = [0, n // 4, n // 2, 3 * n // 4, n]
+    shards = []
+    for r in range(4):
+        lo, hi = bounds[r], bounds[r + 1]
+        sh = lb.Corpus.ragged(200, hi - lo, int(off[hi] - off[lo]))
+        sh.append_ragged_packed_device(packed[int(off[lo]):int(off[hi])], counts[lo:hi])
+        sh.query_key_device(fq, keys[r:r + 1], index_base=lo)
+        shards.append(sh)
+    gpu.cuda.synchronize()
+    best = max(int(k) & 0xFFFFFFFFFFFFFFFF for k in keys.cpu().numpy().astype(np.uint64))
+    assert lb.Corpus.decode_key(best) == (planted, score)
