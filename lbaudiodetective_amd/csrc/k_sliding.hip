@@ -68,48 +68,81 @@ __device__ __forceinline__ unsigned long long sl_key(float score, uint64_t globa
            (unsigned long long)(0xFFFFFFFFu - (uint32_t)global_index);
 }
 
-// acc of lane l - 1; lane 0 receives -inf (a diagonal that began in an earlier chunk)
-__device__ __forceinline__ float shift_right_one(float acc) {
-    const int ninf = (int)0xFF800000u;
-    return __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(acc), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+// value of lane l - 1 (lane 0 receives 0; whatever enters a chunk from the left belongs to a window that is not
+// wholly inside the chunk and is never used)
+__device__ __forceinline__ float from_left_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
 }
 
-// MODE 0: every lane's entry is longer than the query; 1: none is; 2: mixed
-template <int MODE>
-__device__ __forceinline__ void run_steps(const Rec& r, const uint32_t (&nz_e)[4], uint32_t tri_e, bool case_a, bool start_b,
-                                          const uint32_t* __restrict__ q, uint32_t nq, const float* s_tri, float& acc_out,
-                                          int& smax_out) {
-    float acc = __int_as_float((int)0xFF800000u);
-    int smax = (int)0xFF800000u;   // float bits as a signed integer: -inf sorts below every sum >= 0
+constexpr int kNegInf = (int)0xFF800000u;   // -inf; as a signed integer it sorts below the bits of every sum >= 0
+
+// One chunk = 64 K consecutive records; lane l holds records K l .. K l + K - 1, so a diagonal moves from register
+// set k - 1 to set k inside the lane and crosses to the next lane only from set K - 1 to set 0.
+// MODE 0: every entry in the chunk is longer than the query; 1: none is; 2: mixed.
+template <int K, int MODE>
+__device__ __forceinline__ void run_steps(const uint32_t (&P)[K][4], const uint32_t (&N)[K][4], const uint32_t (&nz)[K][4],
+                                          const uint32_t (&tri)[K], const bool (&case_a)[K], const bool (&start_b)[K],
+                                          const uint32_t* __restrict__ q, uint32_t nq, const float* s_tri,
+                                          float (&acc)[K], int (&smax)[K]) {
+    // MODE 2: the mask of a cell is the entry's NZ in A lanes and the query's in B lanes:
+    //   m = sel_e & (nz_q | sel_a)   with sel_e = A ? nz_e : ~0,  sel_a = A ? ~0 : 0     (one v_bitop3)
+    uint32_t sel_e[K][4], sel_a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        acc[k] = MODE == 0 ? 0.0f : __int_as_float(kNegInf);   // MODE 0: step 0 adds to the zeros, no reset needed
+        smax[k] = kNegInf;
+        sel_a[k] = case_a[k] ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sel_e[k][w] = case_a[k] ? nz[k][w] : 0xFFFFFFFFu;
+    }
     for (uint32_t a = 0; a < nq; ++a) {
         const uint32_t* __restrict__ qa = q + (size_t)a * kQWords;
-        uint32_t hits = 0;
+        uint32_t nzq[4] = {0, 0, 0, 0}, triq = 0;
+        if (MODE != 0) {
+            // the query's mask and table row in vector registers, once per step for the K cells (a VALU
+            // instruction reads one scalar operand only)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint32_t t = (r.P[w] ^ qa[w]) | (r.N[w] ^ qa[4 + w]);
-            const uint32_t nz = MODE == 0 ? nz_e[w] : MODE == 1 ? qa[8 + w] : (case_a ? nz_e[w] : qa[8 + w]);
-            hits += __popc(nz & ~t);
+            for (int w = 0; w < 4; ++w) asm("v_mov_b32 %0, %1" : "=v"(nzq[w]) : "s"(qa[8 + w]));
+            asm("v_mov_b32 %0, %1" : "=v"(triq) : "s"(qa[12]));
         }
-        const uint32_t tb = MODE == 0 ? tri_e : MODE == 1 ? qa[12] : (case_a ? tri_e : qa[12]);
-        const float ratio = s_tri[tb + hits];
-        float sh = shift_right_one(acc);
-        if (MODE == 0) sh = a == 0 ? 0.0f : sh;
-        if (MODE == 1) sh = start_b ? 0.0f : sh;
-        if (MODE == 2) sh = (start_b || (a == 0 && case_a)) ? 0.0f : sh;
-        acc = __fadd_rn(sh, ratio);
-        if (MODE != 0) smax = max(smax, __float_as_int(acc));
+        float ratio[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t h0 = MODE == 0 ? tri[k] : MODE == 1 ? triq : (case_a[k] ? tri[k] : triq);
+            uint32_t h = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                // a & ~(b ^ c), twice: two v_bitop3_b32 per word (left to itself the compiler builds xor, xor, bitop3)
+                uint32_t m = MODE == 0 ? nz[k][w] : nzq[w];
+                if (MODE == 2) m = __builtin_amdgcn_bitop3_b32(sel_e[k][w], nzq[w], sel_a[k], 0xE0);   // a & (b | c)
+                const uint32_t u = __builtin_amdgcn_bitop3_b32(m, P[k][w], qa[w], 0x90);
+                const uint32_t v = __builtin_amdgcn_bitop3_b32(u, N[k][w], qa[4 + w], 0x90);
+                // h += popc(v) as ONE accumulating v_bcnt (the compiler distributes the table's * 4 over the sum)
+                if (w == 0) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(v), "v"(h0));   // starts at the table row
+                else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(v));
+            }
+            ratio[k] = s_tri[h];
+        }
+        const float in0 = from_left_lane(acc[K - 1]);
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            float sh = k ? acc[k - 1] : in0;
+            if (MODE == 1) sh = start_b[k] ? 0.0f : sh;
+            if (MODE == 2) sh = (start_b[k] || (a == 0 && case_a[k])) ? 0.0f : sh;
+            acc[k] = __fadd_rn(sh, ratio[k]);
+            if (MODE != 0) smax[k] = max(smax[k], __float_as_int(acc[k]));
+        }
     }
-    acc_out = acc;
-    smax_out = smax;
 }
 
+template <int K>
 __global__ __launch_bounds__(kSlThreads) void compare_sliding_kernel(
     const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
-    uint64_t n_chunks, uint4 range_mask, const float* __restrict__ tri, uint64_t index_base,
+    uint64_t n_chunks, uint4 range_mask, const float* __restrict__ tri_tbl, uint64_t index_base,
     unsigned int* __restrict__ score_bits, unsigned long long* __restrict__ key_out) {
     __shared__ float s_tri[kTriSize];
     __shared__ unsigned long long s_k[kSlThreads / 64];
-    for (uint32_t i = threadIdx.x; i < kTriSize; i += kSlThreads) s_tri[i] = tri[i];
+    for (uint32_t i = threadIdx.x; i < kTriSize; i += kSlThreads) s_tri[i] = tri_tbl[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -119,45 +152,63 @@ __global__ __launch_bounds__(kSlThreads) void compare_sliding_kernel(
     unsigned long long best = 0ull;
 
     for (uint64_t c = wave; c < n_chunks; c += n_waves) {
-        const uint64_t p = c * chunk_step + lane;
-        const bool inb = p < n_pos;
-        uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
-        if (inb) {
-            ra = recs[2 * p];
-            rb = recs[2 * p + 1];
-        }
-        const Rec r = unpack_rec(ra, rb);
-        const uint32_t ne = r.isat + r.rem + 1u;       // saturated; exact whenever it is <= nq
-        const bool case_a = ne > nq;                   // the entry is the longer side (Fp.m:123-131)
-        const uint32_t n2 = case_a ? nq : ne;
-        uint32_t nz_e[4];
-        uint32_t possible = 0;
+        const uint64_t p0 = c * chunk_step + (uint64_t)lane * K;
+        uint32_t P[K][4], N[K][4], nz[K][4], tri[K], isat[K], rem[K], idx[K], n2[K];
+        bool case_a[K], start_b[K], inb[K];
+        bool some_a = false, some_b = false;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            nz_e[w] = (r.P[w] | r.N[w]) & rm[w];
-            possible += __popc(nz_e[w]);
+        for (int k = 0; k < K; ++k) {
+            inb[k] = p0 + k < n_pos;
+            uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+            if (inb[k]) {
+                ra = recs[2 * (p0 + k)];
+                rb = recs[2 * (p0 + k) + 1];
+            }
+            const Rec r = unpack_rec(ra, rb);
+            uint32_t possible = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                P[k][w] = r.P[w];
+                N[k][w] = r.N[w];
+                nz[k][w] = (r.P[w] | r.N[w]) & rm[w];
+                possible += __popc(nz[k][w]);
+            }
+            tri[k] = possible * (possible + 1u) / 2u;
+            isat[k] = r.isat; rem[k] = r.rem; idx[k] = r.idx;
+            const uint32_t ne = r.isat + r.rem + 1u;       // saturated; exact whenever it is <= nq
+            case_a[k] = ne > nq;                           // the entry is the longer side (Fp.m:123-131)
+            n2[k] = case_a[k] ? nq : ne;
+            start_b[k] = !case_a[k] && r.isat == 0u;
+            some_a |= case_a[k] && inb[k];
+            some_b |= !case_a[k] && inb[k];
         }
-        const uint32_t tri_e = possible * (possible + 1u) / 2u;
-        const bool start_b = !case_a && r.isat == 0u;
-        const unsigned long long any_a = __ballot(case_a && inb);
-        const unsigned long long any_b = __ballot(!case_a && inb);
+        const bool any_a = __ballot(some_a) != 0ull, any_b = __ballot(some_b) != 0ull;
 
-        float acc;
-        int smax;
-        if (any_b == 0ull) run_steps<0>(r, nz_e, tri_e, case_a, start_b, q, nq, s_tri, acc, smax);
-        else if (any_a == 0ull) run_steps<1>(r, nz_e, tri_e, case_a, start_b, q, nq, s_tri, acc, smax);
-        else run_steps<2>(r, nz_e, tri_e, case_a, start_b, q, nq, s_tri, acc, smax);
+        float acc[K];
+        int smax[K];
+        if (!any_b) run_steps<K, 0>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
+        else if (!any_a) run_steps<K, 1>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
+        else run_steps<K, 2>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
 
-        // the lane closes a window iff the window lies inside its entry AND inside this chunk
-        const bool closes = case_a ? (r.isat >= nq - 1u) : (r.rem == 0u);
-        const bool valid = inb && closes && lane >= n2 - 1u;
-        const float s = case_a ? acc : __int_as_float(smax);
-        if (valid) {
-            const float cand = __fdiv_rn(s, (float)n2);                  // Fp.m:144
-            const float match = (0.0f < cand) ? cand : 0.0f;             // MAX(match, cand) from match = 0
-            if (score_bits) atomicMax(&score_bits[r.idx], __float_as_uint(match));
-            const unsigned long long k = sl_key(match, index_base + r.idx);
-            best = k > best ? k : best;
+        // a record closes a window iff the window lies inside its entry AND inside this chunk.  The exact
+        // division (Fp.m:144) runs only where the sum can reach the lane's best so far.
+        const float thr = __uint_as_float((uint32_t)(best >> 32)) * 0.99999f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool closes = case_a[k] ? (isat[k] >= nq - 1u) : (rem[k] == 0u);
+            const bool valid = inb[k] && closes && lane * K + k >= n2[k] - 1u;
+            const float s = case_a[k] ? acc[k] : __int_as_float(smax[k]);
+            const float n2f = (float)n2[k];
+            const bool need = valid && (score_bits != nullptr || s >= thr * n2f);
+            if (__ballot(need) != 0ull) {
+                if (need) {
+                    const float cand = __fdiv_rn(s, n2f);
+                    const float match = (0.0f < cand) ? cand : 0.0f;         // MAX(match, cand) from match = 0
+                    if (score_bits) atomicMax(&score_bits[idx[k]], __float_as_uint(match));
+                    const unsigned long long key = sl_key(match, index_base + idx[k]);
+                    best = key > best ? key : best;
+                }
+            }
         }
     }
 #pragma unroll
@@ -418,7 +469,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     const uint4 rm = sliding_range_mask(subfp_len, range);
     const uint32_t look = (n_query < ne_max ? n_query : ne_max) - 1u;   // records a window reaches back
     const int cus = device_cu_count();
-    if (look >= 48u) {
+    if (look >= 64u) {
         const uint64_t cap = (uint64_t)cus * 8u;
         const uint32_t grid = (uint32_t)(n_entries < cap ? n_entries : cap);
         hipLaunchKernelGGL(compare_ragged_long_kernel, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, d_off, n_entries,
@@ -427,13 +478,20 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     }
     const float* tri = sliding_tri_table();
     if (!tri) return hipErrorOutOfMemory;
-    const uint32_t step = 64u - look;
-    const uint64_t n_chunks = n_pos <= 64u ? 1u : (n_pos - 64u + step - 1u) / step + 1u;
+    // 64 K records per wave and chunk; a short overlap relative to the chunk keeps the repeated work small
+    const uint32_t K = look <= 6u ? 1u : 4u;
+    const uint32_t step = 64u * K - look;
+    const uint64_t span = 64ull * K;
+    const uint64_t n_chunks = n_pos <= span ? 1u : (n_pos - span + step - 1u) / step + 1u;
     const uint64_t want = (n_chunks + (kSlThreads / 64) - 1) / (kSlThreads / 64);
     const uint64_t cap = (uint64_t)cus * 6u;                             // 21 KB of LDS per workgroup
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    hipLaunchKernelGGL(compare_sliding_kernel, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_qblk, n_query,
-                       step, n_chunks, rm, tri, index_base, d_score_bits, d_key);
+    if (K == 1)
+        hipLaunchKernelGGL(compare_sliding_kernel<1>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_qblk,
+                           n_query, step, n_chunks, rm, tri, index_base, d_score_bits, d_key);
+    else
+        hipLaunchKernelGGL(compare_sliding_kernel<4>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_qblk,
+                           n_query, step, n_chunks, rm, tri, index_base, d_score_bits, d_key);
     return hipGetLastError();
 }
 
