@@ -84,6 +84,7 @@ extern const OSStatus kLBAudioDetectiveDeviceUnavailable;         /* 'nogp' */
 extern const OSStatus kLBAudioDetectiveDeviceError;               /* 'gper' */
 extern const OSStatus kLBAudioDetectiveUnsupportedFile;           /* 'fmt?' */
 extern const OSStatus kLBAudioDetectiveMemFull;                   /* -108 (MacErrors.h memFullErr): a host allocation failed */
+extern const OSStatus kLBAudioDetectiveCollectiveError;           /* 'rccl': RCCL missing or a collective failed */
 
 typedef struct LBAudioDetective* LBAudioDetectiveRef;                       /* D.h:22 */
 typedef struct LBAudioDetectiveFingerprint* LBAudioDetectiveFingerprintRef; /* Fp.h:11 */
@@ -353,6 +354,29 @@ OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef inCorpus, LBAudio
 OSStatus LBAudioDetectiveCorpusQueryKeyDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                               UInt32 inRange, UInt64 inIndexBase, void* outKey, void* inStream);
 void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* outScore);
+/* Sharded query with the exchange step inside the library (one process per GPU, every rank holds a contiguous
+ * index range of the corpus and calls this with the same query): scan of this rank's entries, then ONE
+ * ncclAllReduce(count = number of queries, ncclUint64, ncclMax) of the keys over RCCL / xGMI on inStream, then the
+ * 8-byte read-back; every rank receives the global best match, the lowest global index winning ties
+ * (LBAudioDetectiveTests.m:80-83 across shards).  inComm is an ncclComm_t passed as void* -- the caller's own, or
+ * one made with LBAudioDetectiveCommInitRank.  RCCL is loaded on first use (librccl.so.1; a copy already in the
+ * process is reused).  ArgumentInvalid when inIndexBase + the shard's entry count exceeds 2^32 (the key carries
+ * a 32-bit global index). */
+OSStatus LBAudioDetectiveCorpusQuerySharded(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
+                                            UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
+                                            SInt64* outIndex, Float32* outScore);
+OSStatus LBAudioDetectiveCorpusQueryBatchSharded(LBAudioDetectiveCorpusRef inCorpus,
+                                                 const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
+                                                 UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
+                                                 SInt64* outIndices, Float32* outScores);
+/* Communicator helpers for hosts without an RCCL binding of their own: rank 0 obtains a 128-byte id
+ * (LBAD_COMM_UNIQUE_ID_BYTES) and hands it to the other ranks by whatever means the host has (a file, a socket,
+ * MPI, torch.distributed ...); then every rank calls InitRank with the current HIP device set.  Thin wrappers
+ * of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy. */
+#define LBAD_COMM_UNIQUE_ID_BYTES 128
+OSStatus LBAudioDetectiveCommGetUniqueId(void* outUniqueId);
+OSStatus LBAudioDetectiveCommInitRank(void** outComm, SInt32 inNumberOfRanks, const void* inUniqueId, SInt32 inRank);
+OSStatus LBAudioDetectiveCommDestroy(void* inComm);
 /* Several queries against one pass over the corpus (the scan is HBM-bound: up to 8 queries share each
  * read of an entry).  Results are those of inCount separate LBAudioDetectiveCorpusQuery calls.  The
  * KeysDevice form writes inCount keys to the device pointer outKeys for a sharded max-reduction. */
@@ -388,6 +412,7 @@ OSStatus LBAudioDetectiveSynthCorpusDevice(UInt32 inSeed, UInt64 inFirstEntry, U
 
 /* ---- minimal device plumbing for hosts without a HIP binding --------------------------- */
 SInt32 LBAudioDetectiveDeviceCount(void);
+OSStatus LBAudioDetectiveDeviceSet(SInt32 inDevice);   /* the current device of this thread (one process drives one GPU) */
 OSStatus LBAudioDetectiveDeviceMalloc(void** outPointer, UInt64 inBytes);
 OSStatus LBAudioDetectiveDeviceFree(void* inPointer);
 OSStatus LBAudioDetectiveDeviceCopyIn(void* inDevice, const void* inHost, UInt64 inBytes);

@@ -127,6 +127,12 @@ _SIGNATURES = {
     "LBAudioDetectiveCorpusGetSubfingerprintTotal": (UInt64, [Ref]),
     "LBAudioDetectiveSynthRaggedCorpusDevice": (OSStatus, [UInt32, UInt64, UInt64, C.c_void_p, UInt64, UInt32, C.c_void_p,
                                                            C.c_void_p]),
+    "LBAudioDetectiveCorpusQuerySharded": (OSStatus, [Ref, Ref, UInt32, UInt64, C.c_void_p, C.c_void_p, _P(SInt64), _P(Float32)]),
+    "LBAudioDetectiveCorpusQueryBatchSharded": (OSStatus, [Ref, _P(Ref), UInt32, UInt32, UInt64, C.c_void_p, C.c_void_p,
+                                                           _P(SInt64), _P(Float32)]),
+    "LBAudioDetectiveCommGetUniqueId": (OSStatus, [C.c_void_p]),
+    "LBAudioDetectiveCommInitRank": (OSStatus, [_P(C.c_void_p), SInt32, C.c_void_p, SInt32]),
+    "LBAudioDetectiveCommDestroy": (OSStatus, [C.c_void_p]),
     "LBAudioDetectiveCorpusDispose": (None, [Ref]),
     "LBAudioDetectiveCorpusGetCount": (UInt64, [Ref]),
     "LBAudioDetectiveCorpusGetEntryStrideBytes": (UInt32, [Ref]),
@@ -144,6 +150,7 @@ _SIGNATURES = {
     "LBAudioDetectiveSynthClipsDevice": (OSStatus, [UInt32, UInt64, UInt64, UInt32, UInt32, UInt32, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveSynthCorpusDevice": (OSStatus, [UInt32, UInt64, UInt64, UInt32, UInt32, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveDeviceCount": (SInt32, []),
+    "LBAudioDetectiveDeviceSet": (OSStatus, [SInt32]),
     "LBAudioDetectiveDeviceMalloc": (OSStatus, [_P(C.c_void_p), UInt64]),
     "LBAudioDetectiveDeviceFree": (OSStatus, [C.c_void_p]),
     "LBAudioDetectiveDeviceCopyIn": (OSStatus, [C.c_void_p, C.c_void_p, UInt64]),
@@ -162,6 +169,7 @@ CONSTANTS = {
     "kLBAudioDetectiveDeviceError": OSStatus,
     "kLBAudioDetectiveUnsupportedFile": OSStatus,
     "kLBAudioDetectiveMemFull": OSStatus,
+    "kLBAudioDetectiveCollectiveError": OSStatus,
 }
 
 _lib = None

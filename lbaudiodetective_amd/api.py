@@ -527,6 +527,23 @@ class Corpus:
                                                            _stream_ptr(stream)), "CorpusQueryKeyDevice")
         return key_out
 
+    def query_sharded(self, fp: Fingerprint, comm: "Comm", index_base: int = 0, range_: int = 0, stream=None):
+        """LBAudioDetectiveCorpusQuerySharded: this rank's scan + the library's own RCCL all-reduce (ncclUint64,
+        ncclMax) of the key; collective, every rank gets (global index, score)."""
+        idx, score = N.SInt64(-1), N.Float32(0.0)
+        _check(self._L.LBAudioDetectiveCorpusQuerySharded(self._ref, fp._ref, range_, index_base, comm._ref,
+                                                         _stream_ptr(stream), C.byref(idx), C.byref(score)),
+               "CorpusQuerySharded")
+        return int(idx.value), float(score.value)
+
+    def query_batch_sharded(self, fps, comm: "Comm", index_base: int = 0, range_: int = 0, stream=None):
+        n = len(fps)
+        refs = (N.Ref * n)(*[f._ref for f in fps])
+        idx, sc = (N.SInt64 * n)(), (N.Float32 * n)()
+        _check(self._L.LBAudioDetectiveCorpusQueryBatchSharded(self._ref, refs, n, range_, index_base, comm._ref,
+                                                              _stream_ptr(stream), idx, sc), "CorpusQueryBatchSharded")
+        return [(int(idx[i]), float(sc[i])) for i in range(n)]
+
     def scores_device(self, fp: Fingerprint, range_: int = 0, stream=None):
         import torch
         out = torch.empty(len(self), dtype=torch.float32, device="cuda")
@@ -539,6 +556,39 @@ class Corpus:
         idx, score = N.SInt64(-1), N.Float32(0.0)
         N.lib().LBAudioDetectiveCorpusDecodeKey(key & 0xFFFFFFFFFFFFFFFF, C.byref(idx), C.byref(score))
         return int(idx.value), float(score.value)
+
+
+class Comm:
+    """An RCCL communicator made through the library's helpers (ncclCommInitRank with the current device).
+    `unique_id()` on rank 0, the 128 bytes travel to the other ranks by whatever means the host has, then every
+    rank constructs Comm(n_ranks, unique_id, rank)."""
+
+    UNIQUE_ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(Comm.UNIQUE_ID_BYTES)
+        _check(N.lib().LBAudioDetectiveCommGetUniqueId(buf), "CommGetUniqueId")
+        return buf.raw
+
+    def __init__(self, n_ranks: int, unique_id: bytes, rank: int):
+        assert len(unique_id) == Comm.UNIQUE_ID_BYTES
+        self._L = N.lib()
+        self.n_ranks, self.rank = n_ranks, rank
+        ref = C.c_void_p()
+        _check(self._L.LBAudioDetectiveCommInitRank(C.byref(ref), n_ranks, unique_id, rank), "CommInitRank")
+        self._ref = ref
+
+    def dispose(self):
+        if getattr(self, "_ref", None):
+            self._L.LBAudioDetectiveCommDestroy(self._ref)
+            self._ref = None
+
+    def __del__(self):
+        try:
+            self.dispose()
+        except Exception:
+            pass
 
 
 def read_audio_url(path: str, sample_rate: float = 0.0, resampler: int = 0):

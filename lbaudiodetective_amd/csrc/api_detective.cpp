@@ -812,6 +812,10 @@ SInt32 LBAudioDetectiveDeviceCount(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
+OSStatus LBAudioDetectiveDeviceSet(SInt32 inDevice) {
+    LBAD_HIP(hipSetDevice(inDevice));
+    return noErr;
+}
 OSStatus LBAudioDetectiveDeviceMalloc(void** outPointer, UInt64 inBytes) {
     if (!outPointer) return kLBAudioDetectiveArgumentInvalid;
     if (!lbad::device_ready()) return kLBAudioDetectiveDeviceUnavailable;

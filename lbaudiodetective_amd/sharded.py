@@ -92,13 +92,27 @@ def broadcast_fingerprint(fp, src: int = 0, group=None, device=None):
     return out
 
 
+def make_comm(rank: int = 0, world_size: int = 1, group=None):
+    """The library's own RCCL communicator for the sharded query (LBAudioDetectiveCommInitRank).  Rank 0 obtains
+    the 128-byte id; torch.distributed -- plumbing, whatever backend it runs on -- carries it to the other ranks.
+    The current CUDA/HIP device must already be this rank's."""
+    from .api import Comm
+    uid = [Comm.unique_id() if rank == 0 else None]
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.broadcast_object_list(uid, src=0, group=group)
+    return Comm(world_size, uid[0], rank)
+
+
 class ShardedCorpus:
-    """This rank's shard of a global corpus plus the collective top-1 query."""
+    """This rank's shard of a global corpus plus the collective top-1 query.  With `comm` (make_comm) the
+    exchange step runs inside the library (ncclAllReduce of the uint64 keys, LBAudioDetectiveCorpusQuerySharded);
+    without it the keys are reduced through torch.distributed (the CPU tests use gloo)."""
 
     def __init__(self, subfingerprint_length: int, subfingerprints_per_entry: int, n_entries_global: int,
-                 rank: int = 0, world_size: int = 1, group=None):
+                 rank: int = 0, world_size: int = 1, group=None, comm=None):
         from .api import Corpus
-        self.rank, self.world_size, self.group = rank, world_size, group
+        self.rank, self.world_size, self.group, self.comm = rank, world_size, group, comm
         self.n_entries_global = n_entries_global
         self.begin, self.end = shard_range(n_entries_global, rank, world_size)
         self.local = Corpus(subfingerprint_length, subfingerprints_per_entry, max(1, self.end - self.begin))
@@ -108,6 +122,8 @@ class ShardedCorpus:
 
     def query_batch(self, fps, range_: int = 0, keys_out=None):
         """Collective: several queries, one pass over every shard, one all-reduce of len(fps) int64 keys."""
+        if self.comm is not None:
+            return self.local.query_batch_sharded(fps, self.comm, self.begin, range_)
         import torch
         if keys_out is None:
             keys_out = torch.zeros(len(fps), dtype=torch.int64, device="cuda")
@@ -117,6 +133,8 @@ class ShardedCorpus:
 
     def query(self, fp, range_: int = 0, key_out=None):
         """Collective: every rank calls it with the same query; returns (global index, score)."""
+        if self.comm is not None:
+            return self.local.query_sharded(fp, self.comm, self.begin, range_)
         import torch
         if key_out is None:
             key_out = torch.zeros(1, dtype=torch.int64, device="cuda")

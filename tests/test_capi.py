@@ -15,7 +15,7 @@ def _has_gpu():
 
 def test_exports_every_declared_symbol(lb):
     funcs, consts = lb._native.declared_symbols()
-    assert len(funcs) >= 60 and len(consts) == 9
+    assert len(funcs) >= 60 and len(consts) == 10
     raw = C.CDLL(lb.LIB_PATH)
     for name in funcs + consts:
         assert hasattr(raw, name), f"{name} declared in include/lbaudiodetective.h but not exported"
@@ -157,14 +157,14 @@ def test_unsupported_and_missing_files(lb, tmp_path):
         lb.constant("kLBAudioDetectiveUnsupportedFile")
 
 
-def _build_example(tmp_path, lb):
+def _build_example(tmp_path, lb, name="compare_urls"):
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "compare_urls")
+    exe = str(tmp_path / name)
     libdir = os.path.dirname(lb.LIB_PATH)
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
-                           os.path.join(root, "examples", "compare_urls.c"), "-L", libdir, "-llbaudiodetective",
-                           "-Wl,-rpath," + libdir, "-o", exe])
+    subprocess.check_call(["gcc", "-std=c99", "-D_DEFAULT_SOURCE", "-Wall", "-Wextra", "-Werror", "-I",
+                           os.path.join(root, "include"), os.path.join(root, "examples", name + ".c"), "-L", libdir,
+                           "-llbaudiodetective", "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
 
@@ -180,6 +180,18 @@ def test_c_host_builds_against_the_header(lb, tmp_path):
         out = subprocess.run([exe, os.path.join(birds, "BlackBird.caf"), os.path.join(birds, "BlackBird_eql.caf")],
                              capture_output=True, text=True)
         assert out.returncode == 1 and "OSStatus" in out.stderr       # 'nogp': no fallback
+
+
+def test_sharded_c_host_builds_and_fails_loudly_without_gpu(lb, tmp_path):
+    """examples/sharded_query.c (one process per GPU, RCCL behind the C ABI, no Python) is plain C99 too; without a
+    GPU its first device call reports an OSStatus instead of computing anything."""
+    import subprocess
+    exe = _build_example(tmp_path, lb, "sharded_query")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 2 and "usage" in out.stderr
+    if not _has_gpu():
+        out = subprocess.run([exe, "0", "1", str(tmp_path / "id"), "1000"], capture_output=True, text=True)
+        assert out.returncode == 1 and "OSStatus" in out.stderr
 
 
 def test_out_of_range_indices_are_safe(lb):

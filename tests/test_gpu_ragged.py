@@ -206,3 +206,57 @@ def test_full_size_ragged_corpus(lb, gpu, oracle, n):
     gpu.cuda.synchronize()
     best = max(int(k) & 0xFFFFFFFFFFFFFFFF for k in keys.cpu().numpy().astype(np.uint64))
     assert lb.Corpus.decode_key(best) == (planted, score)
+
+
+# ---------------------------------------------------------------------------------------------
+# the exchange step inside the library: RCCL behind the C ABI
+# ---------------------------------------------------------------------------------------------
+def test_sharded_query_through_native_rccl(lb, gpu, oracle):
+    """LBAudioDetectiveCorpusQuerySharded at world size 1 through a REAL ncclCommInitRank (the library's own
+    dlopen-ed RCCL): scan + ncclAllReduce(ncclUint64, ncclMax) + read-back equals the plain query, for the uniform
+    and the ragged corpus, single and batched; the 32-bit global index is guarded."""
+    comm = lb.make_comm(0, 1)
+    n = 50_000
+    host = oracle.synth_corpus(CSEED, 0, 2000, 5, 200)
+    c = lb.Corpus(200, 5, n)
+    c.append_packed_device(lb.synth_corpus_device(CSEED, 0, n, 5, 200))
+    qs = []
+    for probe in (7, 1234, 1999):
+        q = host[probe].copy()
+        q[:, :14] ^= 1
+        qs.append(lb.Fingerprint.from_bools(q))
+    for fq in qs:
+        want = c.query(fq)
+        assert c.query_sharded(fq, comm) == want
+        base = 1_000_000
+        gi, gs = c.query_sharded(fq, comm, index_base=base)
+        assert (gi - base, gs) == want
+    assert c.query_batch_sharded(qs, comm) == [c.query(f) for f in qs]
+    with pytest.raises(lb.LBAudioDetectiveError):
+        c.query_sharded(qs[0], comm, index_base=2**32 - n + 1)          # index_base + count > 2^32
+    assert c.query_sharded(qs[0], comm, index_base=2**32 - n)[0] == 2**32 - n + 7
+    # ragged corpus, query of another length
+    rng = np.random.default_rng(21)
+    entries = [_rand_fp(rng, int(k), 200) for k in rng.integers(1, 60, 400)]
+    r, _ = _ragged_corpus(lb, gpu, entries, 200)
+    q = _rand_fp(rng, 21, 200)
+    q[:18] = entries[123][1:19] if entries[123].shape[0] >= 19 else q[:18]
+    fq = lb.Fingerprint.from_bools(q)
+    assert r.query_sharded(fq, comm, index_base=10) == (r.query(fq)[0] + 10, r.query(fq)[1])
+    # the Python sharded wrapper on the native path
+    sc = lb.ShardedCorpus(200, 5, n, rank=0, world_size=1, comm=comm)
+    sc.append_packed_device(lb.synth_corpus_device(CSEED, 0, n, 5, 200))
+    assert sc.query(qs[1]) == c.query(qs[1])
+    comm.dispose()
+
+
+def test_sharded_c_host_one_rank(lb, gpu, tmp_path):
+    """examples/sharded_query.c as its own process: a pure-C rank (no Python, no torch) builds its shard, creates
+    the communicator through the library and finds the planted entry."""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_capi import _build_example
+    exe = _build_example(tmp_path, lb, "sharded_query")
+    out = subprocess.run([exe, "0", "1", str(tmp_path / "rccl.id"), "3000000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "best match index 1777777 " in out.stdout and "score 0.919" in out.stdout, out.stdout
