@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio-seconds fingerprinted per second (BASELINE.json metric).
 
-One "step" = one pass of the fingerprint hot path (frame -> FFT -> sub-band energy -> Haar ->
-ranked sign bits) over the whole resident batch: 100 000 synthetic 1 s / 44.1 kHz mono clips,
-1024-point windows, stride 64 (BASELINE.json configs[1]).  Inputs are generated on the device
-before the timed region, outputs (5 x 32 bytes per clip) stay in HBM.
+One pass = the fingerprint hot path (frame -> FFT -> sub-band energy -> Haar -> ranked sign bits) over the
+whole resident batch: 100 000 synthetic 1 s / 44.1 kHz mono clips, 1024-point windows, stride 64
+(BASELINE.json configs[1]).  Inputs are generated on the device before the timed region, outputs (5 x 32 bytes
+per clip) stay in HBM.  One "step" = `passes_per_step` back-to-back passes over that batch: a pass takes ~20 ms,
+so a step is sized (from two calibration passes, before the warm-up) such that the K timed steps last at least
+--min-seconds (default 3 s) -- long enough for clocks and power to settle and for an outside sampler to see the
+GPU busy.  `value` is audio-seconds per second over the whole timed region either way; `ms_per_pass`,
+`passes_per_step`, the first and last quartile of the step times, the shader clock read inside a probe kernel
+and the board power sampled during the timed region are reported beside it.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -87,7 +92,99 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the side measurements of the configs[0] settings and of configs[4]")
     ap.add_argument("--cpu-sample", type=int, default=0, help="clips for the CPU baseline (0 = 4000 per thread)")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="lower bound of the timed region; a step becomes as many passes over the batch as that takes")
+    ap.add_argument("--passes-per-step", type=int, default=0, help="override the calibration (0 = from --min-seconds)")
+    ap.add_argument("--no-sliding", action="store_true", help="skip the ragged-corpus (sliding compare) leg")
+    ap.add_argument("--no-files", action="store_true", help="skip the file leg (BASELINE configs[0] on the bird fixtures)")
     return ap.parse_args(argv)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+class Telemetry:
+    """Board power / clocks (rocm-smi, hwmon as fallback) and the shader clock read inside a one-wave probe
+    kernel on a side stream, sampled from a thread while the timed region runs."""
+
+    def __init__(self, lb, torch, period=0.2):
+        import threading
+        self.lb, self.torch, self.period = lb, torch, period
+        self.stop_flag = False
+        self.smi, self.mhz = [], []
+        self.side = torch.cuda.Stream()
+        self.dev = torch.cuda.current_device()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def read_smi():
+        import glob
+        try:
+            r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+            card = next(iter(json.loads(r.stdout).values()))
+            out = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if "power" in kl and "(w)" in kl:
+                    out["power_w"] = float(v)
+                elif "sclk" in kl and "level" in kl:
+                    out["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
+            if out:
+                return out
+        except Exception:                                   # noqa: BLE001
+            pass
+        out = {}
+        for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"):
+            try:
+                out["power_w"] = int(open(f).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+        for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"):
+            try:
+                out["sclk_mhz"] = int(open(f).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+        return out
+
+    def _run(self):
+        self.torch.cuda.set_device(self.dev)
+        while not self.stop_flag:
+            t = time.perf_counter()
+            try:
+                self.mhz.append(self.lb.probe_shader_clock(self.side, 2000))
+            except Exception:                               # noqa: BLE001
+                pass
+            v = self.read_smi()
+            if v:
+                self.smi.append(v)
+            time.sleep(max(0.0, self.period - (time.perf_counter() - t)))
+
+    def start(self):
+        self.idle = self.read_smi()
+        self.thread.start()
+
+    def stop(self):
+        self.stop_flag = True
+        self.thread.join(timeout=10)
+
+    def summary(self):
+        def stats(xs):
+            xs = sorted(xs)
+            return None if not xs else {"min": round(xs[0], 1), "median": round(xs[len(xs) // 2], 1), "max": round(xs[-1], 1),
+                                        "samples": len(xs)}
+        return {"shader_clock_mhz_in_kernel": stats(self.mhz),
+                "board_power_w": stats([v["power_w"] for v in self.smi if "power_w" in v]),
+                "sclk_mhz_smi": stats([v["sclk_mhz"] for v in self.smi if "sclk_mhz" in v]),
+                "idle": self.idle,
+                "how": "probe kernel (s_memtime / s_memrealtime, 2 ms, side stream) and rocm-smi --showpower --showclocks, "
+                       "sampled from a thread during the timed region"}
 
 
 # ---- launcher ---------------------------------------------------------------------------------------
@@ -145,6 +242,154 @@ def profile_traffic(variant: int, clips_per_launch: float):
     except (OSError, ValueError, KeyError):
         return None, None
 
+
+
+# ---- side legs (one GPU) --------------------------------------------------------------------------------
+def sliding_leg(args, torch, np):
+    """Upstream's best-match loop in its real shape (LBAudioDetectiveTests.m:57-91: one fingerprint against
+    candidates of OTHER lengths, LBAudioDetectiveFingerprint.m:123-146 swaps and slides) as one corpus query:
+    1 M synthetic entries of 20..70 sub-fingerprints, query of 21 cut out of entry 777 777 with 7 % of its sign
+    pairs flipped."""
+    import lbaudiodetective_amd as lb
+    from oracle import oracle as O
+    n, lo, hi, nq = 1_000_000, 20, 70, 21
+    counts = O.synth_ragged_counts(CSEED, 0, n, lo, hi)
+    total = int(counts.sum())
+    packed = lb.synth_ragged_corpus_device(CSEED, 0, counts, 200)
+    corpus = lb.Corpus.ragged(200, n, total)
+    corpus.append_ragged_packed_device(packed, counts)
+    del packed
+    src = O.synth_entry(CSEED, PLANTED_1GPU, int(counts[PLANTED_1GPU]), 200)
+    q = src[3:3 + nq].copy()
+    flip = np.random.default_rng(3).random((nq, 100)) < 0.07
+    pos = q[:, 0::2].copy()
+    q[:, 0::2] = np.where(flip, q[:, 1::2], pos)
+    q[:, 1::2] = np.where(flip, pos, q[:, 1::2])
+    fq = lb.Fingerprint.from_bools(q)
+    key = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        corpus.query_key_device(fq, key)
+    torch.cuda.synchronize()
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        corpus.query_key_device(fq, key)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    best = lb.Corpus.decode_key(int(key.item()) & (2**64 - 1))
+    t1 = time.perf_counter()
+    for _ in range(20):
+        api = corpus.query(fq)
+    lat_ms = (time.perf_counter() - t1) * 1e3 / 20
+    scores = corpus.scores_device(fq).cpu().numpy()
+    alg = 25 * total                                     # SURVEY 8d: 25 B per sub-fingerprint
+    out = {
+        "workload": f"1 query of {nq} sub-fingerprints vs {n} entries of {lo}..{hi} sub-fingerprints "
+                    f"({total} records, {32 * total / 1e9:.2f} GB in HBM), every sliding offset of every entry",
+        "best_index": best[0], "best_score": best[1], "planted_index": PLANTED_1GPU, "found_planted": bool(best[0] == PLANTED_1GPU),
+        "scan_ms": round(ms, 4), "query_latency_ms": round(lat_ms, 4),
+        "subfingerprint_compares_per_s": round(nq * total / (ms * 1e-3), 1),
+        "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel<4> (k_sliding.hip): integer VALU "
+                     "(2 v_bitop3 + 1 v_bcnt per 32 sign pairs), not HBM",
+                     "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes": alg, "layout_GBps": round(32 * total / (ms * 1e-3) / 1e9, 1)},
+    }
+    assert api == best, (api, best)
+    if not args.no_cpu_baseline:
+        # the oracle's Boolean-per-byte loop (the reference's layout) on a bounded sample of the same corpus;
+        # also the parity check of the scores the GPU produced for those entries
+        threads = usable_cores()
+        n_s = 60_000
+        ent = O.synth_ragged_entries(CSEED, 0, counts[:n_s], 200)
+        O.corpus_best_ragged(q, (ent[: int(counts[:2000].sum())], counts[:2000]), 200, nthreads=threads)
+        t1 = time.perf_counter()
+        _, _, want = O.corpus_best_ragged(q, (ent, counts[:n_s]), 200, nthreads=threads, want_scores=True)
+        dt = time.perf_counter() - t1
+        n_1 = 6_000
+        t1 = time.perf_counter()
+        O.corpus_best_ragged(q, (ent[: int(counts[:n_1].sum())], counts[:n_1]), 200, nthreads=1)
+        dt1 = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": round(n_s / dt, 1), "unit": "entries/s", "cores": threads, "kind": "port", "per_core": round(n_s / dt / threads, 1),
+            "single_thread": {"value": round(n_1 / dt1, 1), "unit": "entries/s", "cores": 1},
+            "cpu_model": cpu_model(),
+            "sample": f"first {n_s} entries ({int(counts[:n_s].sum())} sub-fingerprints as 200 Booleans each, the "
+                      f"reference's layout) through oracle/lbad_oracle.c:lbo_corpus_best_ragged, {threads} OpenMP threads, {dt * 1e3:.0f} ms",
+        }
+        out["parity"] = {"entries_checked": n_s,
+                         "bit_exact": bool(np.array_equal(scores[:n_s].view(np.uint32), want.view(np.uint32)))}
+    return out
+
+
+def files_leg(args, torch, np):
+    """BASELINE configs[0] as worded: bundled Birds/*.caf files through LBAudioDetectiveCompareAudioURLs at the
+    reference's defaults (5512 Hz, 2048-point windows, upstream's file loop), then every fixture through the file
+    entry points for a files-per-second figure.  The CPU baseline is the oracle's file loop on PCM decoded and
+    converted by the library's host functions."""
+    import lbaudiodetective_amd as lb
+    from oracle import oracle as O
+    birds = os.path.join(ROOT, "tests", "golden", "birds")
+    a, b = os.path.join(birds, "BlackBird.caf"), os.path.join(birds, "BlackBird_eql.caf")
+    if not (os.path.exists(a) and os.path.exists(b)):
+        return None
+    det = lb.Detective()
+    m = det.compare_audio_urls(a, b)
+    reps = 50
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        m = det.compare_audio_urls(a, b)
+    pair_ms = (time.perf_counter() - t1) * 1e3 / reps
+    paths = sorted(os.path.join(birds, f) for f in os.listdir(birds) if f.endswith(".caf"))
+    seconds = 0.0
+    for p in paths:
+        x, rate = lb.read_audio_url(p)
+        seconds += x.size / rate
+    rounds = 5
+    if hasattr(det, "process_audio_urls"):
+        det.process_audio_urls(paths)
+        t1 = time.perf_counter()
+        for _ in range(rounds):
+            fps = det.process_audio_urls(paths)
+        dt = time.perf_counter() - t1
+        how = "LBAudioDetectiveProcessAudioURLs (one batch call per round)"
+    else:
+        fps = [det.process_audio_url(p) for p in paths]
+        t1 = time.perf_counter()
+        for _ in range(rounds):
+            fps = [det.process_audio_url(p) for p in paths]
+        dt = time.perf_counter() - t1
+        how = "LBAudioDetectiveProcessAudioURL per file"
+    n_sub = sum(f.number_of_subfingerprints for f in fps)
+    out = {
+        "workload": f"configs[0]: {os.path.basename(a)} vs {os.path.basename(b)} through LBAudioDetectiveCompareAudioURLs "
+                    f"(reference defaults 5512 Hz / 2048 / 64, upstream's file loop); then the {len(paths)} bundled fixtures "
+                    f"({seconds:.0f} s of audio) x {rounds} through {how}",
+        "compare_audio_urls_ms": round(pair_ms, 4), "match": m,
+        "files_per_s": round(len(paths) * rounds / dt, 1), "ms_per_file": round(dt * 1e3 / (len(paths) * rounds), 4),
+        "audio_seconds_per_s": round(seconds * rounds / dt, 1), "subfingerprints_per_round": n_sub,
+    }
+    if not args.no_cpu_baseline:
+        cfg = O.Config()
+        sample = paths[:12]
+        pcm = []
+        for p in sample:
+            x, rate = lb.read_audio_url(p)
+            y, _ = lb.read_audio_url(p, cfg.sample_rate, 0)
+            pcm.append((y, x.size, max(1, int(round(cfg.stride * cfg.sample_rate / rate)))))
+        t1 = time.perf_counter()
+        got = [O.fingerprint_file_loop(y, n, h, cfg, O.TAIL_NOTHING) for y, n, h in pcm]
+        dt1 = time.perf_counter() - t1
+        same = all(np.array_equal(g, fps[paths.index(p)].to_bools()) for g, p in zip(got, sample))
+        out["cpu_baseline"] = {
+            "value": round(len(sample) / dt1, 2), "unit": "files/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+            "sample": f"oracle file loop (lbo_fingerprint_file_loop) on the first {len(sample)} fixtures, PCM already decoded "
+                      f"and converted, one thread, {dt1:.1f} s",
+        }
+        out["parity"] = {"files_checked": len(sample), "bit_exact": bool(same)}
+    return out
 
 # ---- one rank -----------------------------------------------------------------------------------------
 def run_rank(args) -> int:
@@ -216,13 +461,34 @@ def run_rank(args) -> int:
         packed = torch.empty((n_clips, per, lb.PACKED_BYTES), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
 
-        def step():
+        def one_pass():
             det.fingerprint_clips_device(clips, out=packed)
+
+        # size a step: two calibration passes (untimed), then as many passes per step as --min-seconds needs
+        one_pass()
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        one_pass()
+        one_pass()
+        torch.cuda.synchronize()
+        pass_s = (time.perf_counter() - c0) / 2
+        passes = args.passes_per_step or max(1, int(-(-args.min_seconds // (args.steps * pass_s))))
+        if world > 1:                                       # every rank must run the same number of passes
+            t = torch.tensor([passes], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            passes = int(t.item())
+
+        def step():
+            for _ in range(passes):
+                one_pass()
 
         for _ in range(args.warmup):
             step()
         barrier()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        tele = Telemetry(lb, torch) if rank == 0 else None
+        if tele:
+            tele.start()
         det.set_stage_timing(True)      # HIP events around each kernel, on the launch stream, inside the timed region
         t0 = time.perf_counter()
         for s in range(args.steps):
@@ -231,18 +497,31 @@ def run_rank(args) -> int:
             ev[s][1].record()
         barrier()
         elapsed = time.perf_counter() - t0
+        if tele:
+            tele.stop()
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         ms_per_step = elapsed * 1e3 / args.steps
-        value = n_gpus * n_clips * args.steps / elapsed            # audio-seconds per second, whole job
-        kern_avg_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-        stage1_ms, stage2_ms, launches = det.stage_times()      # summed over the K timed steps
+        value = n_gpus * n_clips * passes * args.steps / elapsed       # audio-seconds per second, whole job
+        step_ms = [a.elapsed_time(b) for a, b in ev]
+        kern_avg_ms = sum(step_ms) / len(step_ms) / passes              # one pass, HIP events on the launch stream
+        stage1_ms, stage2_ms, launches = det.stage_times()      # summed over the timed passes
         det.set_stage_timing(False)
-        launches_per_step = launches // args.steps
+        launches_per_pass = launches // (args.steps * passes)
         rows_ms = stage1_ms / launches                          # dominant kernel: average launch duration
-        clips_per_launch = n_clips / launches_per_step
+        clips_per_launch = n_clips / launches_per_pass
+        qn = max(1, len(step_ms) // 4)
+        sustained = {
+            "timed_region_s": round(elapsed, 3), "passes_per_step": passes, "passes_timed": passes * args.steps,
+            "ms_per_pass": round(ms_per_step / passes, 4),
+            "step_ms_first_quartile": round(sum(step_ms[:qn]) / qn, 4),
+            "step_ms_last_quartile": round(sum(step_ms[-qn:]) / qn, 4),
+            "step_ms_min": round(min(step_ms), 4), "step_ms_max": round(max(step_ms), 4),
+        }
+        if tele:
+            sustained.update(tele.summary())
 
         if rank == 0:
             alg_bytes = algorithmic_bytes_per_clip(SAMPLES, WINDOW, STRIDE)
@@ -251,9 +530,10 @@ def run_rank(args) -> int:
             achieved = alg_bytes * clips_per_launch / (rows_ms * 1e-3) / 1e9
             result.update({
                 "value": round(value, 1), "ms_per_step": round(ms_per_step, 4),
+                "ms_per_pass": round(ms_per_step / passes, 4), "passes_per_step": passes, "sustained": sustained,
                 "config": {
                     "workload": "configs[1]: 100k synthetic 1 s @44.1 kHz mono clips, 1024-pt FFT, stride 64, "
-                                "fingerprint-only, input resident in HBM",
+                                f"fingerprint-only, input resident in HBM; one step = {passes} passes over the batch",
                     "clips_per_gpu": n_clips, "samples_per_clip": SAMPLES, "window": WINDOW, "stride": STRIDE,
                     "bands": 32, "subfingerprints_per_clip": per, "kernel_variant": args.variant,
                     "parallelism": f"clips sharded x{n_gpus}, no collective",
@@ -270,8 +550,8 @@ def run_rank(args) -> int:
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_clip": alg_bytes, "clips_per_launch": clips_per_launch,
-                    "launches_per_step": launches_per_step, "kernel_ms_avg": round(rows_ms, 4),
-                    "stage2_kernel_ms_avg": round(stage2_ms / launches, 4), "step_ms_avg": round(kern_avg_ms, 4),
+                    "launches_per_pass": launches_per_pass, "kernel_ms_avg": round(rows_ms, 4),
+                    "stage2_kernel_ms_avg": round(stage2_ms / launches, 4), "pass_ms_avg": round(kern_avg_ms, 4),
                     "fp32_canonical_tflops": round(canon_flops * clips_per_launch / (rows_ms * 1e-3) / 1e12, 3),
                     "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                     "fp32_frac_canonical": round(canon_flops * clips_per_launch / (rows_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
@@ -289,16 +569,25 @@ def run_rank(args) -> int:
 
             if not args.no_cpu_baseline and world == 1:
                 threads = usable_cores()
-                n_cpu = args.cpu_sample or min(n_clips, 4000 * threads)     # ~11 s at ~2.8 ms per clip per thread
+                n_cpu = args.cpu_sample or min(n_clips, 3000 * threads)     # ~9 s at ~2.8 ms per clip per thread
                 sample = clips[:n_cpu].cpu().numpy()
                 O.fingerprint_batch(sample[: 2 * threads], cfg, nthreads=threads)    # warm the caches/threads
                 t1 = time.perf_counter()
                 O.fingerprint_batch(sample, cfg, nthreads=threads)
                 dt = time.perf_counter() - t1
+                n_one = min(n_cpu, 1200)                                    # ~3.5 s on one core
+                t1 = time.perf_counter()
+                O.fingerprint_batch(sample[:n_one], cfg, nthreads=1)
+                dt1 = time.perf_counter() - t1
                 result["cpu_baseline"] = {
                     "value": round(n_cpu / dt, 2), "unit": "audio-s/s", "cores": threads, "kind": "port",
+                    "per_core": round(n_cpu / dt / threads, 2),
+                    "single_thread": {"value": round(n_one / dt1, 2), "unit": "audio-s/s", "cores": 1,
+                                      "sample": f"first {n_one} clips, one thread, {dt1:.1f} s"},
+                    "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
                     "sample": f"first {n_cpu} clips of the same batch through oracle/lbad_oracle.c "
-                              f"(scalar radix-2 restatement, not vDSP), {threads} OpenMP threads, {dt:.1f} s",
+                              f"(scalar radix-2 restatement of the reference, not vDSP: Accelerate does not exist on "
+                              f"Linux), {threads} OpenMP threads, {dt:.1f} s",
                 }
         del clips, packed
         # ---- the other processing configurations of BASELINE.json (side measurements, one GPU) ---------------
@@ -370,7 +659,11 @@ def run_rank(args) -> int:
                 }
         else:
             import lbaudiodetective_amd as lb
-            sc = lb.ShardedCorpus(200, per, total, rank=rank, world_size=world)
+            # the exchange step runs INSIDE the library: its own RCCL communicator (ncclCommInitRank through
+            # LBAudioDetectiveCommInitRank; torch.distributed only carries the 128-byte id) and
+            # LBAudioDetectiveCorpusQuerySharded = scan + ncclAllReduce(ncclUint64, ncclMax) + 8-byte read-back
+            comm = sharded.make_comm(rank, world)
+            sc = lb.ShardedCorpus(200, per, total, rank=rank, world_size=world, comm=comm)
             chunk = 1 << 20
             for b in range(sc.begin, sc.end, chunk):
                 sc.append_packed_device(lb.synth_corpus_device(CSEED, b, min(chunk, sc.end - b), per, 200))
@@ -383,7 +676,7 @@ def run_rank(args) -> int:
             fq = lb.Fingerprint.from_bools(q)
             key = torch.zeros(1, dtype=torch.int64, device=dev)
             for _ in range(3):
-                best = sc.query(fq, key_out=key)
+                best = sc.query(fq)
             barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -394,7 +687,7 @@ def run_rank(args) -> int:
             scan_ms = e0.elapsed_time(e1) / reps
             local_key = key.clone()
             ar_ms = None
-            if world > 1:                                       # the exchange step alone: 8 bytes over RCCL
+            if world > 1:                                       # for reference: 8 bytes through torch.distributed's RCCL
                 barrier()
                 t1 = time.perf_counter()
                 for _ in range(reps):
@@ -405,7 +698,7 @@ def run_rank(args) -> int:
             barrier()
             t1 = time.perf_counter()
             for _ in range(reps):
-                best = sc.query(fq, key_out=key)                # scan + all-reduce + 8-byte read-back
+                best = sc.query(fq)                             # scan + ncclAllReduce + 8-byte read-back, in the library
             lat_ms = (time.perf_counter() - t1) * 1e3 / reps
             api_lat_ms = None
             if world == 1:
@@ -432,6 +725,9 @@ def run_rank(args) -> int:
                     "scan_ms": round(scan_ms, 4), "allreduce_ms": (round(ar_max, 4) if world > 1 else None),
                     "query_latency_ms": round(api_lat_ms if api_lat_ms is not None else lat_ms, 4),
                     "query_latency_sharded_path_ms": round(lat_ms, 4),
+                    "collective": "ncclAllReduce(count 1, ncclUint64, ncclMax) inside LBAudioDetectiveCorpusQuerySharded, "
+                                  f"communicator of {world} rank(s) from ncclCommInitRank; allreduce_ms is the same 8 bytes "
+                                  "through torch.distributed, for reference",
                     "entries_per_s": round(total / ((api_lat_ms if api_lat_ms is not None else lat_ms) * 1e-3), 1),
                     "scan_entries_per_s": round(total / (scan_ms * 1e-3), 1),
                     "achieved_GBps_algorithmic_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9, 2),
@@ -487,6 +783,16 @@ def run_rank(args) -> int:
                                  "layout_GBps": round(big.entry_stride_bytes * n_big / (ms * 1e-3) / 1e9, 1)},
                 }
                 big.dispose()
+
+    # =========================== sliding compare on a ragged corpus (side measurement) ====================
+    if world == 1 and not dry and not args.no_sliding and args.corpus != 0:
+        result["compare_sliding"] = sliding_leg(args, torch, np)
+
+    # =========================== the reference's own workload: files (BASELINE configs[0]) ================
+    if world == 1 and not dry and not args.no_files:
+        files = files_leg(args, torch, np)
+        if files:
+            result["configs0_files"] = files
 
     if world > 1:
         dist.barrier()

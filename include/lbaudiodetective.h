@@ -418,6 +418,10 @@ OSStatus LBAudioDetectiveDeviceFree(void* inPointer);
 OSStatus LBAudioDetectiveDeviceCopyIn(void* inDevice, const void* inHost, UInt64 inBytes);
 OSStatus LBAudioDetectiveDeviceCopyOut(void* inHost, const void* inDevice, UInt64 inBytes);
 OSStatus LBAudioDetectiveDeviceSynchronize(void);
+/* Measurement aid: shader clock (MHz) averaged over inMicroseconds, read inside a one-wave kernel on inStream
+ * (s_memtime against the constant 100 MHz s_memrealtime) -- launched on a side stream it reports the clock the
+ * chip runs at UNDER the load of whatever else is executing.  Synchronises inStream. */
+OSStatus LBAudioDetectiveProbeShaderClock(void* inStream, UInt32 inMicroseconds, Float64* outMegahertz);
 const char* LBAudioDetectiveVersionString(void);
 
 #ifdef __cplusplus

@@ -6,7 +6,7 @@
 from ._native import build, lib, constant, LIB_PATH, PACKED_BYTES, PACKED_WORDS, ROWS_PER_FRAME  # noqa: F401
 from .api import (  # noqa: F401
     Comm, Corpus, Detective, Fingerprint, Frame, Stream, LBAudioDetectiveError, noErr, pack_subfingerprint,
-    frames_to_subfingerprints_device, read_audio_url, synth_clips_device, synth_corpus_device, synth_ragged_corpus_device, unpack_packed, unpack_subfingerprint,
+    frames_to_subfingerprints_device, probe_shader_clock, read_audio_url, synth_clips_device, synth_corpus_device, synth_ragged_corpus_device, unpack_packed, unpack_subfingerprint,
 )
 from .sharded import ShardedCorpus, broadcast_fingerprint, gather_packed, make_comm, shard_range  # noqa: F401
 

@@ -156,6 +156,7 @@ _SIGNATURES = {
     "LBAudioDetectiveDeviceCopyIn": (OSStatus, [C.c_void_p, C.c_void_p, UInt64]),
     "LBAudioDetectiveDeviceCopyOut": (OSStatus, [C.c_void_p, C.c_void_p, UInt64]),
     "LBAudioDetectiveDeviceSynchronize": (OSStatus, []),
+    "LBAudioDetectiveProbeShaderClock": (OSStatus, [C.c_void_p, UInt32, _P(Float64)]),
     "LBAudioDetectiveVersionString": (C.c_char_p, []),
 }
 

@@ -603,6 +603,14 @@ def read_audio_url(path: str, sample_rate: float = 0.0, resampler: int = 0):
     return out, float(rate.value)
 
 
+def probe_shader_clock(stream=None, microseconds: int = 2000) -> float:
+    """Shader clock in MHz over `microseconds`, measured by a one-wave kernel on `stream` (use a side stream to
+    read the clock under another kernel's load); synchronises that stream."""
+    mhz = N.Float64(0.0)
+    _check(N.lib().LBAudioDetectiveProbeShaderClock(_stream_ptr(stream), microseconds, C.byref(mhz)), "ProbeShaderClock")
+    return float(mhz.value)
+
+
 def synth_clips_device(seed: int, first: int, n_clips: int, sample_rate_hz: int, n_samples: int,
                        stereo_sum: bool = False, out=None, stream=None):
     import torch

@@ -812,6 +812,22 @@ SInt32 LBAudioDetectiveDeviceCount(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
+OSStatus LBAudioDetectiveProbeShaderClock(void* inStream, UInt32 inMicroseconds, Float64* outMegahertz) {
+    if (!outMegahertz || inMicroseconds == 0 || inMicroseconds > 1000000u) return kLBAudioDetectiveArgumentInvalid;
+    if (!lbad::device_ready()) return kLBAudioDetectiveDeviceUnavailable;
+    hipStream_t stream = static_cast<hipStream_t>(inStream);
+    unsigned long long* d = nullptr;
+    unsigned long long h[2] = {0, 0};
+    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d), sizeof(h)));
+    OSStatus st = lbad::hip_status(lbad::launch_clock_probe(inMicroseconds, d, stream), "clock probe", __LINE__);
+    if (st == noErr) st = lbad::hip_status(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream), "copy", __LINE__);
+    if (st == noErr) st = lbad::hip_status(hipStreamSynchronize(stream), "sync", __LINE__);
+    (void)hipFree(d);
+    if (st != noErr) return st;
+    *outMegahertz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
+    return noErr;
+}
+
 OSStatus LBAudioDetectiveDeviceSet(SInt32 inDevice) {
     LBAD_HIP(hipSetDevice(inDevice));
     return noErr;

@@ -195,6 +195,8 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
                                   uint32_t range, uint64_t index_base, unsigned int* d_score_bits,
                                   unsigned long long* d_key, hipStream_t stream);
 
+// measurement: ticks of the shader clock and of the constant 100 MHz clock over ~usec microseconds (2 words)
+hipError_t launch_clock_probe(uint32_t usec, unsigned long long* d_out, hipStream_t stream);
 // synthetic data
 hipError_t launch_synth_clips(uint32_t seed, uint64_t first, uint64_t n_clips, uint32_t rate_hz, uint32_t n_samples,
                               uint32_t stereo, float* d_out, hipStream_t stream);

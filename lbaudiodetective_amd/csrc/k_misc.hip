@@ -208,6 +208,30 @@ hipError_t launch_synth_clips(uint32_t seed, uint64_t first, uint64_t n_clips, u
     return hipGetLastError();
 }
 
+// Shader clock under whatever load the device carries right now: one wave spins for about `usec` microseconds and
+// reports how far s_memtime (shader-clock ticks) and s_memrealtime (a constant 100 MHz) advanced.  Meant to be
+// launched on a side stream next to a running kernel (it needs one wave slot, no LDS).
+__global__ __launch_bounds__(64) void clock_probe_kernel(uint32_t usec, unsigned long long* __restrict__ out) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < (unsigned long long)usec * 100ull) {
+        __builtin_amdgcn_s_sleep(8);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = r1 - r0;
+    }
+}
+
+hipError_t launch_clock_probe(uint32_t usec, unsigned long long* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, usec, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth_corpus(uint32_t seed, uint64_t first, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
                                uint32_t* d_out, hipStream_t stream) {
     const uint64_t total = n_entries * n_sub;

@@ -153,6 +153,21 @@ void lbo_synth_entry(uint32_t seed, uint64_t entry, uint32_t n_sub, uint32_t sub
  * lbo_synth_entry(seed, entry, count, ...). */
 uint32_t lbo_synth_ragged_count(uint32_t seed, uint64_t entry, uint32_t lo, uint32_t hi);
 
+/* ---- file front end (lbad_file_oracle.c: own restatement of the container formats, the IMA4 / LPCM decoders and
+ * the three documented converter models; stands in for ExtAudioFile, LBAudioDetective.m:224-237) ------------- */
+/* Whole file -> mono float32 at the file's rate (channels averaged, CAF packet-table priming / valid-frame
+ * trimming applied).  *out_mono is malloc'ed (lbo_file_free).  0 ok, -43 not found, 1 unsupported, 2 no memory. */
+int lbo_file_decode(const char* path, float** out_mono, uint64_t* out_frames, double* out_rate);
+int lbo_file_decode_bytes(const uint8_t* file, uint64_t n_bytes, float** out_mono, uint64_t* out_frames, double* out_rate);
+void lbo_file_free(float* p);
+/* Converter models 0 (Kaiser sinc, 24 zero crossings, beta 9, cut-off 0.92), 1 (4 zero crossings, beta 3, cut-off
+ * 1.0), 2 (linear interpolation); out holds lbo_resample_count() samples. */
+uint64_t lbo_resample_count(uint64_t n_in, double rate_in, double rate_out);
+int lbo_resample(const float* in, uint64_t n_in, double rate_in, double rate_out, int model, float* out);
+/* decode + convert + upstream's window loop (hop_mode 1: file-frame bookkeeping with tail_mode; 0: PCM framing) */
+int lbo_fingerprint_file(const char* path, const lbo_config* cfg, int hop_mode, int tail_mode, int resampler,
+                         uint8_t** out_bools, uint64_t* out_count);
+
 #ifdef __cplusplus
 }
 #endif

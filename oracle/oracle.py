@@ -32,11 +32,8 @@ class Config(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (no GPU involved)."""
-    src = os.path.join(_HERE, "lbad_oracle.c")
-    hdr = os.path.join(_HERE, "lbad_oracle.h")
-    stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
-    )
+    srcs = [os.path.join(_HERE, n) for n in ("lbad_oracle.c", "lbad_file_oracle.c", "lbad_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"] + (["-B"] if force else []))
     return _LIB_PATH
@@ -87,6 +84,14 @@ def lib():
     sig("lbo_corpus_best_ragged", None, [u8p, C.c_uint32, u8p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
                                          C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_void_p])
     sig("lbo_synth_ragged_count", C.c_uint32, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32])
+    sig("lbo_file_decode", C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64), C.POINTER(C.c_double)])
+    sig("lbo_file_decode_bytes", C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_double)])
+    sig("lbo_file_free", None, [C.POINTER(C.c_float)])
+    sig("lbo_resample_count", C.c_uint64, [C.c_uint64, C.c_double, C.c_double])
+    sig("lbo_resample", C.c_int, [f32p, C.c_uint64, C.c_double, C.c_double, C.c_int, f32p])
+    sig("lbo_fingerprint_file", C.c_int, [C.c_char_p, cfgp, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
+                                          C.POINTER(C.c_uint64)])
     sig("lbo_synth_sine_table", None, [i16p])
     sig("lbo_synth_clip", None, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_int, f32p])
     sig("lbo_synth_entry", None, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, u8p])
@@ -312,6 +317,50 @@ def synth_ragged_entries(seed: int, first: int, counts: np.ndarray, subfp_len: i
     for i, n in enumerate(counts):
         lib().lbo_synth_entry(seed & 0xFFFFFFFF, first + i, int(n), subfp_len, out[at:at + int(n)].reshape(-1))
         at += int(n)
+    return out
+
+
+# ---- file front end (lbad_file_oracle.c) -------------------------------------------------------------------
+def decode_audio_file(path: str = None, data: bytes = None):
+    """A CAF / WAV file (or its bytes) -> (mono float32 at the file's rate, rate); ValueError if unsupported."""
+    buf, n, rate = C.POINTER(C.c_float)(), C.c_uint64(0), C.c_double(0.0)
+    if data is not None:
+        rc = lib().lbo_file_decode_bytes(data, len(data), C.byref(buf), C.byref(n), C.byref(rate))
+    else:
+        rc = lib().lbo_file_decode(path.encode(), C.byref(buf), C.byref(n), C.byref(rate))
+    if rc == -43:
+        raise FileNotFoundError(path)
+    if rc != 0:
+        raise ValueError(f"unsupported audio file (oracle status {rc})")
+    try:
+        out = np.ctypeslib.as_array(buf, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+    finally:
+        lib().lbo_file_free(buf)
+    return out, float(rate.value)
+
+
+def resample(x: np.ndarray, rate_in: float, rate_out: float, model: int = 0) -> np.ndarray:
+    x = np.ascontiguousarray(x, np.float32)
+    n = int(lib().lbo_resample_count(x.size, rate_in, rate_out))
+    out = np.zeros(max(n, 1), np.float32)
+    if lib().lbo_resample(x if x.size else np.zeros(1, np.float32), x.size, rate_in, rate_out, model, out) != 0:
+        raise ValueError("unsupported conversion")
+    return out[:n]
+
+
+def fingerprint_file(path: str, cfg: Config, hop_mode: int = 1, tail_mode: int = TAIL_NOTHING, resampler: int = 0) -> np.ndarray:
+    """decode + convert + upstream's window loop, all in the oracle: [count, subfp_len] Booleans."""
+    buf, n = C.POINTER(C.c_uint8)(), C.c_uint64(0)
+    rc = lib().lbo_fingerprint_file(path.encode(), C.byref(cfg), hop_mode, tail_mode, resampler, C.byref(buf), C.byref(n))
+    if rc == -43:
+        raise FileNotFoundError(path)
+    if rc != 0:
+        raise ValueError(f"oracle status {rc}")
+    try:
+        out = np.ctypeslib.as_array(buf, shape=(n.value * cfg.subfp_len,)).copy().reshape(n.value, cfg.subfp_len) \
+            if n.value else np.zeros((0, cfg.subfp_len), np.uint8)
+    finally:
+        C.CDLL(None).free(buf)
     return out
 
 

@@ -68,6 +68,83 @@ def test_ima4_decode_matches_independent_decoder(lb):
     assert lb.read_audio_url(os.path.join(BIRDS, "BlackBird_eql.caf"))[0].size == 177455
 
 
+def test_host_front_end_equals_the_independent_oracle_on_every_fixture(lb, oracle):
+    """All sixty upstream fixtures, every packet: the library's host decoder (IMA4 and 32-bit LPCM payloads) and its
+    three converter models against oracle/lbad_file_oracle.c, which shares no code with them."""
+    names = sorted(f for f in os.listdir(BIRDS) if f.endswith(".caf"))
+    assert len(names) == 60
+    for i, f in enumerate(names):
+        p = os.path.join(BIRDS, f)
+        want, wrate = oracle.decode_audio_file(p)
+        got, grate = lb.read_audio_url(p)
+        assert grate == wrate == 44100.0 and np.array_equal(got, want), f
+        if i % 6 == 0:                                       # ten files through the three converters
+            for mode in (0, 1, 2):
+                y, _ = lb.read_audio_url(p, 5512.0, mode)
+                assert np.array_equal(y, oracle.resample(want, wrate, 5512.0, mode)), (f, mode)
+    x, _ = oracle.decode_audio_file(os.path.join(BIRDS, "Crow.caf"))
+    for rate_out, mode in ((48000.0, 0), (8000.0, 1), (96000.0, 2), (44100.0, 0)):       # interpolating, copy
+        y, _ = lb.read_audio_url(os.path.join(BIRDS, "Crow.caf"), rate_out, mode)
+        assert np.array_equal(y, oracle.resample(x[:], 44100.0, rate_out, mode)), (rate_out, mode)
+
+
+def test_oracle_file_reader_on_assorted_containers(lb, oracle, tmp_path):
+    """Hand-built CAF / WAV files of every payload shape the front end accepts (integer widths, floats, both byte
+    orders, unsigned 8-bit WAV, several channels, IMA4 with a packet table): oracle == closed-form expectation ==
+    the library's host reader."""
+    rng = np.random.default_rng(12)
+    frames, ch = 777, 3
+    v = rng.integers(-2**23, 2**23, (frames, ch))
+
+    def caf(path, fourcc, flags, bpp, fpp, channels, bits, payload, pakt=None):
+        desc = struct.pack(">d4sIIIII", 22050.0, fourcc, flags, bpp, fpp, channels, bits)
+        out = b"caff" + struct.pack(">HH", 1, 0) + b"desc" + struct.pack(">q", len(desc)) + desc
+        if pakt:
+            body = struct.pack(">qqii", *pakt, 0)
+            out += b"pakt" + struct.pack(">q", len(body)) + body
+        open(path, "wb").write(out + b"data" + struct.pack(">q", 4 + len(payload)) + bytes(4) + payload)
+
+    p = str(tmp_path / "t.caf")
+    for bits, little in ((8, False), (16, True), (16, False), (24, True), (24, False), (32, True), (32, False)):
+        q = (v >> (24 - bits)) if bits < 24 else (v << (bits - 24))
+        raw = q.astype("<i8").view(np.uint8).reshape(frames, ch, 8)[:, :, : bits // 8]
+        caf(p, b"lpcm", 2 if little else 0, ch * bits // 8, 1, ch, bits, (raw if little else raw[:, :, ::-1]).tobytes())
+        want = (q.astype(np.float64) / 2.0 ** (bits - 1)).astype(np.float32).astype(np.float64).sum(axis=1) / ch
+        got, rate = oracle.decode_audio_file(p)
+        assert rate == 22050.0 and np.array_equal(got, want.astype(np.float32)), (bits, little)
+        assert np.array_equal(lb.read_audio_url(p)[0], got), (bits, little)
+    for dt, bits in (("f4", 32), ("f8", 64)):
+        for little in (True, False):
+            x = rng.standard_normal((frames, ch)).astype(("<" if little else ">") + dt)
+            caf(p, b"lpcm", 1 | (2 if little else 0), ch * bits // 8, 1, ch, bits, x.tobytes())
+            want = (x.astype(np.float32).astype(np.float64).sum(axis=1) / ch).astype(np.float32)
+            got, _ = oracle.decode_audio_file(p)
+            assert np.array_equal(got, want) and np.array_equal(lb.read_audio_url(p)[0], got), (dt, little)
+    u8 = rng.integers(0, 256, (frames, 2)).astype(np.uint8)
+    w = str(tmp_path / "u8.wav")
+    open(w, "wb").write(b"RIFF" + struct.pack("<I", 36 + u8.size) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 8000, 16000, 2, 8)
+                        + b"data" + struct.pack("<I", u8.size) + u8.tobytes())
+    got, rate = oracle.decode_audio_file(w)
+    assert rate == 8000.0 and np.array_equal(got, (((u8.astype(np.float64) - 128) / 128).sum(axis=1) / 2).astype(np.float32))
+    assert np.array_equal(lb.read_audio_url(w)[0], got)
+    # IMA4: two channels of real packets, packet table with priming and a trimmed tail
+    bird = open(os.path.join(BIRDS, "Wren.caf"), "rb").read()
+    at = bird.index(b"data") + 16
+    packets = np.frombuffer(bird[at:at + 34 * 200], np.uint8).reshape(100, 2, 34)        # 100 stereo packet pairs
+    caf(p, b"ima4", 0, 68, 64, 2, 0, packets.tobytes(), pakt=(100, 6000, 70))
+    got, _ = oracle.decode_audio_file(p)
+    caf(str(tmp_path / "l.caf"), b"ima4", 0, 34, 64, 1, 0, packets[:, 0].tobytes())
+    caf(str(tmp_path / "r.caf"), b"ima4", 0, 34, 64, 1, 0, packets[:, 1].tobytes())
+    l, r = oracle.decode_audio_file(str(tmp_path / "l.caf"))[0], oracle.decode_audio_file(str(tmp_path / "r.caf"))[0]
+    assert got.size == 6000 and np.array_equal(got, ((l + r) / np.float32(2))[70:6070])
+    assert np.array_equal(l[:25600], _ima4_python(str(tmp_path / "l.caf")))               # the Python loop, 400 packets
+    assert np.array_equal(lb.read_audio_url(p)[0], got)
+    for junk in (b"", b"caff", b"RIFF" + bytes(40), bird[:64]):
+        open(p, "wb").write(junk)
+        with pytest.raises(ValueError):
+            oracle.decode_audio_file(p)
+
+
 def test_lpcm_containers(lb, tmp_path):
     rng = np.random.default_rng(4)
     x = rng.integers(-2**31, 2**31 - 1, 1000, dtype=np.int64).astype(np.int32)

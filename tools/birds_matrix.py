@@ -6,7 +6,7 @@ Fig. 24-28).  Every original recording is compared with the ten sequences of one
     python tools/birds_matrix.py [--engine gpu|oracle] [--hop 1] [--tail 1] [--resampler 0] [--check] [--json out.json]
 
 engine gpu     LBAudioDetectiveCompareAudioURLs of the HIP library (the product path)
-engine oracle  the library's host-side decoder + converter, then oracle/lbad_oracle.c (no GPU needed)
+engine oracle  oracle/lbad_file_oracle.c (container, decode, converter) + oracle/lbad_oracle.c (no GPU, no product code)
 --check        exit 1 unless the bounds of `check()` hold (the ones tests/ assert)
 """
 import argparse
@@ -45,19 +45,14 @@ def fingerprints_gpu(names, hop, tail, resampler):
 
 
 def fingerprints_oracle(names, hop, tail, resampler):
-    import lbaudiodetective_amd as lb
+    """Entirely the oracle: its own CAF / IMA4 / LPCM reader and converter (oracle/lbad_file_oracle.c), then the
+    file loop of oracle/lbad_oracle.c.  Nothing of the product runs."""
     from oracle import oracle as O
     from concurrent.futures import ThreadPoolExecutor
     cfg = O.Config()
 
     def one(n):
-        p = os.path.join(DIR, n + ".caf")
-        x, rate = lb.read_audio_url(p)
-        y, _ = lb.read_audio_url(p, cfg.sample_rate, resampler)
-        if hop == 0:
-            return O.fingerprint_pcm(y, cfg)
-        h = max(1, int(round(cfg.stride * cfg.sample_rate / rate)))
-        return O.fingerprint_file_loop(y, x.size, h, cfg, tail)
+        return O.fingerprint_file(os.path.join(DIR, n + ".caf"), cfg, hop, tail, resampler)
     with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
         return dict(zip(names, ex.map(one, names)))
 

@@ -2,9 +2,11 @@
 """Randomized sweep of the file entry points (not part of the test suite): tools/fuzz_files.py [trials] [seed].
 Random WAV and CAF files (rate, 1-3 channels, 8 / 16 / 24 / 32-bit integer or 32 / 64-bit float samples of either
 byte order, IMA4 packets with and without a packet table, any length) through LBAudioDetectiveProcessAudioURL --
-decode and conversion to the processing rate on the DEVICE, then upstream's file loop -- against the oracle fed by
-the library's HOST decoder + converter (LBAudioDetectiveReadAudioURL): the two must agree bit for bit for every
-payload format, rate ratio (decimating and interpolating), converter model, hop mode and end-of-file treatment.
+decode and conversion to the processing rate on the DEVICE, then upstream's file loop -- against the ORACLE's own
+file front end (oracle/lbad_file_oracle.c: container, IMA4 / LPCM decode, converter models, file loop; no code shared
+with the library): the two must agree bit for bit for every payload format, rate ratio (decimating and
+interpolating), converter model, hop mode and end-of-file treatment.  The library's HOST functions
+(LBAudioDetectiveReadAudioURL) are checked against the oracle's decode + conversion on the way.
 Round 2, decode and conversion on the device: 60 000 trials (seed 13), 0 mismatches, 423 s on one MI355X (34 570 of the
 files long enough for at least one sub-fingerprint: 9 793 IMA4, 12 483 CAF LPCM, 12 294 WAV)."""
 import os, struct, sys, tempfile, time
@@ -117,15 +119,17 @@ for t in range(trials):
     except lb.LBAudioDetectiveError as e:
         got = ("error", e.status)
     try:
-        xs, rate = lb.read_audio_url(path)
-        y, _ = lb.read_audio_url(path, cfg.sample_rate, resampler)
-        if hop_mode == 0:
-            want = O.fingerprint_pcm(y, cfg) if y.size >= cfg.window else np.zeros((0, cfg.subfp_len), np.uint8)
-        else:
-            hop = max(1, int(round(cfg.stride * cfg.sample_rate / rate)))
-            want = O.fingerprint_file_loop(y, xs.size, hop, cfg, tail_mode)
-    except lb.LBAudioDetectiveError as e:
-        want = ("error", e.status)
+        want = O.fingerprint_file(path, cfg, hop_mode, tail_mode, resampler)
+        xs, rate = O.decode_audio_file(path)
+        hs, hrate = lb.read_audio_url(path)                      # the library's host decoder and converter, on the way
+        hy, _ = lb.read_audio_url(path, cfg.sample_rate, resampler)
+        if hrate != rate or not np.array_equal(hs, xs) or not np.array_equal(hy, O.resample(xs, rate, cfg.sample_rate, resampler)):
+            bad += 1
+            print("HOST FRONT END MISMATCH", t, file_rate, channels, kind, frames, cfg.sample_rate, resampler, flush=True)
+    except (ValueError, FileNotFoundError):
+        want = ("error",)
+    if isinstance(got, tuple):
+        got = ("error",)
     same = (isinstance(got, tuple) and isinstance(want, tuple) and got == want) or \
            (not isinstance(got, tuple) and not isinstance(want, tuple) and got.shape[0] == want.shape[0] and (want.shape[0] == 0 or np.array_equal(got, want)))
     if isinstance(got, tuple):
