@@ -100,6 +100,24 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def quiet_stdout(fn):
+    """Run fn with file descriptor 1 pointing at stderr (C libraries that print to stdout must not disturb the
+    one JSON line this program owes its caller)."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return fn()
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                   # noqa: BLE001
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -111,59 +129,76 @@ def cpu_model() -> str:
 
 
 class Telemetry:
-    """Board power / clocks (rocm-smi, hwmon as fallback) and the shader clock read inside a one-wave probe
-    kernel on a side stream, sampled from a thread while the timed region runs."""
+    """Board power, shader clock and busy percentage of THIS GPU (amdgpu's sysfs files under its PCI address;
+    rocm-smi as fallback) and the shader clock read inside a one-wave probe kernel on a side stream, sampled
+    from a thread while the timed region runs."""
 
-    def __init__(self, lb, torch, period=0.2):
+    def __init__(self, lb, torch, period=0.05):
         import threading
         self.lb, self.torch, self.period = lb, torch, period
         self.stop_flag = False
         self.smi, self.mhz = [], []
         self.side = torch.cuda.Stream()
         self.dev = torch.cuda.current_device()
+        self.sysfs = self.find_sysfs(torch, self.dev)
         self.thread = threading.Thread(target=self._run, daemon=True)
 
     @staticmethod
-    def read_smi():
+    def find_sysfs(torch, dev):
         import glob
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            base = os.path.join("/sys/bus/pci/devices", addr)
+            if not os.path.isdir(base):
+                return None
+            hw = glob.glob(os.path.join(base, "hwmon", "hwmon*"))
+            files = {"busy": os.path.join(base, "gpu_busy_percent")}
+            for h in hw:
+                for name in ("power1_average", "power1_input"):
+                    if os.path.exists(os.path.join(h, name)) and "power" not in files:
+                        files["power"] = os.path.join(h, name)
+                if os.path.exists(os.path.join(h, "freq1_input")):
+                    files["sclk"] = os.path.join(h, "freq1_input")
+            return {"pci": addr, **{k: v for k, v in files.items() if os.path.exists(v)}}
+        except Exception:                                   # noqa: BLE001
+            return None
+
+    def read_smi(self):
+        out = {}
+        if self.sysfs:
+            for key, scale, name in (("power", 1e-6, "power_w"), ("sclk", 1e-6, "sclk_mhz"), ("busy", 1.0, "busy_pct")):
+                try:
+                    out[name] = int(open(self.sysfs[key]).read()) * scale
+                except (KeyError, OSError, ValueError):
+                    pass
+            if out:
+                return out
         try:
             r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
             card = next(iter(json.loads(r.stdout).values()))
-            out = {}
             for k, v in card.items():
                 kl = k.lower()
                 if "power" in kl and "(w)" in kl:
                     out["power_w"] = float(v)
-                elif "sclk" in kl and "level" in kl:
+                elif kl.startswith("sclk clock speed"):
                     out["sclk_mhz"] = float(str(v).strip("()").lower().replace("mhz", ""))
-            if out:
-                return out
         except Exception:                                   # noqa: BLE001
             pass
-        out = {}
-        for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"):
-            try:
-                out["power_w"] = int(open(f).read()) / 1e6
-            except (OSError, ValueError):
-                pass
-        for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input"):
-            try:
-                out["sclk_mhz"] = int(open(f).read()) / 1e6
-            except (OSError, ValueError):
-                pass
         return out
 
     def _run(self):
         self.torch.cuda.set_device(self.dev)
         while not self.stop_flag:
             t = time.perf_counter()
-            try:
-                self.mhz.append(self.lb.probe_shader_clock(self.side, 2000))
-            except Exception:                               # noqa: BLE001
-                pass
             v = self.read_smi()
             if v:
                 self.smi.append(v)
+            if len(self.smi) % 4 == 1:                      # the probe kernel every fourth sample (2 ms each)
+                try:
+                    self.mhz.append(self.lb.probe_shader_clock(self.side, 2000))
+                except Exception:                           # noqa: BLE001
+                    pass
             time.sleep(max(0.0, self.period - (time.perf_counter() - t)))
 
     def start(self):
@@ -181,10 +216,11 @@ class Telemetry:
                                         "samples": len(xs)}
         return {"shader_clock_mhz_in_kernel": stats(self.mhz),
                 "board_power_w": stats([v["power_w"] for v in self.smi if "power_w" in v]),
-                "sclk_mhz_smi": stats([v["sclk_mhz"] for v in self.smi if "sclk_mhz" in v]),
-                "idle": self.idle,
-                "how": "probe kernel (s_memtime / s_memrealtime, 2 ms, side stream) and rocm-smi --showpower --showclocks, "
-                       "sampled from a thread during the timed region"}
+                "sclk_mhz_driver": stats([v["sclk_mhz"] for v in self.smi if "sclk_mhz" in v]),
+                "gpu_busy_pct": stats([v["busy_pct"] for v in self.smi if "busy_pct" in v]),
+                "idle_before": self.idle, "source": (self.sysfs or {}).get("pci", "rocm-smi"),
+                "how": "probe kernel (s_memtime against the 100 MHz s_memrealtime, 2 ms, side stream) and amdgpu's hwmon / "
+                       "gpu_busy_percent files of this GPU's PCI address, sampled from a thread during the timed region"}
 
 
 # ---- launcher ---------------------------------------------------------------------------------------
@@ -662,7 +698,7 @@ def run_rank(args) -> int:
             # the exchange step runs INSIDE the library: its own RCCL communicator (ncclCommInitRank through
             # LBAudioDetectiveCommInitRank; torch.distributed only carries the 128-byte id) and
             # LBAudioDetectiveCorpusQuerySharded = scan + ncclAllReduce(ncclUint64, ncclMax) + 8-byte read-back
-            comm = sharded.make_comm(rank, world)
+            comm = quiet_stdout(lambda: sharded.make_comm(rank, world))   # RCCL prints a version banner on stdout
             sc = lb.ShardedCorpus(200, per, total, rank=rank, world_size=world, comm=comm)
             chunk = 1 << 20
             for b in range(sc.begin, sc.end, chunk):

@@ -120,6 +120,23 @@ OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, LBAud
                                           LBAudioDetectiveURLRef inFileURL2, UInt32 inComparisonRange,
                                           Float32* outMatch);                             /* D.h:235 */
 
+/* Addition: many files in one call -- upstream's tests fingerprint 200 files per test, one call each
+ * (LBAudioDetectiveTests.m:57-91).  Every payload is uploaded at once and decode, conversion, the window loop and
+ * the Haar / sign stage of ALL files run as one launch chain (one per distinct hop when the files' sample rates
+ * differ); the converted samples never leave the device.  outFingerprints[i] is what
+ * LBAudioDetectiveProcessAudioURL returns for file i (NULL if it failed); outStatuses (optional) receives every
+ * file's status, and the call then returns noErr whenever the batch itself could run; without it the first
+ * failing file's status is returned.  LBAudioDetectiveProcessAudioURL / ...CompareAudioURLs are this call with
+ * one / two files. */
+OSStatus LBAudioDetectiveProcessAudioURLs(LBAudioDetectiveRef inDetective, const char* const* inFilePaths, UInt32 inCount,
+                                          LBAudioDetectiveFingerprintRef* outFingerprints, OSStatus* outStatuses);
+/* Parity aid: the file front end alone, on the device -- the mono samples at the processing rate that the window
+ * loop of LBAudioDetectiveProcessAudioURL consumes (payload decode + conversion, k_decode.hip / k_resample.hip),
+ * copied to a host buffer the caller releases with LBAudioDetectiveFreeSamples; outFileFrames = the file's length
+ * in FILE frames (LBAudioDetective.m:236). */
+OSStatus LBAudioDetectiveConvertAudioURL(LBAudioDetectiveRef inDetective, const char* inFilePath, Float32** outSamples,
+                                         UInt64* outCount, UInt64* outFileFrames, Float64* outFileSampleRate);
+
 /* ======================================================================================
  * Part 1b -- fingerprint (Fp.h).  Sub-fingerprints cross this API as unpacked Booleans.
  * ==================================================================================== */

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "LBAudioDetectiveSetAnalysisStride": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveProcessAudioURL": (OSStatus, [Ref, C.c_char_p, _P(Ref)]),
     "LBAudioDetectiveCompareAudioURLs": (OSStatus, [Ref, C.c_char_p, C.c_char_p, UInt32, _P(Float32)]),
+    "LBAudioDetectiveProcessAudioURLs": (OSStatus, [Ref, _P(C.c_char_p), UInt32, _P(Ref), _P(OSStatus)]),
+    "LBAudioDetectiveConvertAudioURL": (OSStatus, [Ref, C.c_char_p, _P(_P(Float32)), _P(UInt64), _P(UInt64), _P(Float64)]),
     # ---- fingerprint (Fp.h) ----
     "LBAudioDetectiveFingerprintNew": (Ref, [UInt32]),
     "LBAudioDetectiveFingerprintDispose": (None, [Ref]),

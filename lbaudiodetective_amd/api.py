@@ -322,6 +322,32 @@ class Detective:
         _check(self._L.LBAudioDetectiveProcessAudioURL(self._ref, path.encode(), C.byref(out)), "ProcessAudioURL")
         return Fingerprint(_ref=out.value)
 
+    def process_audio_urls(self, paths, statuses: bool = False):
+        """LBAudioDetectiveProcessAudioURLs: every file through one launch chain -> list of Fingerprint (None where a
+        file failed; with statuses=True also the list of OSStatus values, else a failure raises)."""
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+        refs = (N.Ref * n)()
+        sts = (N.OSStatus * n)()
+        _check(self._L.LBAudioDetectiveProcessAudioURLs(self._ref, arr, n, refs, sts), "ProcessAudioURLs")
+        fps = [Fingerprint(_ref=refs[i]) if refs[i] else None for i in range(n)]
+        if statuses:
+            return fps, [int(sts[i]) for i in range(n)]
+        for i in range(n):
+            _check(int(sts[i]), f"ProcessAudioURLs[{paths[i]}]")
+        return fps
+
+    def convert_audio_url(self, path: str):
+        """The device front end alone: (mono samples at the processing rate, file frames, file rate)."""
+        buf, n, ff, rate = C.POINTER(N.Float32)(), N.UInt64(0), N.UInt64(0), N.Float64(0.0)
+        _check(self._L.LBAudioDetectiveConvertAudioURL(self._ref, path.encode(), C.byref(buf), C.byref(n), C.byref(ff),
+                                                       C.byref(rate)), "ConvertAudioURL")
+        try:
+            out = np.ctypeslib.as_array(buf, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+        finally:
+            self._L.LBAudioDetectiveFreeSamples(buf)
+        return out, int(ff.value), float(rate.value)
+
     def compare_audio_urls(self, path1: str, path2: str, range_: int = 0) -> float:
         m = N.Float32(float("nan"))
         _check(self._L.LBAudioDetectiveCompareAudioURLs(self._ref, path1.encode(), path2.encode(), range_, C.byref(m)),

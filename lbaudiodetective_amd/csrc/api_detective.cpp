@@ -106,30 +106,23 @@ static OSStatus ensure_scratch(LBAudioDetective* d, uint64_t floats) {
     return noErr;
 }
 
-// End-of-file treatment of upstream's file loop (one clip = one file, float32): rows from
-// `first_short` on belong to windows whose read cannot be met in full.
-struct FileTail {
-    uint32_t mode = 0;          // 1: nothing read -> all-zero rows; 2: partial reads over the stale spectrum
-    uint64_t first_short = 0;   // first such window
-    uint64_t n_client = 0;      // samples the file really has at the processing rate
-    const uint32_t* d_tbl = nullptr;   // mode 2: per window [n_read, lo[bands], hi[bands]] on the device
-};
-
-static hipError_t apply_file_tail(const Plan& p, const FileTail& t, const void* d_pcm, uint64_t rows, float* frames,
+static hipError_t apply_file_tail(const Plan& p, const FileTail& t, const void* d_pcm, uint64_t rows_total, float* frames,
                                   hipStream_t stream) {
+    const uint64_t rows = t.rows ? t.rows : rows_total;
     if (t.first_short >= rows) return hipSuccess;
+    float* file_frames = frames + t.row_begin * p.bands;
     if (t.mode == 1)   // inNumberFrames == 0: empty band loops, 0 / divisor in every band (:382-404): +0, NaN for a zero divisor
-        return launch_empty_rows(p, frames + t.first_short * p.bands, rows - t.first_short, stream);
+        return launch_empty_rows(p, file_frames + t.first_short * p.bands, rows - t.first_short, stream);
     if (t.mode == 2)
-        return launch_file_tail(p, static_cast<const float*>(d_pcm), t.n_client, p.stride, t.first_short,
-                                (uint32_t)(rows - t.first_short), t.d_tbl, frames, stream);
+        return launch_file_tail(p, static_cast<const float*>(d_pcm) + t.pcm_begin, t.n_client, p.stride, t.first_short,
+                                (uint32_t)(rows - t.first_short), t.d_tbl, file_frames, stream);
     return hipSuccess;
 }
 
 // The batch hot path: every clip -> frames_per_clip packed sub-fingerprints.
 OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, uint32_t fmt, uint64_t n_clips,
                                   uint64_t spc, uint32_t* d_packed, float* d_raw, float* d_haar, hipStream_t stream,
-                                  const FileTail* tail = nullptr) {
+                                  const FileTail* tail, size_t n_tails) {
     if (fmt > 2) return kLBAudioDetectiveArgumentInvalid;
     if (tail && (n_clips != 1 || fmt != 0)) return kLBAudioDetectiveArgumentInvalid;
     const size_t elem = fmt == 1 ? 2 : 4;
@@ -167,7 +160,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     const uint64_t frame_floats = (uint64_t)kRowsPerFrame * p.bands;
     if (d_raw) {  // the caller's tap buffer doubles as the inter-kernel scratch
         LBAD_HIP(stage1(d_pcm, n_clips, d_raw));
-        if (tail) LBAD_HIP(apply_file_tail(p, *tail, d_pcm, per * kRowsPerFrame, d_raw, stream));
+        for (size_t t = 0; tail && t < n_tails; ++t) LBAD_HIP(apply_file_tail(p, tail[t], d_pcm, per * kRowsPerFrame, d_raw, stream));
         LBAD_HIP(stage2(d_raw, n_clips * per, d_packed, d_haar));
         return noErr;
     }
@@ -191,7 +184,8 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
         const uint64_t nc = (n_clips - c0) < chunk ? (n_clips - c0) : chunk;
         LBAD_HIP(mark());
         LBAD_HIP(stage1(d_pcm + c0 * spc * elem, nc, d->d_frames));
-        if (tail) LBAD_HIP(apply_file_tail(p, *tail, d_pcm, per * kRowsPerFrame, d->d_frames, stream));
+        for (size_t t = 0; tail && t < n_tails; ++t)
+            LBAD_HIP(apply_file_tail(p, tail[t], d_pcm, per * kRowsPerFrame, d->d_frames, stream));
         LBAD_HIP(mark());
         LBAD_HIP(stage2(d->d_frames, nc * per, d_packed + c0 * per * kPackedWords,
                         d_haar ? d_haar + c0 * per * frame_floats : nullptr));
@@ -206,7 +200,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
 // allocation per call.
 constexpr size_t kPinnedLimit = 512u << 10;  // larger transfers go straight from the caller's memory (measured: staging 1.6 MB costs more than it saves)
 
-static OSStatus grow_device(void** ptr, size_t* cap, size_t bytes) {
+OSStatus grow_device(void** ptr, size_t* cap, size_t bytes) {
     if (*cap >= bytes) return noErr;
     if (*ptr) (void)hipFree(*ptr);
     *ptr = nullptr;
@@ -268,7 +262,7 @@ static OSStatus fingerprint_clips_host(LBAudioDetective* d, const void* clips, u
         packed_host = packed_big.data();
     }
     if (tail) tail->d_tbl = reinterpret_cast<const uint32_t*>(dev + pcm_pad);
-    st = fingerprint_clips_device(d, dev, fmt, n_clips, spc, d->d_io_packed, nullptr, nullptr, stream, tail);
+    st = fingerprint_clips_device(d, dev, fmt, n_clips, spc, d->d_io_packed, nullptr, nullptr, stream, tail, tail ? 1 : 0);
     if (st != noErr) return st;
     LBAD_HIP(hipMemcpyAsync(packed_host, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
     LBAD_HIP(hipStreamSynchronize(stream));
@@ -328,7 +322,7 @@ static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& 
 }
 
 // :297-298,326-328 -- New(0), then the length is fixed when the first sub-fingerprint arrives
-static LBAudioDetectiveFingerprintRef fingerprint_from_bools(const LBAudioDetective* d, const Boolean* bools, uint64_t per) {
+LBAudioDetectiveFingerprintRef fingerprint_from_bools(const LBAudioDetective* d, const Boolean* bools, uint64_t per) {
     LBAudioDetectiveFingerprintRef fp = LBAudioDetectiveFingerprintNew(0);
     for (uint64_t s = 0; s < per; ++s) {
         UInt32 len = d->subfp_len;
@@ -365,6 +359,8 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->d_rs_bytes) (void)hipFree(inDetective->d_rs_bytes);
     if (inDetective->d_rs_in) (void)hipFree(inDetective->d_rs_in);
     if (inDetective->d_rs_out) (void)hipFree(inDetective->d_rs_out);
+    if (inDetective->d_rs_tail) (void)hipFree(inDetective->d_rs_tail);
+    if (inDetective->h_files) (void)hipHostFree(inDetective->h_files);
     for (double* t : inDetective->d_rs_table)
         if (t) (void)hipFree(t);
     if (inDetective->io_stream) (void)hipStreamDestroy(inDetective->io_stream);
@@ -556,12 +552,7 @@ OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef d, const Float32* inSamp
     LBAD_GUARD_END
 }
 
-static OSStatus read_url(LBAudioDetectiveURLRef inFileURL, std::vector<float>& mono, double& rate) {
-#ifdef __OBJC__
-    const char* path = [[inFileURL path] fileSystemRepresentation];
-#else
-    const char* path = inFileURL;
-#endif
+static OSStatus read_url(const char* path, std::vector<float>& mono, double& rate) {
     const lbad::AudioFileStatus fs = lbad::read_audio_file(path, mono, rate);
     if (fs == lbad::AudioFileStatus::NotFound) return -43;  // fnfErr, what ExtAudioFileOpenURL reports
     if (fs != lbad::AudioFileStatus::Ok) return kLBAudioDetectiveUnsupportedFile;
@@ -675,49 +666,60 @@ OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32*
     LBAD_GUARD_END
 }
 
-OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL,
+OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, const char* inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
     LBAD_GUARD_BEGIN
-    if (!inFileURL) return kLBAudioDetectiveArgumentInvalid;  // :211-214
-#ifdef __OBJC__
-    const char* path = [[inFileURL path] fileSystemRepresentation];
-#else
-    const char* path = inFileURL;
-#endif
-    lbad::AudioPayload file;
-    const lbad::AudioFileStatus fs = lbad::parse_audio_file(path, file);
-    if (fs == lbad::AudioFileStatus::NotFound) return -43;  // fnfErr, what ExtAudioFileOpenURL reports
-    if (fs != lbad::AudioFileStatus::Ok) return kLBAudioDetectiveUnsupportedFile;
-    const double file_rate = file.sample_rate;
-    const double rate = d->format.mSampleRate;
-    if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
-    // ExtAudioFile decodes and converts to the client format (:229); here both happen on the device
-    std::vector<float> mono;
-    OSStatus st = lbad::convert_file_on_device(d, file, rate, d->resampler, mono);
-    if (st != noErr) return st;
-    if (d->hop_mode == 0) return LBAudioDetectiveProcessPCM(d, mono.data(), mono.size(), outFingerprint);
-
-    // hop_mode 1 -- what upstream does: the length (:236) and the seek offsets (:287-288) are
-    // in FILE frames while each read asks for windowSize CLIENT frames, so the hop is analysisStride file
-    // frames = analysisStride * rate / file_rate client samples and the window count comes from the file length.
-    uint32_t hop = (uint32_t)std::llround((double)d->stride * rate / file_rate);
-    if (hop < 1) hop = 1;
-    return LBAudioDetectiveProcessFileStream(d, mono.data(), mono.size(), file.count, hop, outFingerprint);
+    if (!d || !inFileURL || !outFingerprint) return kLBAudioDetectiveArgumentInvalid;  // :211-214
+    // ExtAudioFile decodes and converts to the client format (:229); here both happen on the device and the
+    // converted samples stay there for the window loop (api_files.cpp: a batch of one file)
+    return lbad::process_audio_files(d, &inFileURL, 1, outFingerprint, nullptr);
     LBAD_GUARD_END
 }
 
-OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, LBAudioDetectiveURLRef inFileURL1,
-                                          LBAudioDetectiveURLRef inFileURL2, UInt32 inComparisonRange,
-                                          Float32* outMatch) {  // :442-464
+// The file front end alone, on the device, for parity checks: the samples the window loop of ProcessAudioURL sees
+// (decode + conversion to the processing rate, k_decode.hip / k_resample.hip), copied back to the host.
+OSStatus LBAudioDetectiveConvertAudioURL(LBAudioDetectiveRef d, const char* inFileURL, Float32** outSamples, UInt64* outCount,
+                                         UInt64* outFileFrames, Float64* outFileSampleRate) {
+    LBAD_GUARD_BEGIN
+    if (!d || !inFileURL || !outSamples || !outCount) return kLBAudioDetectiveArgumentInvalid;
+    lbad::AudioPayload file;
+    const lbad::AudioFileStatus fs = lbad::parse_audio_file(inFileURL, file);
+    if (fs == lbad::AudioFileStatus::NotFound) return -43;
+    if (fs != lbad::AudioFileStatus::Ok) return kLBAudioDetectiveUnsupportedFile;
+    if (!(d->format.mSampleRate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
+    if (!lbad::device_ready()) return kLBAudioDetectiveDeviceUnavailable;
+    std::vector<float> mono;
+    OSStatus st = lbad::convert_file_on_device(d, file, d->format.mSampleRate, d->resampler, mono);
+    if (st != noErr) return st;
+    Float32* buf = static_cast<Float32*>(std::malloc(sizeof(Float32) * (mono.size() ? mono.size() : 1)));
+    if (!buf) return kLBAudioDetectiveMemFull;
+    std::memcpy(buf, mono.data(), sizeof(Float32) * mono.size());
+    *outSamples = buf;
+    *outCount = mono.size();
+    if (outFileFrames) *outFileFrames = file.count;
+    if (outFileSampleRate) *outFileSampleRate = file.sample_rate;
+    return noErr;
+    LBAD_GUARD_END
+}
+
+OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, const char* inFileURL1, const char* inFileURL2,
+                                          UInt32 inComparisonRange, Float32* outMatch) {  // :442-464
+    LBAD_GUARD_BEGIN
+    if (!d) return kLBAudioDetectiveArgumentInvalid;
     if (inComparisonRange == 0) inComparisonRange = d->subfp_len;
-    LBAudioDetectiveFingerprintRef fp1 = NULL, fp2 = NULL;
-    OSStatus st = LBAudioDetectiveProcessAudioURL(d, inFileURL1, &fp1);
-    st = LBAudioDetectiveProcessAudioURL(d, inFileURL2, &fp2);
-    if (st == noErr && fp1 && fp2)
-        *outMatch = LBAudioDetectiveFingerprintCompareToFingerprint(fp1, fp2, inComparisonRange);
-    LBAudioDetectiveFingerprintDispose(fp1);
-    LBAudioDetectiveFingerprintDispose(fp2);
+    // both files in one launch chain; like upstream the status is the SECOND file's (:449-456) and outMatch is
+    // written only if that one is noErr
+    const char* paths[2] = {inFileURL1, inFileURL2};
+    LBAudioDetectiveFingerprintRef fp[2] = {NULL, NULL};
+    OSStatus sts[2] = {noErr, noErr};
+    OSStatus st = lbad::process_audio_files(d, paths, 2, fp, sts);
+    if (st == noErr) st = sts[1];
+    if (st == noErr && fp[0] && fp[1] && outMatch)
+        *outMatch = LBAudioDetectiveFingerprintCompareToFingerprint(fp[0], fp[1], inComparisonRange);
+    LBAudioDetectiveFingerprintDispose(fp[0]);
+    LBAudioDetectiveFingerprintDispose(fp[1]);
     return st;
+    LBAD_GUARD_END
 }
 
 // ---- streaming: chunked PCM in, the partial frame is carried across calls -----------------------------

@@ -1,0 +1,311 @@
+// api_files.cpp -- the file entry points as one GPU workload.
+//
+// Upstream fingerprints a file by seeking and reading it window by window through ExtAudioFile
+// (LBAudioDetective/LBAudioDetective.m:208-308); its test suite does that 200 times per test
+// (LBAudioDetectiveTests/LBAudioDetectiveTests.m:57-91).  Here any number of files goes through ONE launch chain:
+//   host    containers parsed (threads), every payload copied into one pinned block, one upload
+//   device  payload decode (k_decode.hip) and sample-rate conversion (k_resample.hip) of every file straight into
+//           its slot of ONE float32 clip; stage 1 over that clip; the files' end-of-file rows; stage 2; 32 bytes per
+//           sub-fingerprint come back
+// The converted samples never leave the device.  Slots: with a hop of h samples a frame of 128 windows advances
+// G = 128 h samples; file f gets frames_f + ceil(W / G) whole frames of the clip, so that its windows lie on the
+// clip's window grid and the windows that straddle two files fall into frames nobody reads.  Files with
+// different hops (different file rates in hop mode 1) form separate clips.
+#include "internal.hpp"
+#include "audiofile.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace lbad {
+namespace {
+
+struct Job {
+    AudioPayload a;
+    ResamplePlan rp;
+    OSStatus st = noErr;
+    uint32_t hop = 0;
+    uint64_t frames = 0;       // sub-fingerprints of the file
+    uint64_t n_client = 0;     // samples at the processing rate
+    uint64_t slot_frames = 0, frame0 = 0;   // frames of the clip the file owns, first of them
+    uint64_t bytes0 = 0, dec0 = 0;          // offsets of its payload / decoded samples in the batch buffers
+    uint64_t first_short = 0;
+    size_t tbl0 = 0, tbl_n = 0;             // tail mode 2: its table inside the batch's table block (words)
+};
+
+// restore the detective's public stride however the call ends (the plan is keyed by the hop between windows)
+struct StrideGuard {
+    LBAudioDetective* d;
+    uint32_t saved;
+    explicit StrideGuard(LBAudioDetective* det) : d(det), saved(det->stride) {}
+    ~StrideGuard() { d->stride = saved; }
+};
+
+OSStatus grow_pinned(void** ptr, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return noErr;
+    if (*ptr) (void)hipHostFree(*ptr);
+    *ptr = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4;
+    LBAD_HIP(hipHostMalloc(ptr, want, hipHostMallocDefault));
+    *cap = want;
+    return noErr;
+}
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
+
+// one clip: jobs[idx[0..n)] share `hop`
+OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vector<size_t>& idx, uint32_t hop,
+                   LBAudioDetectiveFingerprintRef* out) {
+    const uint32_t W = d->window, bands = d->bands;
+    const uint64_t G = (uint64_t)kRowsPerFrame * hop;
+    const uint64_t gap = (W + G - 1) / G;
+    uint64_t total_frames = 0;
+    size_t bytes_total = 0, dec_total = 0, tbl_words = 0;
+    const bool stale = d->hop_mode == 1 && d->tail_mode == 2;
+    for (size_t i : idx) {
+        Job& j = jobs[i];
+        j.frame0 = total_frames;
+        j.slot_frames = j.frames + gap;
+        total_frames += j.slot_frames;
+        j.bytes0 = bytes_total;
+        bytes_total += align_up(j.a.len);
+        j.dec0 = dec_total;
+        dec_total += (size_t)align_up(j.a.total_frames * sizeof(float)) / sizeof(float);
+        j.first_short = j.n_client >= W ? (j.n_client - W) / hop + 1 : 0;
+        const uint64_t rows = j.frames * kRowsPerFrame;
+        if (stale && j.first_short < rows) {
+            j.tbl0 = tbl_words;
+            j.tbl_n = (size_t)(rows - j.first_short) * (1 + 2 * bands);
+            tbl_words += j.tbl_n;
+        }
+    }
+    if (total_frames > 0xFFFFFFFFull / kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
+    const uint64_t T = total_frames * G + W;                       // samples of the clip: exactly total_frames frames
+    const size_t packed_bytes = (size_t)total_frames * LBAD_PACKED_BYTES;
+
+    OSStatus st = grow_device(&d->d_rs_bytes, &d->d_rs_bytes_cap, bytes_total);
+    if (st == noErr) st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, dec_total * sizeof(float));
+    if (st == noErr) st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, T * sizeof(float));
+    if (st == noErr) st = grow_device(reinterpret_cast<void**>(&d->d_io_packed), &d->d_io_packed_cap, packed_bytes);
+    if (st == noErr && tbl_words) st = grow_device(&d->d_rs_tail, &d->d_rs_tail_cap, tbl_words * sizeof(uint32_t));
+    if (st == noErr) st = grow_pinned(&d->h_files, &d->h_files_cap, bytes_total > packed_bytes ? bytes_total : packed_bytes);
+    if (st != noErr) return st;
+    if (!d->io_stream) LBAD_HIP(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking));
+    hipStream_t stream = d->io_stream;
+
+    // payloads -> pinned block -> device, in one copy
+    char* stage = static_cast<char*>(d->h_files);
+    for (size_t i : idx) std::memcpy(stage + jobs[i].bytes0, jobs[i].a.file.data() + jobs[i].a.off, jobs[i].a.len);
+    LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, stage, bytes_total, hipMemcpyHostToDevice, stream));
+    float* pcm = static_cast<float*>(d->d_rs_out);
+    LBAD_HIP(hipMemsetAsync(pcm, 0, T * sizeof(float), stream));   // the slots' zero padding
+
+    // tail mode 2: nRead shrinks monotonically over the short windows (:252,275: in/out argument)
+    std::vector<uint32_t> tbl(tbl_words);
+    for (size_t i : idx) {
+        const Job& j = jobs[i];
+        if (!j.tbl_n) continue;
+        const uint64_t n_tail = j.frames * kRowsPerFrame - j.first_short;
+        uint32_t n_read = W;
+        for (uint64_t t = 0; t < n_tail; ++t) {
+            const uint64_t start = (j.first_short + t) * hop;
+            const uint64_t avail = j.n_client > start ? j.n_client - start : 0;
+            if (avail < n_read) n_read = (uint32_t)avail;
+            uint32_t* e = tbl.data() + j.tbl0 + (size_t)t * (1 + 2 * bands);
+            e[0] = n_read;
+            make_band_bounds(d->format.mSampleRate, W, n_read, d->plan.table, e + 1, e + 1 + bands);
+        }
+    }
+    if (tbl_words) LBAD_HIP(hipMemcpyAsync(d->d_rs_tail, tbl.data(), tbl_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+
+    std::vector<FileTail> tails;
+    for (size_t i : idx) {
+        const Job& j = jobs[i];
+        float* decoded = static_cast<float*>(d->d_rs_in) + j.dec0;
+        LBAD_HIP(launch_decode((int)j.a.kind, static_cast<const uint8_t*>(d->d_rs_bytes) + j.bytes0, j.a.total_frames, j.a.channels,
+                               j.a.bits, j.a.is_float, j.a.little, decoded, stream));
+        const float* mono = decoded + j.a.first;                    // 'pakt' priming frames are skipped, the tail is cut by count
+        float* slot = pcm + j.frame0 * G;
+        const uint64_t slot_len = j.slot_frames * G;                 // what lies beyond is the next file's
+        const uint64_t n_write = j.n_client < slot_len ? j.n_client : slot_len;
+        if (j.rp.copy) {
+            LBAD_HIP(hipMemcpyAsync(slot, mono, n_write * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        } else {
+            const double* d_table = nullptr;
+            uint64_t table_n = 0;
+            const uint32_t mode = j.rp.mode;
+            if (mode < 2) {
+                table_n = j.rp.table->size();
+                if (!d->d_rs_table[mode]) {
+                    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d->d_rs_table[mode]), table_n * sizeof(double)));
+                    LBAD_HIP(hipMemcpyAsync(d->d_rs_table[mode], j.rp.table->data(), table_n * sizeof(double),
+                                            hipMemcpyHostToDevice, stream));
+                }
+                d_table = d->d_rs_table[mode];
+            }
+            LBAD_HIP(launch_resample(mono, j.a.count, mode, j.rp.ratio, j.rp.scale, j.rp.half, j.rp.table_res, d_table, table_n,
+                                     slot, n_write, stream));
+        }
+        if (d->hop_mode == 1 && d->tail_mode != 0) {
+            FileTail t;
+            t.mode = d->tail_mode;
+            t.first_short = j.first_short;
+            t.n_client = j.n_client;
+            t.d_tbl = j.tbl_n ? static_cast<const uint32_t*>(d->d_rs_tail) + j.tbl0 : nullptr;
+            t.row_begin = j.frame0 * kRowsPerFrame;
+            t.rows = j.frames * kRowsPerFrame;
+            t.pcm_begin = j.frame0 * G;
+            tails.push_back(t);
+        }
+    }
+
+    {
+        StrideGuard guard(d);
+        d->stride = hop;
+        st = ensure_plan(d);
+        if (st == noErr)
+            st = fingerprint_clips_device(d, pcm, 0, 1, T, d->d_io_packed, nullptr, nullptr, stream,
+                                          tails.empty() ? nullptr : tails.data(), tails.size());
+    }
+    if (st != noErr) return st;
+    uint32_t* packed = static_cast<uint32_t*>(d->h_files);
+    LBAD_HIP(hipMemcpyAsync(packed, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
+    LBAD_HIP(hipStreamSynchronize(stream));
+    std::vector<Boolean> bools;
+    for (size_t i : idx) {
+        const Job& j = jobs[i];
+        bools.assign((size_t)j.frames * d->subfp_len, 0);
+        for (uint64_t s = 0; s < j.frames; ++s)
+            LBAudioDetectiveUnpackSubfingerprint(packed + (j.frame0 + s) * LBAD_PACKED_WORDS, d->subfp_len,
+                                                 bools.data() + (size_t)s * d->subfp_len);
+        out[i] = fingerprint_from_bools(d, bools.data(), j.frames);
+    }
+    return noErr;
+}
+
+}  // namespace
+
+OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size_t n, LBAudioDetectiveFingerprintRef* out,
+                             OSStatus* statuses) {
+    if (!d || !paths || !out) return kLBAudioDetectiveArgumentInvalid;
+    for (size_t i = 0; i < n; ++i) out[i] = NULL;
+    const double rate = d->format.mSampleRate;
+    if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = noErr;
+    std::vector<Job> jobs(n);
+
+    // containers: read + parse on the host, several files at a time
+    auto parse_range = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            Job& j = jobs[i];
+            if (!paths[i]) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }   // :211-214
+            const AudioFileStatus fs = parse_audio_file(paths[i], j.a);
+            if (fs == AudioFileStatus::NotFound) { j.st = -43; continue; }            // fnfErr, what ExtAudioFileOpenURL reports
+            if (fs != AudioFileStatus::Ok) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
+            if (!resample_plan(j.a.count, j.a.sample_rate, rate, d->resampler, j.rp)) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }
+            j.n_client = j.a.count == 0 ? 0 : j.rp.n_out;
+        }
+    };
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers > 8) workers = 8;
+    if (n < 4 || workers < 2) {
+        parse_range(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (n + workers - 1) / workers;
+        size_t next = per;
+        try {
+            for (unsigned w = 1; w < workers && next < n; ++w) {
+                const size_t e = next + per < n ? next + per : n;
+                pool.emplace_back(parse_range, next, e);
+                next = e;
+            }
+        } catch (const std::system_error&) {
+        }
+        parse_range(0, per < n ? per : n);
+        if (next < n) parse_range(next, n);
+        for (std::thread& t : pool) t.join();
+    }
+
+    // a missing or unreadable file is reported as such whether or not a device exists (like ExtAudioFileOpenURL);
+    // everything after this point needs the GPU
+    bool any = false;
+    for (const Job& j : jobs) any = any || j.st == noErr;
+    if (any) {
+        st = ensure_plan(d);
+        if (st != noErr) {
+            for (Job& j : jobs)
+                if (j.st == noErr) j.st = st;
+        }
+    }
+
+    // framing per file (:236,250-255), then one clip per hop value, cut where the inter-stage buffer would overflow
+    const uint64_t frame_bytes = (uint64_t)kRowsPerFrame * d->bands * sizeof(float);
+    const uint64_t budget = d->scratch_limit / frame_bytes ? d->scratch_limit / frame_bytes : 1;
+    std::vector<bool> done(n, false);
+    for (size_t i = 0; i < n; ++i) {
+        Job& j = jobs[i];
+        if (j.st != noErr) { done[i] = true; continue; }
+        if (d->hop_mode == 0) {
+            j.hop = d->stride;
+            j.frames = subfingerprint_count(j.n_client, d->window, d->stride);
+        } else {
+            // what upstream does: the length (:236) and the seek offsets (:287-288) are in FILE frames while
+            // each read asks for windowSize CLIENT frames, so the hop is analysisStride file frames =
+            // analysisStride * rate / file_rate client samples and the window count comes from the file length
+            uint32_t hop = (uint32_t)std::llround((double)d->stride * rate / j.a.sample_rate);
+            j.hop = hop < 1 ? 1 : hop;
+            j.frames = j.a.count >= d->window ? ((j.a.count - d->window) / d->stride) / kRowsPerFrame : 0;
+        }
+        if (j.frames == 0) {
+            out[i] = LBAudioDetectiveFingerprintNew(0);
+            done[i] = true;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        const uint32_t hop = jobs[i].hop;
+        const uint64_t gap = (d->window + (uint64_t)kRowsPerFrame * hop - 1) / ((uint64_t)kRowsPerFrame * hop);
+        std::vector<size_t> idx;
+        uint64_t frames = 0;
+        for (size_t k = i; k < n; ++k) {
+            if (done[k] || jobs[k].hop != hop) continue;
+            if (!idx.empty() && frames + jobs[k].frames + gap > budget) break;
+            idx.push_back(k);
+            frames += jobs[k].frames + gap;
+            done[k] = true;
+        }
+        st = run_group(d, jobs, idx, hop, out);
+        if (st != noErr) {
+            for (size_t k : idx) {
+                jobs[k].st = st;
+                if (out[k]) { LBAudioDetectiveFingerprintDispose(out[k]); out[k] = NULL; }
+            }
+        }
+    }
+    OSStatus first = noErr;
+    for (size_t i = 0; i < n; ++i) {
+        if (statuses) statuses[i] = jobs[i].st;
+        if (first == noErr && jobs[i].st != noErr) first = jobs[i].st;
+    }
+    return statuses ? noErr : first;
+}
+
+}  // namespace lbad
+
+extern "C" {
+
+OSStatus LBAudioDetectiveProcessAudioURLs(LBAudioDetectiveRef inDetective, const char* const* inFileURLs,
+                                          UInt32 inCount, LBAudioDetectiveFingerprintRef* outFingerprints,
+                                          OSStatus* outStatuses) {
+    LBAD_GUARD_BEGIN
+    if (!inDetective || (!inFileURLs && inCount) || (!outFingerprints && inCount)) return kLBAudioDetectiveArgumentInvalid;
+    if (inCount == 0) return noErr;
+    return lbad::process_audio_files(inDetective, inFileURLs, inCount, outFingerprints, outStatuses);
+    LBAD_GUARD_END
+}
+
+}  // extern "C"

@@ -90,6 +90,19 @@ struct Plan {
     bool valid = false;
 };
 
+// End-of-file treatment of upstream's file loop for one file inside a float32 clip: the file's windows start at
+// row `row_begin` / sample `pcm_begin` of the clip; windows from `first_short` on (counted from the file's first
+// window) belong to reads that cannot be met in full.
+struct FileTail {
+    uint32_t mode = 0;          // 1: nothing read -> all-zero rows; 2: partial reads over the stale spectrum
+    uint64_t first_short = 0;   // first such window of the file
+    uint64_t n_client = 0;      // samples the file really has at the processing rate
+    const uint32_t* d_tbl = nullptr;   // mode 2: per window [n_read, lo[bands], hi[bands]] on the device
+    uint64_t row_begin = 0;     // first row of the file inside the clip
+    uint64_t rows = 0;          // rows of the file (0: all rows of the clip)
+    uint64_t pcm_begin = 0;     // first sample of the file inside the clip
+};
+
 // ---- kernel launchers (k_*.hip) -------------------------------------------------------------
 // windows -> frame rows.  frames: [n_clips * frames_per_clip][128][bands]
 // fmt: 0 float32, 1 int16, 2 int32 samples
@@ -203,6 +216,20 @@ hipError_t launch_synth_clips(uint32_t seed, uint64_t first, uint64_t n_clips, u
 hipError_t launch_synth_corpus(uint32_t seed, uint64_t first, uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len,
                                uint32_t* d_out, hipStream_t stream);
 
+// ---- shared between the api_*.cpp files ------------------------------------------------------------------
+uint64_t subfingerprint_count(uint64_t n_samples, uint32_t window, uint32_t stride);
+OSStatus ensure_plan(struct ::LBAudioDetective* d);
+OSStatus grow_device(void** ptr, size_t* cap, size_t bytes);
+// the batch hot path on device memory; tails: end-of-file treatment of files laid out inside ONE float32 clip
+OSStatus fingerprint_clips_device(struct ::LBAudioDetective* d, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
+                                  uint64_t samples_per_clip, uint32_t* d_packed, float* d_raw, float* d_haar,
+                                  hipStream_t stream, const FileTail* tails = nullptr, size_t n_tails = 0);
+::LBAudioDetectiveFingerprintRef fingerprint_from_bools(const struct ::LBAudioDetective* d, const Boolean* bools, uint64_t per);
+// the file entry points (api_files.cpp): decode, conversion and the window loop of n files in one launch chain per
+// hop value; statuses (optional) receives every file's status
+OSStatus process_audio_files(struct ::LBAudioDetective* d, const char* const* paths, size_t n,
+                             ::LBAudioDetectiveFingerprintRef* out, OSStatus* statuses);
+
 }  // namespace lbad
 
 // ---- handle layouts ------------------------------------------------------------------------
@@ -251,6 +278,10 @@ struct LBAudioDetective {
     void* d_rs_out = nullptr;
     size_t d_rs_out_cap = 0;
     double* d_rs_table[2] = {nullptr, nullptr};
+    void* d_rs_tail = nullptr;        // tail-mode-2 tables of a file batch
+    size_t d_rs_tail_cap = 0;
+    void* h_files = nullptr;          // pinned staging of a file batch's payload bytes / packed results
+    size_t h_files_cap = 0;
     // optional per-stage timing (hipEvents on the caller's stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2

@@ -1,0 +1,115 @@
+"""GPU parity of the file entry points against the oracle's OWN file front end (oracle/lbad_file_oracle.c +
+oracle/lbad_oracle.c: container, IMA4 / LPCM decode, converter, upstream's window loop -- no code shared with the
+library).  What ExtAudioFile + the loop of LBAudioDetective.m:208-308 do upstream, file by file; here also as one
+batch call."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BIRDS = os.path.join(os.path.dirname(__file__), "golden", "birds")
+
+
+def _all_birds():
+    return sorted(os.path.join(BIRDS, f) for f in os.listdir(BIRDS) if f.endswith(".caf"))
+
+
+def test_device_front_end_equals_oracle_on_every_fixture(lb, gpu, oracle):
+    """Payload decode and sample-rate conversion ON THE DEVICE (k_decode.hip, k_resample.hip) against the
+    independent oracle: all sixty upstream fixtures, every packet, every sample, the three converter models."""
+    det = lb.Detective()
+    for i, p in enumerate(_all_birds()):
+        x, rate = oracle.decode_audio_file(p)
+        for mode in ((0, 1, 2) if i % 10 == 0 else (0,)):
+            det.set_resampler_mode(mode)
+            got, file_frames, file_rate = det.convert_audio_url(p)
+            assert file_frames == x.size and file_rate == rate
+            assert np.array_equal(got, oracle.resample(x, rate, 5512.0, mode)), (p, mode)
+    det.set_resampler_mode(0)
+    d2 = lb.Detective().configure(sample_rate=44100)          # equal rates: the decoded samples themselves
+    x, _ = oracle.decode_audio_file(_all_birds()[3])
+    assert np.array_equal(d2.convert_audio_url(_all_birds()[3])[0], x)
+    d3 = lb.Detective().configure(sample_rate=48000)          # interpolating
+    assert np.array_equal(d3.convert_audio_url(_all_birds()[3])[0], oracle.resample(x, 44100.0, 48000.0, 0))
+
+
+@pytest.mark.parametrize("hop_mode,tail_mode", [(1, 1), (1, 0), (1, 2), (0, 1)])
+def test_batch_of_all_fixtures_equals_single_calls_and_oracle(lb, gpu, oracle, hop_mode, tail_mode):
+    """LBAudioDetectiveProcessAudioURLs on the sixty fixtures at once == sixty LBAudioDetectiveProcessAudioURL calls
+    == the oracle's decode + convert + window loop, bit for bit, for every hop / end-of-file model."""
+    paths = _all_birds()
+    det = lb.Detective()
+    det.set_file_hop_mode(hop_mode).set_file_tail_mode(tail_mode)
+    batch = det.process_audio_urls(paths)
+    cfg = oracle.Config()
+    step = 1 if (hop_mode, tail_mode) == (1, 1) else 4                      # the default model on every file
+    for i in range(0, len(paths), step):
+        want = oracle.fingerprint_file(paths[i], cfg, hop_mode, tail_mode, 0)
+        got = batch[i].to_bools()
+        assert got.shape == want.shape and np.array_equal(got, want), (paths[i], hop_mode, tail_mode)
+        if i % 12 == 0:
+            assert det.process_audio_url(paths[i]).equal_to_fingerprint(batch[i])
+    assert sum(f.number_of_subfingerprints for f in batch) == (1518 if hop_mode == 1 else sum(
+        oracle.fingerprint_file(p, cfg, 0, 1, 0).shape[0] for p in paths))
+    assert det.analysis_stride == 64                                          # the public stride is untouched
+
+
+def _wav(path, x, rate, channels=1):
+    pcm = np.asarray(x, "<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " +
+                struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * 2 * channels, 2 * channels, 16))
+        f.write(b"data" + struct.pack("<I", len(pcm)) + pcm)
+
+
+def test_batch_with_mixed_rates_bad_files_and_other_settings(lb, gpu, oracle, tmp_path):
+    """Files of different sample rates (different hops: several launch chains), stereo, too short for one window,
+    missing and malformed files in ONE call: per-file statuses, the good ones bit-equal to the oracle; and a
+    non-default configuration."""
+    rng = np.random.default_rng(31)
+    paths, kinds = [], []
+    for k, (rate, seconds, ch) in enumerate([(8000, 6, 1), (44100, 3, 2), (22050, 5, 1), (8000, 4, 1), (48000, 2, 1),
+                                             (11025, 0.1, 1), (96000, 2, 1), (5512, 12, 1)]):
+        n = int(rate * seconds)
+        x = (rng.standard_normal((n, ch)) * 3000 + 8000 * np.sin(np.arange(n)[:, None] * (0.01 + 0.003 * k))).astype(np.int16)
+        p = str(tmp_path / f"f{k}.wav")
+        _wav(p, x, rate, ch)
+        paths.append(p)
+        kinds.append("ok")
+    paths.insert(2, str(tmp_path / "missing.wav")); kinds.insert(2, "missing")
+    bad = str(tmp_path / "bad.caf")
+    open(bad, "wb").write(b"caff" + bytes(100))
+    paths.insert(5, bad); kinds.insert(5, "bad")
+    paths.append(os.path.join(BIRDS, "Crow.caf")); kinds.append("ok")
+    for settings in (dict(), dict(sample_rate=8000, window=1024, stride=32, bands=24, subfp_len=120)):
+        det = lb.Detective().configure(**settings)
+        cfg = oracle.Config(**settings)
+        for hop_mode, tail_mode, res in ((1, 1, 0), (1, 2, 1), (0, 1, 2)):
+            det.set_file_hop_mode(hop_mode).set_file_tail_mode(tail_mode).set_resampler_mode(res)
+            fps, sts = det.process_audio_urls(paths, statuses=True)
+            for p, kind, fp, st in zip(paths, kinds, fps, sts):
+                if kind == "missing":
+                    assert st == -43 and fp is None
+                elif kind == "bad":
+                    assert st == lb.constant("kLBAudioDetectiveUnsupportedFile") and fp is None
+                else:
+                    want = oracle.fingerprint_file(p, cfg, hop_mode, tail_mode, res)
+                    assert st == 0 and np.array_equal(fp.to_bools().reshape(want.shape), want), (p, settings, hop_mode, tail_mode, res)
+        with pytest.raises(lb.LBAudioDetectiveError):
+            det.process_audio_urls(paths)                                     # without statuses the first failure is the call's
+    assert lb.Detective().process_audio_urls([]) == []
+
+
+def test_compare_audio_urls_is_one_batch_of_two(lb, gpu, oracle):
+    a, b = os.path.join(BIRDS, "BlackBird.caf"), os.path.join(BIRDS, "BlackBird_eql.caf")
+    det = lb.Detective()
+    cfg = oracle.Config()
+    want = oracle.compare_fp(oracle.fingerprint_file(a, cfg), oracle.fingerprint_file(b, cfg), 200)
+    got = det.compare_audio_urls(a, b)
+    assert np.float32(got).view(np.uint32) == np.float32(want).view(np.uint32) and 0.92 < got < 0.94
+    with pytest.raises(lb.LBAudioDetectiveError) as e:
+        det.compare_audio_urls(a, "/nonexistent.caf")                         # the SECOND file's status (D.m:449-456)
+    assert e.value.status == -43
