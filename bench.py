@@ -142,6 +142,9 @@ class Telemetry:
         self.dev = torch.cuda.current_device()
         self.sysfs = self.find_sysfs(torch, self.dev)
         self.thread = threading.Thread(target=self._run, daemon=True)
+        # the probe kernel waits for a free wave slot next to the running kernel (its stream synchronisation can
+        # take as long as a pass): its own thread, so that the sysfs samples keep their period
+        self.probe_thread = threading.Thread(target=self._probe, daemon=True)
 
     @staticmethod
     def find_sysfs(torch, dev):
@@ -194,20 +197,26 @@ class Telemetry:
             v = self.read_smi()
             if v:
                 self.smi.append(v)
-            if len(self.smi) % 4 == 1:                      # the probe kernel every fourth sample (2 ms each)
-                try:
-                    self.mhz.append(self.lb.probe_shader_clock(self.side, 2000))
-                except Exception:                           # noqa: BLE001
-                    pass
             time.sleep(max(0.0, self.period - (time.perf_counter() - t)))
+
+    def _probe(self):
+        self.torch.cuda.set_device(self.dev)
+        while not self.stop_flag:
+            try:
+                self.mhz.append(self.lb.probe_shader_clock(self.side, 2000))
+            except Exception:                               # noqa: BLE001
+                pass
+            time.sleep(0.25)
 
     def start(self):
         self.idle = self.read_smi()
         self.thread.start()
+        self.probe_thread.start()
 
     def stop(self):
         self.stop_flag = True
         self.thread.join(timeout=10)
+        self.probe_thread.join(timeout=10)
 
     def summary(self):
         def stats(xs):
@@ -218,7 +227,7 @@ class Telemetry:
                 "board_power_w": stats([v["power_w"] for v in self.smi if "power_w" in v]),
                 "sclk_mhz_driver": stats([v["sclk_mhz"] for v in self.smi if "sclk_mhz" in v]),
                 "gpu_busy_pct": stats([v["busy_pct"] for v in self.smi if "busy_pct" in v]),
-                "idle_before": self.idle, "source": (self.sysfs or {}).get("pci", "rocm-smi"),
+                "just_before_the_timed_region": self.idle, "source": (self.sysfs or {}).get("pci", "rocm-smi"),
                 "how": "probe kernel (s_memtime against the 100 MHz s_memrealtime, 2 ms, side stream) and amdgpu's hwmon / "
                        "gpu_busy_percent files of this GPU's PCI address, sampled from a thread during the timed region"}
 

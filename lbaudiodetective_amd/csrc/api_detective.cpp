@@ -108,6 +108,7 @@ static OSStatus ensure_scratch(LBAudioDetective* d, uint64_t floats) {
 
 static hipError_t apply_file_tail(const Plan& p, const FileTail& t, const void* d_pcm, uint64_t rows_total, float* frames,
                                   hipStream_t stream) {
+    if (t.mode == 3) return launch_empty_rows_batch(p, t.d_files, t.n_files, t.max_rows, frames, stream);
     const uint64_t rows = t.rows ? t.rows : rows_total;
     if (t.first_short >= rows) return hipSuccess;
     float* file_frames = frames + t.row_begin * p.bands;
@@ -360,6 +361,7 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->d_rs_in) (void)hipFree(inDetective->d_rs_in);
     if (inDetective->d_rs_out) (void)hipFree(inDetective->d_rs_out);
     if (inDetective->d_rs_tail) (void)hipFree(inDetective->d_rs_tail);
+    if (inDetective->d_rs_desc) (void)hipFree(inDetective->d_rs_desc);
     if (inDetective->h_files) (void)hipHostFree(inDetective->h_files);
     for (double* t : inDetective->d_rs_table)
         if (t) (void)hipFree(t);

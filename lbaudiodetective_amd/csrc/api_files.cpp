@@ -98,7 +98,32 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
 
     // payloads -> pinned block -> device, in one copy
     char* stage = static_cast<char*>(d->h_files);
-    for (size_t i : idx) std::memcpy(stage + jobs[i].bytes0, jobs[i].a.file.data() + jobs[i].a.off, jobs[i].a.len);
+    auto copy_range = [&](size_t b, size_t e) {
+        for (size_t k = b; k < e; ++k) {
+            const Job& j = jobs[idx[k]];
+            std::memcpy(stage + j.bytes0, j.a.file.data() + j.a.off, j.a.len);
+        }
+    };
+    unsigned copiers = std::thread::hardware_concurrency();
+    if (copiers > 8) copiers = 8;
+    if (bytes_total < (8u << 20) || copiers < 2 || idx.size() < 2 * copiers) {
+        copy_range(0, idx.size());
+    } else {                                                     // a memcpy per core: 100 MB of payloads in ~2 ms
+        std::vector<std::thread> pool;
+        const size_t per = (idx.size() + copiers - 1) / copiers;
+        size_t next = per;
+        try {
+            for (unsigned w = 1; w < copiers && next < idx.size(); ++w) {
+                const size_t e = next + per < idx.size() ? next + per : idx.size();
+                pool.emplace_back(copy_range, next, e);
+                next = e;
+            }
+        } catch (const std::system_error&) {
+        }
+        copy_range(0, per < idx.size() ? per : idx.size());
+        if (next < idx.size()) copy_range(next, idx.size());
+        for (std::thread& t : pool) t.join();
+    }
     LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, stage, bytes_total, hipMemcpyHostToDevice, stream));
     float* pcm = static_cast<float*>(d->d_rs_out);
     LBAD_HIP(hipMemsetAsync(pcm, 0, T * sizeof(float), stream));   // the slots' zero padding
@@ -121,45 +146,74 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     }
     if (tbl_words) LBAD_HIP(hipMemcpyAsync(d->d_rs_tail, tbl.data(), tbl_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
 
+    // one descriptor per file for the table-driven kernels: decode, conversion and (tail mode 1) the short rows of
+    // ALL files are one launch each
+    std::vector<FileDesc> descs(idx.size());
     std::vector<FileTail> tails;
-    for (size_t i : idx) {
-        const Job& j = jobs[i];
-        float* decoded = static_cast<float*>(d->d_rs_in) + j.dec0;
-        LBAD_HIP(launch_decode((int)j.a.kind, static_cast<const uint8_t*>(d->d_rs_bytes) + j.bytes0, j.a.total_frames, j.a.channels,
-                               j.a.bits, j.a.is_float, j.a.little, decoded, stream));
-        const float* mono = decoded + j.a.first;                    // 'pakt' priming frames are skipped, the tail is cut by count
-        float* slot = pcm + j.frame0 * G;
+    uint64_t max_units = 0, max_out = 0, max_short = 0;
+    const uint32_t mode = d->resampler;
+    bool any_sinc = false;
+    for (size_t k = 0; k < idx.size(); ++k) {
+        const Job& j = jobs[idx[k]];
+        FileDesc& f = descs[k];
+        f.kind = (uint32_t)j.a.kind; f.channels = j.a.channels; f.bits = j.a.bits;
+        f.flags = (j.a.is_float ? 1u : 0u) | (j.a.little ? 2u : 0u);
+        f.bytes_off = j.bytes0; f.total_frames = j.a.total_frames;
+        f.dec_off = j.dec0; f.first = j.a.first; f.n_in = j.a.count;
+        f.out_off = j.frame0 * G;
         const uint64_t slot_len = j.slot_frames * G;                 // what lies beyond is the next file's
-        const uint64_t n_write = j.n_client < slot_len ? j.n_client : slot_len;
-        if (j.rp.copy) {
-            LBAD_HIP(hipMemcpyAsync(slot, mono, n_write * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        } else {
-            const double* d_table = nullptr;
-            uint64_t table_n = 0;
-            const uint32_t mode = j.rp.mode;
-            if (mode < 2) {
-                table_n = j.rp.table->size();
-                if (!d->d_rs_table[mode]) {
-                    LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d->d_rs_table[mode]), table_n * sizeof(double)));
-                    LBAD_HIP(hipMemcpyAsync(d->d_rs_table[mode], j.rp.table->data(), table_n * sizeof(double),
-                                            hipMemcpyHostToDevice, stream));
-                }
-                d_table = d->d_rs_table[mode];
-            }
-            LBAD_HIP(launch_resample(mono, j.a.count, mode, j.rp.ratio, j.rp.scale, j.rp.half, j.rp.table_res, d_table, table_n,
-                                     slot, n_write, stream));
-        }
-        if (d->hop_mode == 1 && d->tail_mode != 0) {
+        f.n_write = j.n_client < slot_len ? j.n_client : slot_len;
+        f.mode = j.rp.mode; f.copy = j.rp.copy ? 1u : 0u;
+        f.ratio = j.rp.ratio; f.scale = j.rp.scale; f.half = j.rp.half;
+        f.row_begin = j.frame0 * kRowsPerFrame; f.rows = j.frames * kRowsPerFrame; f.first_short = j.first_short;
+        const uint64_t units = j.a.kind == AudioPayload::Ima4 ? j.a.total_frames / 64 : j.a.total_frames;
+        if (units > max_units) max_units = units;
+        if (f.n_write > max_out) max_out = f.n_write;
+        if (f.first_short < f.rows && f.rows - f.first_short > max_short) max_short = f.rows - f.first_short;
+        any_sinc = any_sinc || (!j.rp.copy && mode < 2);
+        if (d->hop_mode == 1 && d->tail_mode == 2) {
             FileTail t;
-            t.mode = d->tail_mode;
+            t.mode = 2;
             t.first_short = j.first_short;
             t.n_client = j.n_client;
             t.d_tbl = j.tbl_n ? static_cast<const uint32_t*>(d->d_rs_tail) + j.tbl0 : nullptr;
-            t.row_begin = j.frame0 * kRowsPerFrame;
-            t.rows = j.frames * kRowsPerFrame;
-            t.pcm_begin = j.frame0 * G;
+            t.row_begin = f.row_begin;
+            t.rows = f.rows;
+            t.pcm_begin = f.out_off;
             tails.push_back(t);
         }
+    }
+    const size_t desc_bytes = descs.size() * sizeof(FileDesc);
+    st = grow_device(&d->d_rs_desc, &d->d_rs_desc_cap, desc_bytes);
+    if (st != noErr) return st;
+    const FileDesc* d_files = static_cast<const FileDesc*>(d->d_rs_desc);
+    LBAD_HIP(hipMemcpyAsync(d->d_rs_desc, descs.data(), desc_bytes, hipMemcpyHostToDevice, stream));
+    const double* d_table = nullptr;
+    uint64_t table_n = 0;
+    int table_res = 0;
+    if (any_sinc) {
+        const ResamplePlan* rp = nullptr;
+        for (size_t i : idx)
+            if (!jobs[i].rp.copy) { rp = &jobs[i].rp; break; }
+        table_n = rp->table->size();
+        table_res = rp->table_res;
+        if (!d->d_rs_table[mode]) {
+            LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d->d_rs_table[mode]), table_n * sizeof(double)));
+            LBAD_HIP(hipMemcpyAsync(d->d_rs_table[mode], rp->table->data(), table_n * sizeof(double), hipMemcpyHostToDevice, stream));
+        }
+        d_table = d->d_rs_table[mode];
+    }
+    LBAD_HIP(launch_decode_batch(d_files, (uint32_t)descs.size(), max_units, static_cast<const uint8_t*>(d->d_rs_bytes),
+                                 static_cast<float*>(d->d_rs_in), stream));
+    LBAD_HIP(launch_resample_batch(d_files, (uint32_t)descs.size(), max_out, static_cast<const float*>(d->d_rs_in), table_res,
+                                   d_table, table_n, pcm, stream));
+    if (d->hop_mode == 1 && d->tail_mode == 1 && max_short) {
+        FileTail t;
+        t.mode = 3;
+        t.d_files = d_files;
+        t.n_files = (uint32_t)descs.size();
+        t.max_rows = max_short;
+        tails.push_back(t);
     }
 
     {
@@ -273,7 +327,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
         uint64_t frames = 0;
         for (size_t k = i; k < n; ++k) {
             if (done[k] || jobs[k].hop != hop) continue;
-            if (!idx.empty() && frames + jobs[k].frames + gap > budget) break;
+            if (!idx.empty() && (frames + jobs[k].frames + gap > budget || idx.size() >= 65535)) break;
             idx.push_back(k);
             frames += jobs[k].frames + gap;
             done[k] = true;

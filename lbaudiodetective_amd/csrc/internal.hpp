@@ -93,8 +93,13 @@ struct Plan {
 // End-of-file treatment of upstream's file loop for one file inside a float32 clip: the file's windows start at
 // row `row_begin` / sample `pcm_begin` of the clip; windows from `first_short` on (counted from the file's first
 // window) belong to reads that cannot be met in full.
+struct FileDesc;
 struct FileTail {
-    uint32_t mode = 0;          // 1: nothing read -> all-zero rows; 2: partial reads over the stale spectrum
+    uint32_t mode = 0;          // 1: nothing read -> all-zero rows; 2: partial reads over the stale spectrum; 3: mode 1 for a
+                                //    whole batch in one launch (d_files / n_files / max_rows below, one FileTail in all)
+    const FileDesc* d_files = nullptr;
+    uint32_t n_files = 0;
+    uint64_t max_rows = 0;
     uint64_t first_short = 0;   // first such window of the file
     uint64_t n_client = 0;      // samples the file really has at the processing rate
     const uint32_t* d_tbl = nullptr;   // mode 2: per window [n_read, lo[bands], hi[bands]] on the device
@@ -153,6 +158,22 @@ hipError_t launch_decode(int kind, const uint8_t* d_data, uint64_t total_frames,
 hipError_t launch_resample(const float* d_in, uint64_t n_in, uint32_t mode, double ratio, double scale, double half,
                            int res, const double* d_table, uint64_t table_n, float* d_out, uint64_t n_out,
                            hipStream_t stream);
+// one file of a batch for the table-driven kernels (k_decode.hip, k_resample.hip, k_file_tail.hip)
+struct FileDesc {
+    uint32_t kind, channels, bits, flags;      // AudioPayload::Kind; flags: 1 float samples, 2 little endian
+    uint64_t bytes_off, total_frames;          // payload inside the batch's byte block; frames it decodes to
+    uint64_t dec_off, first, n_in;             // decoded samples inside the batch's block; first / count that are valid
+    uint64_t out_off, n_write;                 // the file's slot in the clip; samples to write there
+    uint32_t mode, copy;                       // converter model; 1: rates equal, copy
+    double ratio, scale, half;                 // ResamplePlan
+    uint64_t row_begin, rows, first_short;     // the file's rows in the clip; first window whose read is short
+};
+hipError_t launch_decode_batch(const FileDesc* d_files, uint32_t n_files, uint64_t max_units, const uint8_t* d_bytes,
+                               float* d_decoded, hipStream_t stream);
+hipError_t launch_resample_batch(const FileDesc* d_files, uint32_t n_files, uint64_t max_out, const float* d_decoded, int res,
+                                 const double* d_table, uint64_t table_n, float* d_pcm, hipStream_t stream);
+hipError_t launch_empty_rows_batch(const Plan& p, const FileDesc* d_files, uint32_t n_files, uint64_t max_rows, float* d_frames,
+                                   hipStream_t stream);
 hipError_t launch_haar2d_generic(float* d_m, float* d_tmp, uint32_t rows, uint32_t cols, hipStream_t stream);
 hipError_t launch_extract_generic(const float* d_m, uint32_t n, uint32_t n_wavelets, uint8_t* d_out,
                                   hipStream_t stream);
@@ -278,6 +299,8 @@ struct LBAudioDetective {
     void* d_rs_out = nullptr;
     size_t d_rs_out_cap = 0;
     double* d_rs_table[2] = {nullptr, nullptr};
+    void* d_rs_desc = nullptr;        // per-file descriptors of a file batch
+    size_t d_rs_desc_cap = 0;
     void* d_rs_tail = nullptr;        // tail-mode-2 tables of a file batch
     size_t d_rs_tail_cap = 0;
     void* h_files = nullptr;          // pinned staging of a file batch's payload bytes / packed results

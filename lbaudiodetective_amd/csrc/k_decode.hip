@@ -24,10 +24,8 @@ __device__ const int kImaStep[89] = {7,     8,     9,     10,    11,    12,    1
 // one thread per packet position: its `channels` interleaved 34-byte packets (2-byte big-endian header = 9-bit
 // predictor + 7-bit step index, 64 4-bit codes, low nibble first), accumulated into the 64 output frames channel by
 // channel as the host loop does (0.0f + v == v, so the first channel may store)
-__global__ __launch_bounds__(kThreads) void ima4_kernel(const uint8_t* __restrict__ data, uint64_t packets, uint32_t channels,
-                                                        float* __restrict__ out) {
-    const uint64_t p = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (p >= packets) return;
+__device__ __forceinline__ void ima4_packet(const uint8_t* __restrict__ data, uint64_t p, uint32_t channels,
+                                            float* __restrict__ out) {
     float* o = out + p * 64;
     for (uint32_t c = 0; c < channels; ++c) {
         const uint8_t* pk = data + (p * channels + c) * 34;
@@ -56,6 +54,13 @@ __global__ __launch_bounds__(kThreads) void ima4_kernel(const uint8_t* __restric
         for (int i = 0; i < 64; ++i) o[i] = __fdiv_rn(o[i], (float)channels);
 }
 
+__global__ __launch_bounds__(kThreads) void ima4_kernel(const uint8_t* __restrict__ data, uint64_t packets, uint32_t channels,
+                                                        float* __restrict__ out) {
+    const uint64_t p = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= packets) return;
+    ima4_packet(data, p, channels, out);
+}
+
 // one sample of `bits` width at p -> float in [-1, 1)  (audiofile.cpp: sample_to_float)
 __device__ __forceinline__ float sample_to_float(const uint8_t* p, uint32_t bits, bool is_float, bool little) {
     uint8_t b[8];
@@ -77,12 +82,9 @@ __device__ __forceinline__ float sample_to_float(const uint8_t* p, uint32_t bits
     }
 }
 
-// one thread per frame; `wav_u8`: the unsigned 8-bit WAV form ((s - 128) / 128.0 in double, always averaged)
-__global__ __launch_bounds__(kThreads) void pcm_kernel(const uint8_t* __restrict__ data, uint64_t frames, uint32_t channels,
-                                                       uint32_t bits, int is_float, int little, int wav_u8,
-                                                       float* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= frames) return;
+// one PCM frame; `wav_u8`: the unsigned 8-bit WAV form ((s - 128) / 128.0 in double, always averaged)
+__device__ __forceinline__ void pcm_frame(const uint8_t* __restrict__ data, uint64_t i, uint32_t channels, uint32_t bits,
+                                          int is_float, int little, int wav_u8, float* __restrict__ out) {
     if (wav_u8) {
         double acc = 0;
         for (uint32_t c = 0; c < channels; ++c) acc += ((int)data[i * channels + c] - 128) / 128.0;
@@ -100,7 +102,39 @@ __global__ __launch_bounds__(kThreads) void pcm_kernel(const uint8_t* __restrict
     }
 }
 
+__global__ __launch_bounds__(kThreads) void pcm_kernel(const uint8_t* __restrict__ data, uint64_t frames, uint32_t channels,
+                                                       uint32_t bits, int is_float, int little, int wav_u8,
+                                                       float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= frames) return;
+    pcm_frame(data, i, channels, bits, is_float, little, wav_u8, out);
+}
+
+// every file of a batch in one launch: blockIdx.y = file, blockIdx.x walks its packets (IMA4) or frames (PCM)
+__global__ __launch_bounds__(kThreads) void decode_batch_kernel(const FileDesc* __restrict__ files, const uint8_t* __restrict__ bytes,
+                                                                float* __restrict__ decoded) {
+    const FileDesc f = files[blockIdx.y];
+    const uint64_t units = f.kind == 1 ? f.total_frames / 64 : f.total_frames;
+    const uint8_t* data = bytes + f.bytes_off;
+    float* out = decoded + f.dec_off;
+    for (uint64_t u = (uint64_t)blockIdx.x * kThreads + threadIdx.x; u < units; u += (uint64_t)gridDim.x * kThreads) {
+        if (f.kind == 1) ima4_packet(data, u, f.channels, out);
+        else pcm_frame(data, u, f.channels, f.bits, (int)(f.flags & 1u), (int)((f.flags >> 1) & 1u), f.kind == 3 ? 1 : 0, out);
+    }
+}
+
 }  // namespace
+
+// d_files: n_files descriptors on the device; max_units: the largest packet / frame count among them
+hipError_t launch_decode_batch(const FileDesc* d_files, uint32_t n_files, uint64_t max_units, const uint8_t* d_bytes,
+                               float* d_decoded, hipStream_t stream) {
+    if (n_files == 0 || max_units == 0) return hipSuccess;
+    if (n_files > 65535u) return hipErrorInvalidValue;
+    uint64_t bx = (max_units + kThreads - 1) / kThreads;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(decode_batch_kernel, dim3((uint32_t)bx, n_files), dim3(kThreads), 0, stream, d_files, d_bytes, d_decoded);
+    return hipGetLastError();
+}
 
 // kind: AudioPayload::Kind (1 IMA4, 2 PCM, 3 unsigned 8-bit WAV); d_out holds total_frames floats
 hipError_t launch_decode(int kind, const uint8_t* d_data, uint64_t total_frames, uint32_t channels, uint32_t bits,

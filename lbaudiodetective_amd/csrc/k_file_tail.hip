@@ -125,7 +125,29 @@ __global__ __launch_bounds__(kThreads) void empty_rows_kernel(float* __restrict_
     if (i < n_values) rows[i] = __fdiv_rn(0.0f, __uint_as_float(band_tbl[2 * bands + (uint32_t)(i % bands)]));
 }
 
+// the same for every file of a batch: blockIdx.y = file, blockIdx.x walks the values of its short rows
+__global__ __launch_bounds__(kThreads) void empty_rows_batch_kernel(const FileDesc* __restrict__ files, float* __restrict__ frames,
+                                                                    uint32_t bands, const uint32_t* __restrict__ band_tbl) {
+    const FileDesc f = files[blockIdx.y];
+    if (f.first_short >= f.rows) return;
+    float* rows = frames + (f.row_begin + f.first_short) * bands;
+    const uint64_t n_values = (f.rows - f.first_short) * bands;
+    for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n_values; i += (uint64_t)gridDim.x * kThreads)
+        rows[i] = __fdiv_rn(0.0f, __uint_as_float(band_tbl[2 * bands + (uint32_t)(i % bands)]));
+}
+
 }  // namespace
+
+hipError_t launch_empty_rows_batch(const Plan& p, const FileDesc* d_files, uint32_t n_files, uint64_t max_rows, float* d_frames,
+                                   hipStream_t stream) {
+    if (n_files == 0 || max_rows == 0) return hipSuccess;
+    if (n_files > 65535u) return hipErrorInvalidValue;
+    uint64_t bx = (max_rows * p.bands + kThreads - 1) / kThreads;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(empty_rows_batch_kernel, dim3((uint32_t)bx, n_files), dim3(kThreads), 0, stream, d_files, d_frames, p.bands,
+                       p.d_bands);
+    return hipGetLastError();
+}
 
 hipError_t launch_empty_rows(const Plan& p, float* d_rows, uint64_t n_rows, hipStream_t stream) {
     const uint64_t n = n_rows * p.bands;

@@ -292,7 +292,8 @@ void lbo_file_free(float* p) { free(p); }
  *     |k - x| <= Z s, s = max(r, 1); out = sum w(k) in[k] / sum w(k) (samples outside the input count as 0, their
  *     weights still enter the normalisation), all in double, k ascending.
  *     h(t) = c sinc(pi c t) I0(beta sqrt(1 - (t/Z)^2)) / I0(beta) for t < Z, 0 from Z on, read from a table of
- *     2048 points per unit of t with linear interpolation.
+ *     2048 points per unit of t with linear interpolation, at table coordinate |k - x| * (2048 / s) (the
+ *     quotient formed once).
  *     model 0: Z = 24, beta = 9, c = 0.92.   model 1: Z = 4, beta = 3, c = 1.
  *   I0 by its power series, summed until a term falls below 1e-17 of the sum (at most 63 terms).
  * ---------------------------------------------------------------------------------------------------------- */
@@ -359,6 +360,7 @@ int lbo_resample(const float* in, uint64_t n_in, double rate_in, double rate_out
     if (!tb) return 2;
     const double s = r > 1.0 ? r : 1.0;
     const double reach = (model == 0 ? 24 : 4) * s;
+    const double per_sample = (double)SRC_POINTS_PER_UNIT / s;   /* table points per input sample */
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
@@ -367,7 +369,7 @@ int lbo_resample(const float* in, uint64_t n_in, double rate_in, double rate_out
         const long first = (long)ceil(x - reach), last = (long)floor(x + reach);
         double num = 0.0, den = 0.0;
         for (long k = first; k <= last; ++k) {
-            const double t = fabs(((double)k - x) / s) * SRC_POINTS_PER_UNIT;
+            const double t = fabs((double)k - x) * per_sample;
             const size_t i = (size_t)t;
             if (i + 1 >= n_tb) continue;
             const double w = tb[i] + (tb[i + 1] - tb[i]) * (t - (double)i);
