@@ -65,7 +65,11 @@ enum {
 };
 #endif
 
-/* An Objective-C host keeps passing NSURL*; everything else passes a filesystem path. */
+/* Upstream's two file entry points take NSURL* (D.h:218,235).  The library itself is plain C and takes filesystem
+ * paths: a C / C++ host calls LBAudioDetectiveProcessAudioURL / ...CompareAudioURLs with a `const char*` in the
+ * NSURL's place; an Objective-C host keeps passing NSURL* -- in Objective-C mode the two names are inline
+ * wrappers (below, after the declarations) that hand `[[url path] fileSystemRepresentation]` to the path-taking
+ * symbols LBAudioDetectiveProcessAudioPath / ...CompareAudioPaths.  No Apple header is needed for that. */
 #ifdef __OBJC__
 @class NSURL;
 typedef NSURL* LBAudioDetectiveURLRef;
@@ -114,11 +118,18 @@ OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef inDetective, UInt
  * windowed-sinc resampler (Apple's converter is closed source; the container is parsed on the host, payload
  * decode, conversion and everything after it run on the GPU), then fingerprinted.
  * Other payloads return kLBAudioDetectiveUnsupportedFile, a missing file -43 (fnfErr). */
+OSStatus LBAudioDetectiveProcessAudioPath(LBAudioDetectiveRef inDetective, const char* inFilePath,
+                                          LBAudioDetectiveFingerprintRef* outFingerprint);
+OSStatus LBAudioDetectiveCompareAudioPaths(LBAudioDetectiveRef inDetective, const char* inFilePath1, const char* inFilePath2,
+                                           UInt32 inComparisonRange, Float32* outMatch);
+#ifndef __OBJC__
+/* the same two functions under upstream's names (exported symbols; LBAudioDetectiveURLRef is const char* here) */
 OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL,
                                          LBAudioDetectiveFingerprintRef* outFingerprint); /* D.h:218 */
 OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, LBAudioDetectiveURLRef inFileURL1,
                                           LBAudioDetectiveURLRef inFileURL2, UInt32 inComparisonRange,
                                           Float32* outMatch);                             /* D.h:235 */
+#endif
 
 /* Addition: many files in one call -- upstream's tests fingerprint 200 files per test, one call each
  * (LBAudioDetectiveTests.m:57-91).  Every payload is uploaded at once and decode, conversion, the window loop and
@@ -214,9 +225,9 @@ OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef inDetective, UInt3
 /* Decode a file to mono float32, optionally converted to inSampleRate (0 = keep the file's rate): host code
  * (no detective, no device), the samples LBAudioDetectiveProcessAudioURL's device converter produces.
  * The buffer is owned by the caller and released with LBAudioDetectiveFreeSamples. */
-OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
+OSStatus LBAudioDetectiveReadAudioURL(const char* inFilePath, Float64 inSampleRate, Float32** outSamples,
                                       UInt64* outCount, Float64* outSampleRate);
-OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate,
+OSStatus LBAudioDetectiveReadAudioURLWithResampler(const char* inFilePath, Float64 inSampleRate,
                                                    UInt32 inResamplerMode, Float32** outSamples, UInt64* outCount,
                                                    Float64* outSampleRate);
 void LBAudioDetectiveFreeSamples(Float32* inSamples);
@@ -444,4 +455,38 @@ const char* LBAudioDetectiveVersionString(void);
 #ifdef __cplusplus
 }
 #endif
+
+#ifdef __OBJC__
+/* Objective-C hosts: upstream's NSURL-taking names (D.h:218,235), source compatible with
+ * LBAudioDetectiveTests.m:66-68 and the README snippet.  The path is taken with two message sends through the
+ * runtime's objc_msgSend; under ARC the intermediate NSString lives until the call has returned. */
+#if defined(__has_include)
+#if __has_include(<objc/message.h>)
+#include <objc/message.h>
+#define LBAD_HAVE_OBJC_MESSAGE_H 1
+#endif
+#endif
+#ifndef LBAD_HAVE_OBJC_MESSAGE_H
+#ifdef __cplusplus
+extern "C" id objc_msgSend(id, SEL, ...);
+#else
+extern id objc_msgSend(id, SEL, ...);
+#endif
+#endif
+static inline const char* LBAudioDetectivePathOfURL(NSURL* inURL) {
+    id path;
+    if (!inURL) return (const char*)0;
+    path = ((id (*)(id, SEL))(void (*)(void))objc_msgSend)((id)inURL, @selector(path));
+    return path ? ((const char* (*)(id, SEL))(void (*)(void))objc_msgSend)(path, @selector(fileSystemRepresentation)) : (const char*)0;
+}
+static inline OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef inDetective, NSURL* inFileURL,
+                                                       LBAudioDetectiveFingerprintRef* outFingerprint) {   /* D.h:218 */
+    return LBAudioDetectiveProcessAudioPath(inDetective, LBAudioDetectivePathOfURL(inFileURL), outFingerprint);
+}
+static inline OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, NSURL* inFileURL1, NSURL* inFileURL2,
+                                                        UInt32 inComparisonRange, Float32* outMatch) {   /* D.h:235 */
+    return LBAudioDetectiveCompareAudioPaths(inDetective, LBAudioDetectivePathOfURL(inFileURL1),
+                                             LBAudioDetectivePathOfURL(inFileURL2), inComparisonRange, outMatch);
+}
+#endif /* __OBJC__ */
 #endif /* LBAUDIODETECTIVE_H */

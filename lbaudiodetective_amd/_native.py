@@ -62,6 +62,8 @@ _SIGNATURES = {
     "LBAudioDetectiveSetAnalysisStride": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveProcessAudioURL": (OSStatus, [Ref, C.c_char_p, _P(Ref)]),
     "LBAudioDetectiveCompareAudioURLs": (OSStatus, [Ref, C.c_char_p, C.c_char_p, UInt32, _P(Float32)]),
+    "LBAudioDetectiveProcessAudioPath": (OSStatus, [Ref, C.c_char_p, _P(Ref)]),
+    "LBAudioDetectiveCompareAudioPaths": (OSStatus, [Ref, C.c_char_p, C.c_char_p, UInt32, _P(Float32)]),
     "LBAudioDetectiveProcessAudioURLs": (OSStatus, [Ref, _P(C.c_char_p), UInt32, _P(Ref), _P(OSStatus)]),
     "LBAudioDetectiveConvertAudioURL": (OSStatus, [Ref, C.c_char_p, _P(_P(Float32)), _P(UInt64), _P(UInt64), _P(Float64)]),
     # ---- fingerprint (Fp.h) ----
@@ -182,6 +184,8 @@ def declared_symbols():
     """Every function / constant name include/lbaudiodetective.h declares (parsed from the header)."""
     import re
     text = open(HEADER).read()
+    # the inline Objective-C wrappers at the end of the header are source, not exported symbols
+    text = re.sub(r"#ifdef __OBJC__\n/\* Objective-C hosts.*?#endif /\* __OBJC__ \*/", "", text, flags=re.S)
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     funcs = set(re.findall(r"\b(LBAudioDetective\w*)\s*\(", text))
     consts = set(re.findall(r"extern const \w+ (kLBAudioDetective\w+);", text))

@@ -3,6 +3,7 @@
 // against N candidates, strict '<', first maximum wins) to an HBM-resident database.
 #include "internal.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -85,13 +86,25 @@ OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint*
 // LBAudioDetectiveCorpusQuery on the specialised scan: one launch, the result arrives in pinned memory
 OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range, unsigned long long* key) {
     if (!c->h_out) {
-        LBAD_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_fast_key), (kScanSlots + 1) * sizeof(unsigned long long)));
-        LBAD_HIP(hipMemset(c->d_fast_key, 0, (kScanSlots + 1) * sizeof(unsigned long long)));
-        c->d_ticket = reinterpret_cast<unsigned int*>(c->d_fast_key + kScanSlots);
-        LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_out), 16, hipHostMallocMapped | hipHostMallocCoherent));
-        c->h_out[0] = c->h_out[1] = 0;
-        LBAD_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->h_out_dev), c->h_out, 0));
+        // built in locals and committed only when everything exists: a failure leaves the corpus as it was
+        unsigned long long *d_fast = nullptr, *h_out = nullptr, *h_out_dev = nullptr;
+        OSStatus st = c->stream ? noErr : kLBAudioDetectiveDeviceError;     // created with the corpus
+        if (st == noErr) st = hip_status(hipMalloc(reinterpret_cast<void**>(&d_fast), (kScanSlots + 1) * sizeof(unsigned long long)), "hipMalloc", __LINE__);
+        if (st == noErr) st = hip_status(hipMemset(d_fast, 0, (kScanSlots + 1) * sizeof(unsigned long long)), "memset", __LINE__);
+        if (st == noErr) st = hip_status(hipHostMalloc(reinterpret_cast<void**>(&h_out), 16, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc", __LINE__);
+        if (st == noErr) {
+            h_out[0] = h_out[1] = 0;
+            st = hip_status(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_out_dev), h_out, 0), "device pointer", __LINE__);
+        }
+        if (st != noErr || !h_out_dev) {
+            if (h_out) (void)hipHostFree(h_out);
+            if (d_fast) (void)hipFree(d_fast);
+            return st != noErr ? st : kLBAudioDetectiveDeviceError;
+        }
+        c->d_fast_key = d_fast;
+        c->d_ticket = reinterpret_cast<unsigned int*>(d_fast + kScanSlots);
+        c->h_out_dev = h_out_dev;
+        c->h_out = h_out;
     }
     if (range == 0) range = c->subfp_len;
     std::vector<uint32_t> slots, block;
@@ -101,6 +114,7 @@ OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint
     LBAD_HIP(launch_compare_planes_fast(c->d_planes, c->capacity, c->count, c->n_sub, block.data(), 0, nullptr,
                                         c->d_fast_key, c->stream, c->d_ticket, c->h_out_dev, seq));
     volatile unsigned long long* out = c->h_out;
+    const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 1; out[1] != seq; ++spins) {
         if ((spins & 0xFFFFF) == 0) {                       // every million polls: is the stream still alive?
             const hipError_t e = hipStreamQuery(c->stream);
@@ -109,6 +123,9 @@ OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint
                 if (out[1] != seq) return kLBAudioDetectiveDeviceError;
             } else if (e != hipErrorNotReady) {
                 return hip_status(e, "corpus query", __LINE__);
+            } else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                fprintf(stderr, "lbaudiodetective: corpus scan not finished after 30 s\n");   // a hung kernel must not hang the host
+                return kLBAudioDetectiveDeviceError;
             }
         }
 #if defined(__x86_64__)
@@ -139,8 +156,10 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLengt
     c->capacity = inCapacity;
     c->n_planes = lbad::planes_per_entry(inSubfingerprintLength, inSubfingerprintsPerEntry);
     const size_t bytes = (size_t)c->n_planes * inCapacity * sizeof(uint4);
+    // the polled query's own stream exists from the start, so that every append can order it behind itself
     if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_planes), bytes), "hipMalloc corpus", __LINE__) != noErr ||
-        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr) {
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr ||
+        lbad::hip_status(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "stream", __LINE__) != noErr) {
         LBAudioDetectiveCorpusDispose(c);
         return NULL;
     }
@@ -222,6 +241,7 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (c->h_query) (void)hipHostFree(c->h_query);
     if (c->d_key) (void)hipFree(c->d_key);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->append_event) (void)hipEventDestroy(c->append_event);
     if (c->d_fast_key) (void)hipFree(c->d_fast_key);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -247,8 +267,12 @@ OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef c, c
     if (c->count + inNumberOfEntries > c->capacity) return kLBAudioDetectiveArgumentInvalid;
     LBAD_HIP(lbad::launch_pack_planes(static_cast<const uint32_t*>(inPacked), inNumberOfEntries, c->n_sub, c->subfp_len,
                                       c->d_planes, c->capacity, c->count, static_cast<hipStream_t>(inStream)));
+    // the polled query runs on the corpus's own stream: it waits for this event instead of keeping the caller's
+    // stream handle (which may be gone by then); appends on several streams each leave their event behind
+    if (!c->append_event) LBAD_HIP(hipEventCreateWithFlags(&c->append_event, hipEventDisableTiming));
+    LBAD_HIP(hipEventRecord(c->append_event, static_cast<hipStream_t>(inStream)));
+    if (c->stream) LBAD_HIP(hipStreamWaitEvent(c->stream, c->append_event, 0));
     c->appended = true;
-    c->append_stream = static_cast<hipStream_t>(inStream);
     c->count += inNumberOfEntries;
     return noErr;
 }
@@ -533,10 +557,7 @@ OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef c, LBAudioDetecti
     unsigned long long key = 0;
     if (inQuery && c->count > 0 && c->variant != 1 && inQuery->length == c->subfp_len &&
         lbad::planes_fast_supported(c->subfp_len, c->n_sub, inQuery->count)) {
-        if (c->appended) {                                  // order behind appends issued on another stream, once
-            LBAD_HIP(hipStreamSynchronize(c->append_stream));
-            c->appended = false;
-        }
+        c->appended = false;                                // every append made the query stream wait for it
         OSStatus st = lbad::query_fast(c, inQuery, inRange, &key);
         if (st != noErr) return st;
         LBAudioDetectiveCorpusDecodeKey(key, outIndex, outScore);

@@ -579,7 +579,7 @@ OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef d, UInt32 inMode) 
     return noErr;
 }
 
-OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate,
+OSStatus LBAudioDetectiveReadAudioURLWithResampler(const char* inFileURL, Float64 inSampleRate,
                                                    UInt32 inResamplerMode, Float32** outSamples, UInt64* outCount,
                                                    Float64* outSampleRate) {
     LBAD_GUARD_BEGIN
@@ -604,7 +604,7 @@ OSStatus LBAudioDetectiveReadAudioURLWithResampler(LBAudioDetectiveURLRef inFile
     LBAD_GUARD_END
 }
 
-OSStatus LBAudioDetectiveReadAudioURL(LBAudioDetectiveURLRef inFileURL, Float64 inSampleRate, Float32** outSamples,
+OSStatus LBAudioDetectiveReadAudioURL(const char* inFileURL, Float64 inSampleRate, Float32** outSamples,
                                       UInt64* outCount, Float64* outSampleRate) {
     return LBAudioDetectiveReadAudioURLWithResampler(inFileURL, inSampleRate, 0, outSamples, outCount, outSampleRate);
 }
@@ -628,6 +628,7 @@ OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32*
         return noErr;
     }
     const uint64_t rows = frames * lbad::kRowsPerFrame;
+    if (rows > (UINT64_MAX - W) / inHop || frames > 0xFFFFFFFFull / lbad::kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
     const uint64_t need = rows * inHop + W;                // (need - W) / hop / 128 == frames
     std::vector<float> padded;
     const float* pcm = inClientSamples;
@@ -656,12 +657,18 @@ OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32*
         }
     }
     std::vector<Boolean> bools((size_t)frames * d->subfp_len);
-    const uint32_t saved = d->stride;
-    d->stride = inHop;                                      // the plan is keyed by the hop between windows
-    st = ensure_plan(d);
-    if (st == noErr)
-        st = lbad::fingerprint_clips_host(d, pcm, 0, 1, need, bools.data(), tail.mode ? &tail : nullptr, tbl.empty() ? nullptr : &tbl);
-    d->stride = saved;
+    {
+        // the plan is keyed by the hop between windows; the public stride comes back however this block is left
+        struct Restore {
+            LBAudioDetective* det;
+            uint32_t saved;
+            ~Restore() { det->stride = saved; }
+        } restore{d, d->stride};
+        d->stride = inHop;
+        st = ensure_plan(d);
+        if (st == noErr)
+            st = lbad::fingerprint_clips_host(d, pcm, 0, 1, need, bools.data(), tail.mode ? &tail : nullptr, tbl.empty() ? nullptr : &tbl);
+    }
     if (st != noErr) return st;
     *outFingerprint = lbad::fingerprint_from_bools(d, bools.data(), frames);
     return noErr;
@@ -676,6 +683,11 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, const char* inFi
     // converted samples stay there for the window loop (api_files.cpp: a batch of one file)
     return lbad::process_audio_files(d, &inFileURL, 1, outFingerprint, nullptr);
     LBAD_GUARD_END
+}
+
+// the path-taking names an Objective-C host's inline wrappers call (include/lbaudiodetective.h)
+OSStatus LBAudioDetectiveProcessAudioPath(LBAudioDetectiveRef d, const char* inFilePath, LBAudioDetectiveFingerprintRef* outFingerprint) {
+    return LBAudioDetectiveProcessAudioURL(d, inFilePath, outFingerprint);
 }
 
 // The file front end alone, on the device, for parity checks: the samples the window loop of ProcessAudioURL sees
@@ -722,6 +734,11 @@ OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, const char* inF
     LBAudioDetectiveFingerprintDispose(fp[1]);
     return st;
     LBAD_GUARD_END
+}
+
+OSStatus LBAudioDetectiveCompareAudioPaths(LBAudioDetectiveRef d, const char* inFilePath1, const char* inFilePath2,
+                                           UInt32 inComparisonRange, Float32* outMatch) {
+    return LBAudioDetectiveCompareAudioURLs(d, inFilePath1, inFilePath2, inComparisonRange, outMatch);
 }
 
 // ---- streaming: chunked PCM in, the partial frame is carried across calls -----------------------------

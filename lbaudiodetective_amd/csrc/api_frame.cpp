@@ -3,6 +3,8 @@
 // Mirrors LBAudioDetective/LBAudioDetectiveFrame.m; line cites refer to it.
 #include "internal.hpp"
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstring>
 
@@ -84,6 +86,37 @@ bool dense(const LBAudioDetectiveFrame* f, std::vector<float>& m) {
 
 extern "C" {
 
+// Device memory of the two computing Frame calls: one buffer per device, created on first use and only growing
+// (like the other one-off entry points), behind a mutex -- a caller that decomposes many frames pays two copies
+// and one launch per call, no allocation.
+namespace {
+struct FrameContext {
+    std::mutex lock;
+    void* d = nullptr;
+    size_t cap = 0;
+    hipStream_t stream = nullptr;
+};
+FrameContext g_frame[lbad::kMaxDevices];
+
+// returns the context of the current device with at least `bytes` of device memory, locked by `guard`
+FrameContext* frame_context(size_t bytes, std::unique_lock<std::mutex>& guard) {
+    const int dev = lbad::current_device();
+    if (dev < 0 || dev >= lbad::kMaxDevices) return nullptr;
+    FrameContext& c = g_frame[dev];
+    guard = std::unique_lock<std::mutex>(c.lock);
+    if (!c.stream && lbad::hip_status(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "stream", __LINE__) != noErr) return nullptr;
+    if (c.cap < bytes) {
+        void* nd = nullptr;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (lbad::hip_status(hipMalloc(&nd, want), "hipMalloc", __LINE__) != noErr) return nullptr;
+        if (c.d) (void)hipFree(c.d);
+        c.d = nd;
+        c.cap = want;
+    }
+    return &c;
+}
+}  // namespace
+
 void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame) {  // :113-132
     LBAudioDetectiveFrame* f = inFrame;
     const uint32_t rows = f->n_rows, cols = f->row_length;
@@ -94,13 +127,15 @@ void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame) {  // :113
         fprintf(stderr, "lbaudiodetective: no HIP device, LBAudioDetectiveFrameDecompose did nothing\n");
         return;
     }
-    float* d = nullptr;
     const size_t bytes = m.size() * sizeof(float);
-    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&d), 2 * bytes), "hipMalloc", __LINE__) != noErr) return;
-    bool ok = lbad::hip_status(hipMemcpy(d, m.data(), bytes, hipMemcpyHostToDevice), "copy in", __LINE__) == noErr;
-    ok = ok && lbad::hip_status(lbad::launch_haar2d_generic(d, d + m.size(), rows, cols, nullptr), "haar", __LINE__) == noErr;
-    ok = ok && lbad::hip_status(hipMemcpy(m.data(), d, bytes, hipMemcpyDeviceToHost), "copy out", __LINE__) == noErr;
-    (void)hipFree(d);
+    std::unique_lock<std::mutex> guard;
+    FrameContext* c = frame_context(2 * bytes, guard);
+    if (!c) return;
+    float* d = static_cast<float*>(c->d);
+    bool ok = lbad::hip_status(hipMemcpyAsync(d, m.data(), bytes, hipMemcpyHostToDevice, c->stream), "copy in", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(lbad::launch_haar2d_generic(d, d + m.size(), rows, cols, c->stream), "haar", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(hipMemcpyAsync(m.data(), d, bytes, hipMemcpyDeviceToHost, c->stream), "copy out", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(hipStreamSynchronize(c->stream), "sync", __LINE__) == noErr;
     if (!ok) return;
     for (uint32_t r = 0; r < rows; ++r)
         std::memcpy(f->rows[r].data(), m.data() + (size_t)r * cols, cols * sizeof(float));
@@ -118,17 +153,17 @@ void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, U
         return;
     }
     const uint32_t nw = std::min(inNumberOfWavelets, n);  // upstream indexes past the array beyond n
-    float* d = nullptr;
-    uint8_t* d_out = nullptr;
     const size_t bytes = m.size() * sizeof(float);
-    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&d), bytes + 2 * (size_t)nw), "hipMalloc", __LINE__) != noErr)
-        return;
-    d_out = reinterpret_cast<uint8_t*>(d) + bytes;
+    std::unique_lock<std::mutex> guard;
+    FrameContext* c = frame_context(bytes + 2 * (size_t)nw, guard);
+    if (!c) return;
+    float* d = static_cast<float*>(c->d);
+    uint8_t* d_out = reinterpret_cast<uint8_t*>(d) + bytes;
     std::vector<uint8_t> flags((size_t)2 * nw, 0);
-    bool ok = lbad::hip_status(hipMemcpy(d, m.data(), bytes, hipMemcpyHostToDevice), "copy in", __LINE__) == noErr;
-    ok = ok && lbad::hip_status(lbad::launch_extract_generic(d, n, nw, d_out, nullptr), "extract", __LINE__) == noErr;
-    ok = ok && lbad::hip_status(hipMemcpy(flags.data(), d_out, flags.size(), hipMemcpyDeviceToHost), "copy out", __LINE__) == noErr;
-    (void)hipFree(d);
+    bool ok = lbad::hip_status(hipMemcpyAsync(d, m.data(), bytes, hipMemcpyHostToDevice, c->stream), "copy in", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(lbad::launch_extract_generic(d, n, nw, d_out, c->stream), "extract", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(hipMemcpyAsync(flags.data(), d_out, flags.size(), hipMemcpyDeviceToHost, c->stream), "copy out", __LINE__) == noErr;
+    ok = ok && lbad::hip_status(hipStreamSynchronize(c->stream), "sync", __LINE__) == noErr;
     if (!ok) return;
     // upstream only ever writes TRUE into the caller's (pre-zeroed) buffer
     for (size_t i = 0; i < flags.size(); ++i)

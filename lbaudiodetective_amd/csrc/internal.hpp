@@ -330,8 +330,8 @@ struct LBAudioDetectiveCorpus {
     unsigned long long* h_out_dev = nullptr;     // its device address
     unsigned long long seq = 0;
     hipStream_t stream = nullptr;
-    bool appended = false;                       // entries were appended since the last polled query ...
-    hipStream_t append_stream = nullptr;         // ... on this stream
+    bool appended = false;                       // entries were appended since the last polled query
+    hipEvent_t append_event = nullptr;           // recorded behind the latest append on ITS stream
     // ragged form (LBAudioDetectiveCorpusNewRagged): entries of any length as a stream of 32-byte records
     bool ragged = false;
     uint4* d_recs = nullptr;                     // 2 x uint4 per record

@@ -194,6 +194,22 @@ def test_sharded_c_host_builds_and_fails_loudly_without_gpu(lb, tmp_path):
         assert out.returncode == 1 and "OSStatus" in out.stderr
 
 
+def test_header_compiles_for_an_objective_c_host():
+    """north_star: "Objective-C host -> HIP".  tests/objc_host_snippet.m passes NSURL* to LBAudioDetectiveProcessAudioURL /
+    ...CompareAudioURLs exactly like LBAudioDetectiveTests.m:66-68; the header must compile as Objective-C (manual
+    retain/release and ARC) and Objective-C++ without any Apple SDK header."""
+    import shutil, subprocess
+    clang = shutil.which("clang") or "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no clang")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "objc_host_snippet.m")
+    for lang, extra in (("objective-c", []), ("objective-c", ["-fobjc-arc", "-fobjc-runtime=macosx-10.13"]), ("objective-c++", [])):
+        out = subprocess.run([clang, "-x", lang, *extra, "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I",
+                              os.path.join(root, "include"), src], capture_output=True, text=True)
+        assert out.returncode == 0, (lang, extra, out.stderr[-1500:])
+
+
 def test_out_of_range_indices_are_safe(lb):
     fp = lb.Fingerprint.from_bools(np.ones((2, 8), np.uint8))
     assert not fp.subfingerprint_at_index(5).any()
