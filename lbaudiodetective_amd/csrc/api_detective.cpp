@@ -628,7 +628,7 @@ OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32*
         return noErr;
     }
     const uint64_t rows = frames * lbad::kRowsPerFrame;
-    if (rows > (UINT64_MAX - W) / inHop || frames > 0xFFFFFFFFull / lbad::kRowsPerFrame) return kLBAudioDetectiveArgumentInvalid;
+    if (rows > (UINT64_MAX - W) / inHop) return kLBAudioDetectiveArgumentInvalid;   // rows * hop + W must not wrap
     const uint64_t need = rows * inHop + W;                // (need - W) / hop / 128 == frames
     std::vector<float> padded;
     const float* pcm = inClientSamples;
