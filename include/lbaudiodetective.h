@@ -16,7 +16,10 @@
  *
  * Threading: like upstream, nothing here is re-entrant per object -- one call at a time per detective,
  * fingerprint, frame, stream or corpus; distinct objects are independent.  One process drives one GPU
- * (the current HIP device at the time of the call).
+ * (the current HIP device at the time of the call).  A detective also serves ONE HIP STREAM at a time: the
+ * frame-row buffer between its two kernels, the kernels' claim counters, its conversion buffers and its timing
+ * events belong to it, so two batch calls in flight on different streams of the same detective would share them.
+ * Use one detective per stream or thread (they are cheap: a plan of a few tables).
  *
  * Plain C, plain pointers and sizes only.  "Device pointer" means memory of the current
  * HIP device (e.g. torch.Tensor.data_ptr()); "stream" is a hipStream_t passed as void*
@@ -209,6 +212,10 @@ Boolean LBAudioDetectiveFrameEqualToFrame(LBAudioDetectiveFrameRef inFrame1, LBA
  * analysisStride * processingRate / fileRate processing-rate samples (rounded, at least 1).
  * Hop mode 0: analysisStride samples at the processing rate, like the PCM entry points. */
 OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef inDetective, UInt32 inMode);
+/* NOTE on defaults: since round 2 the file entry points default to hop mode 1 and tail mode 1 (upstream's
+ * behaviour; round 1 shipped hop mode 0 / zero-filled tails).  For a file whose rate differs from the processing
+ * rate the two give different fingerprints, so a corpus built from FILES with the round-1 defaults must be
+ * rebuilt, or queried with LBAudioDetectiveSetFileHopMode(d, 0).  Fingerprints of PCM are unaffected. */
 /* Hop mode 1 only -- the windows upstream starts so close to the end of the file that ExtAudioFileRead
  * cannot deliver windowSize frames (the last ~windowSize * fileRate / processingRate file frames):
  *   1 (default) the read delivers nothing: inNumberFrames = 0 makes every band of the row 0.0

@@ -4,12 +4,13 @@
 # kernel-trace/stats pass, then separate --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ sets), each with
 # --kernel-trace only; summaries land in gpurun_out/prof_<label>/summary.json
 label=$1; shift
+driver=${PROF_DRIVER:-tools/prof_config.py}      # e.g. PROF_DRIVER=tools/prof_sliding.py
 out=$PWD/gpurun_out/prof_$label
 mkdir -p $out
 export PYTHONPATH=$PWD
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 $repo/tools/prof_config.py "$@" > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o p -- python3 $repo/$driver "$@" > $out/stats.log 2>&1
 i=0
 # PROF_SETS=short: only the HBM-byte and LDS passes (the per-point passes of the LDS-tile sweep)
 if [ "$PROF_SETS" = "short" ]; then
@@ -20,7 +21,7 @@ else
 fi
 for set in "${sets[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 $repo/tools/prof_config.py "$@" > $out/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/pmc$i -o p -- python3 $repo/$driver "$@" > $out/pmc$i.log 2>&1
 done
 cd $repo
 python3 tools/prof_summarize.py $out > $out/summary.json
