@@ -272,11 +272,9 @@ static OSStatus fingerprint_clips_host(LBAudioDetective* d, const void* clips, u
     return noErr;
 }
 
-// The file front end on the device: the payload's bytes go up, k_decode.hip turns them into mono float32 at the file's
-// rate, k_resample.hip converts to `rate_out`, the converted samples come back (upstream's file loop, which follows,
-// does its bookkeeping on the host).  Both kernels repeat the host functions' arithmetic (audiofile.cpp), so `out` is
-// what lbad::decode_payload + lbad::resample return for the same file.  The two kernel tables are uploaded once per
-// detective.
+// The file front end on the device, one file, samples back on the host (LBAudioDetectiveConvertAudioURL, the parity
+// aid): the payload's bytes go up, the SAME table-driven kernels the batch path uses (decode_batch_kernel,
+// resample_batch_kernel, here with one descriptor) decode and convert, the converted samples come back.
 static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& a, double rate_out, uint32_t mode,
                                        std::vector<float>& out) {
     out.clear();
@@ -289,25 +287,24 @@ static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& 
     if (st != noErr) return st;
     st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, a.total_frames * sizeof(float));
     if (st != noErr) return st;
-    if (!rp.copy) {
-        st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, rp.n_out * sizeof(float));
-        if (st != noErr) return st;
-    }
+    st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, rp.n_out * sizeof(float));
+    if (st != noErr) return st;
+    st = grow_device(&d->d_rs_desc, &d->d_rs_desc_cap, sizeof(FileDesc));
+    if (st != noErr) return st;
     if (!d->io_stream) LBAD_HIP(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking));
     hipStream_t stream = d->io_stream;
+    FileDesc f;
+    std::memset(&f, 0, sizeof(f));
+    f.kind = (uint32_t)a.kind; f.channels = a.channels; f.bits = a.bits;
+    f.flags = (a.is_float ? 1u : 0u) | (a.little ? 2u : 0u);
+    f.total_frames = a.total_frames; f.first = a.first; f.n_in = a.count;
+    f.n_write = rp.n_out; f.mode = rp.mode; f.copy = rp.copy ? 1u : 0u;
+    f.ratio = rp.ratio; f.scale = rp.scale; f.half = rp.half;
     LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, a.file.data() + a.off, a.len, hipMemcpyHostToDevice, stream));
-    float* decoded = static_cast<float*>(d->d_rs_in);
-    LBAD_HIP(launch_decode((int)a.kind, static_cast<const uint8_t*>(d->d_rs_bytes), a.total_frames, a.channels, a.bits, a.is_float,
-                           a.little, decoded, stream));
-    const float* mono = decoded + a.first;                    // 'pakt' priming frames are skipped, the tail is cut by count
-    if (rp.copy) {
-        LBAD_HIP(hipMemcpyAsync(out.data(), mono, rp.n_out * sizeof(float), hipMemcpyDeviceToHost, stream));
-        LBAD_HIP(hipStreamSynchronize(stream));
-        return noErr;
-    }
+    LBAD_HIP(hipMemcpyAsync(d->d_rs_desc, &f, sizeof(f), hipMemcpyHostToDevice, stream));
     const double* d_table = nullptr;
     uint64_t table_n = 0;
-    if (mode < 2) {
+    if (!rp.copy && mode < 2) {
         table_n = rp.table->size();
         if (!d->d_rs_table[mode]) {
             LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d->d_rs_table[mode]), table_n * sizeof(double)));
@@ -315,8 +312,11 @@ static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& 
         }
         d_table = d->d_rs_table[mode];
     }
-    LBAD_HIP(launch_resample(mono, a.count, mode, rp.ratio, rp.scale, rp.half, rp.table_res, d_table, table_n,
-                             static_cast<float*>(d->d_rs_out), rp.n_out, stream));
+    const FileDesc* d_files = static_cast<const FileDesc*>(d->d_rs_desc);
+    const uint64_t units = a.kind == AudioPayload::Ima4 ? a.total_frames / 64 : a.total_frames;
+    LBAD_HIP(launch_decode_batch(d_files, 1, units, static_cast<const uint8_t*>(d->d_rs_bytes), static_cast<float*>(d->d_rs_in), stream));
+    LBAD_HIP(launch_resample_batch(d_files, 1, rp.n_out, static_cast<const float*>(d->d_rs_in), rp.table_res, d_table, table_n,
+                                   static_cast<float*>(d->d_rs_out), stream));
     LBAD_HIP(hipMemcpyAsync(out.data(), d->d_rs_out, rp.n_out * sizeof(float), hipMemcpyDeviceToHost, stream));
     LBAD_HIP(hipStreamSynchronize(stream));
     return noErr;

@@ -151,13 +151,6 @@ hipError_t launch_file_tail(const Plan& plan, const float* d_pcm, uint64_t n_cli
                             uint32_t n_tail, const uint32_t* d_tbl, float* d_frames, hipStream_t stream);
 
 // generic matrix ops behind the Frame API
-// the file front end's payload decoders (k_decode.hip: audiofile.cpp's decode_ima4 / decode_pcm, same arithmetic)
-hipError_t launch_decode(int kind, const uint8_t* d_data, uint64_t total_frames, uint32_t channels, uint32_t bits,
-                         bool is_float, bool little, float* d_out, hipStream_t stream);
-// the file front end's sample-rate converter (k_resample.hip): audiofile.cpp's resample(), same arithmetic
-hipError_t launch_resample(const float* d_in, uint64_t n_in, uint32_t mode, double ratio, double scale, double half,
-                           int res, const double* d_table, uint64_t table_n, float* d_out, uint64_t n_out,
-                           hipStream_t stream);
 // one file of a batch for the table-driven kernels (k_decode.hip, k_resample.hip, k_file_tail.hip)
 struct FileDesc {
     uint32_t kind, channels, bits, flags;      // AudioPayload::Kind; flags: 1 float samples, 2 little endian

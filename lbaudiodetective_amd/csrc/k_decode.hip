@@ -54,13 +54,6 @@ __device__ __forceinline__ void ima4_packet(const uint8_t* __restrict__ data, ui
         for (int i = 0; i < 64; ++i) o[i] = __fdiv_rn(o[i], (float)channels);
 }
 
-__global__ __launch_bounds__(kThreads) void ima4_kernel(const uint8_t* __restrict__ data, uint64_t packets, uint32_t channels,
-                                                        float* __restrict__ out) {
-    const uint64_t p = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (p >= packets) return;
-    ima4_packet(data, p, channels, out);
-}
-
 // one sample of `bits` width at p -> float in [-1, 1)  (audiofile.cpp: sample_to_float)
 __device__ __forceinline__ float sample_to_float(const uint8_t* p, uint32_t bits, bool is_float, bool little) {
     uint8_t b[8];
@@ -102,14 +95,6 @@ __device__ __forceinline__ void pcm_frame(const uint8_t* __restrict__ data, uint
     }
 }
 
-__global__ __launch_bounds__(kThreads) void pcm_kernel(const uint8_t* __restrict__ data, uint64_t frames, uint32_t channels,
-                                                       uint32_t bits, int is_float, int little, int wav_u8,
-                                                       float* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= frames) return;
-    pcm_frame(data, i, channels, bits, is_float, little, wav_u8, out);
-}
-
 // every file of a batch in one launch: blockIdx.y = file, blockIdx.x walks its packets (IMA4) or frames (PCM)
 __global__ __launch_bounds__(kThreads) void decode_batch_kernel(const FileDesc* __restrict__ files, const uint8_t* __restrict__ bytes,
                                                                 float* __restrict__ decoded) {
@@ -133,23 +118,6 @@ hipError_t launch_decode_batch(const FileDesc* d_files, uint32_t n_files, uint64
     uint64_t bx = (max_units + kThreads - 1) / kThreads;
     if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(decode_batch_kernel, dim3((uint32_t)bx, n_files), dim3(kThreads), 0, stream, d_files, d_bytes, d_decoded);
-    return hipGetLastError();
-}
-
-// kind: AudioPayload::Kind (1 IMA4, 2 PCM, 3 unsigned 8-bit WAV); d_out holds total_frames floats
-hipError_t launch_decode(int kind, const uint8_t* d_data, uint64_t total_frames, uint32_t channels, uint32_t bits,
-                         bool is_float, bool little, float* d_out, hipStream_t stream) {
-    if (total_frames == 0) return hipSuccess;
-    const uint64_t units = kind == 1 ? total_frames / 64 : total_frames;
-    const uint64_t blocks = (units + kThreads - 1) / kThreads;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (kind == 1)
-        hipLaunchKernelGGL(ima4_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_data, units, channels, d_out);
-    else if (kind == 2 || kind == 3)
-        hipLaunchKernelGGL(pcm_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_data, units, channels, bits,
-                           is_float ? 1 : 0, little ? 1 : 0, kind == 3 ? 1 : 0, d_out);
-    else
-        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -59,20 +59,115 @@ __device__ __forceinline__ float linear_sample(const float* __restrict__ in, uin
     return (float)(a * (1.0 - f) + b * f);
 }
 
-__global__ __launch_bounds__(kThreads) void resample_sinc_kernel(const float* __restrict__ in, uint64_t n_in, double ratio,
-                                                                 double scale, double half, int res,
-                                                                 const double* __restrict__ table, uint64_t table_n,
-                                                                 float* __restrict__ out, uint64_t n_out) {
-    const uint64_t n = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (n >= n_out) return;
-    out[n] = sinc_sample(in, n_in, ratio, scale, half, res, table, table_n, n);
-}
+// Band-limited models with the kernel table staged through LDS.  The table coordinate of tap j (counted from the
+// output's own first tap k0) is |j - half + f| * coord with f = k0 - (pos - half) in [0, 1): it depends on the output
+// only through its phase f.  When the file rate is (nearly) a multiple of the processing rate -- 44.1 kHz -> 5512 Hz:
+// ratio 8.0007 -- the phases of 256 consecutive outputs lie within 0.19 of each other, so for every tap the whole
+// block reads a run of ~50 consecutive table points.  The block stages those runs for kTapGroup taps at a time
+// (rows of kRowLen doubles) and every lane takes its two points from LDS instead of 16 bytes through L1 per tap
+// (23 GB per sixty files, what bounded the kernel).  Same values, same operations, same order as sinc_sample;
+// a lane whose index falls outside the staged run (or a block whose phases are spread wider) reads the table itself.
+constexpr int kRowLen = 64;
+constexpr int kTapGroup = 48;
+// The block's input samples go through LDS as well: at a ratio of 8 the lanes of a wave read samples 32 bytes apart
+// (16 cache lines per load instruction and tap).  One pad word per 64 keeps lanes 8 samples apart on distinct banks.
+constexpr int kInMax = 3072;
 
-__global__ __launch_bounds__(kThreads) void resample_linear_kernel(const float* __restrict__ in, uint64_t n_in, double ratio,
-                                                                   float* __restrict__ out, uint64_t n_out) {
-    const uint64_t n = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (n >= n_out) return;
-    out[n] = linear_sample(in, n_in, ratio, n);
+__device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in, uint64_t n_in, double ratio, double scale,
+                                                   double half, int res, const double* __restrict__ table, uint64_t table_n,
+                                                   uint64_t n, bool active, double (*s_rows)[kRowLen], uint32_t* s_lo,
+                                                   uint32_t* s_stat, float* s_in) {
+    const double pos = (double)n * ratio;
+    const long k0 = (long)ceil(pos - half), k1 = (long)floor(pos + half);
+    const double coord = (double)res / scale;
+    const uint32_t tn = table_n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)table_n;
+    // phase spread and tap count of the block (fixed-point phases through LDS atomics: the bounds only place the
+    // staged runs, the margins below absorb the rounding)
+    const double fr = (double)k0 - (pos - half);
+    __syncthreads();                                          // s_stat is reused by consecutive blocks
+    if (threadIdx.x == 0) {
+        s_stat[0] = 0xFFFFFFFFu;
+        s_stat[1] = 0u;
+        s_stat[2] = 0u;
+        s_stat[3] = 0x7FFFFFFFu;                              // smallest first tap (as int)
+        s_stat[4] = 0x80000001u;                              // largest last tap (as int)
+    }
+    __syncthreads();
+    if (active) {
+        const double fc = fr < 0.0 ? 0.0 : (fr > 1.0 ? 1.0 : fr);
+        const uint32_t q = (uint32_t)(fc * 1073741824.0);     // 2^30
+        atomicMin(&s_stat[0], q);
+        atomicMax(&s_stat[1], q + 1u);
+        atomicMax(&s_stat[2], (uint32_t)(k1 - k0 + 1));
+        atomicMin(reinterpret_cast<int*>(&s_stat[3]), (int)(k0 < -2147483647L ? -2147483647L : (k0 > 2147483647L ? 2147483647L : k0)));
+        atomicMax(reinterpret_cast<int*>(&s_stat[4]), (int)(k1 < -2147483647L ? -2147483647L : (k1 > 2147483647L ? 2147483647L : k1)));
+    }
+    __syncthreads();
+    const double fmin = (double)s_stat[0] * (1.0 / 1073741824.0), fmax = (double)s_stat[1] * (1.0 / 1073741824.0);
+    const int n_taps = (int)s_stat[2];
+    if (n_taps == 0) return 0.0f;                             // no active lane in the block
+#if defined(LBAD_EXP_FORCE_PLAIN)
+    const bool tiled = false;
+#elif defined(LBAD_EXP_FORCE_TILED)
+    const bool tiled = true;
+#else
+    const bool tiled = (fmax - fmin) * coord + 6.0 <= (double)kRowLen;
+#endif
+    if (!tiled) {                                             // phases too far apart: plain reads
+        return active ? sinc_sample(in, n_in, ratio, scale, half, res, table, table_n, n) : 0.0f;
+    }
+    // the input samples every tap of the block reads
+    const long kbase = (long)(int)s_stat[3], kend = (long)(int)s_stat[4];
+    const bool stage_in = n_in < 0x7FFFFFFFull && kend - kbase + 1 <= (long)kInMax;
+    if (stage_in) {
+        for (long p = threadIdx.x; p <= kend - kbase; p += kThreads) {
+            const long kk = kbase + p;
+            s_in[p + (p >> 6)] = kk >= 0 && (uint64_t)kk < n_in ? in[(uint64_t)kk] : 0.0f;
+        }
+    }
+    double acc = 0.0, wsum = 0.0;
+    double kd = (double)k0;
+    long k = k0;
+    for (int g0 = 0; g0 < n_taps; g0 += kTapGroup) {
+        __syncthreads();
+        if (threadIdx.x < kTapGroup) {                        // first staged point of row r: 2 points below the smallest index
+            const double a = (double)(g0 + (int)threadIdx.x) - half + fmin, b = (double)(g0 + (int)threadIdx.x) - half + fmax;
+            const double tmin = a >= 0.0 ? a * coord : (b <= 0.0 ? -b * coord : 0.0);
+            const double lo = floor(tmin) - 2.0;
+            s_lo[threadIdx.x] = lo > 0.0 ? (lo < 4294967000.0 ? (uint32_t)lo : 0xFFFFFF00u) : 0u;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kTapGroup * kRowLen; e += kThreads) {
+            const int r = e / kRowLen, c = e % kRowLen;
+            const uint64_t i = (uint64_t)s_lo[r] + (uint64_t)c;
+            s_rows[r][c] = i < table_n ? table[i] : 0.0;
+        }
+        __syncthreads();
+        const int rows = n_taps - g0 < kTapGroup ? n_taps - g0 : kTapGroup;
+        for (int r = 0; r < rows; ++r, ++k, kd += 1.0) {
+            if (!active || k > k1) continue;
+            const double t = fabs(kd - pos) * coord;          // table coordinate
+            const uint32_t i = (uint32_t)t;
+            const bool ok = i + 1u < tn && t < 4294967040.0;
+            const uint32_t idx = i - s_lo[r];
+            double ta, tb;
+            if (idx < (uint32_t)(kRowLen - 1)) {               // unsigned: also false when i < s_lo[r]
+                ta = s_rows[r][idx];
+                tb = s_rows[r][idx + 1u];
+            } else {
+                const uint32_t ic = ok ? i : 0u;
+                ta = table[ic];
+                tb = table[ic + 1u];
+            }
+            const double w = ok ? ta + (tb - ta) * (t - (double)i) : 0.0;
+            wsum += w;
+            const bool inside = k >= 0 && (uint64_t)k < n_in;
+            const long q = k - kbase;
+            const float x = stage_in ? s_in[q + (q >> 6)] : (inside ? in[(uint64_t)k] : 0.0f);
+            acc += w * (ok && inside ? (double)x : 0.0);       // + (+-0.0) leaves acc as it is (acc is never -0.0)
+        }
+    }
+    return (float)(wsum != 0.0 ? acc / wsum : 0.0);
 }
 
 // every file of a batch in one launch: blockIdx.y = file, blockIdx.x walks its output samples; a file whose rate is
@@ -80,33 +175,29 @@ __global__ __launch_bounds__(kThreads) void resample_linear_kernel(const float* 
 __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc* __restrict__ files, const float* __restrict__ decoded,
                                                                   int res, const double* __restrict__ table, uint64_t table_n,
                                                                   float* __restrict__ pcm) {
+    __shared__ double s_rows[kTapGroup][kRowLen];
+    __shared__ uint32_t s_lo[kTapGroup];
+    __shared__ uint32_t s_stat[8];
+    __shared__ float s_in[kInMax + kInMax / 64 + 1];
     const FileDesc f = files[blockIdx.y];
     const float* in = decoded + f.dec_off + f.first;
     float* out = pcm + f.out_off;
-    for (uint64_t n = (uint64_t)blockIdx.x * kThreads + threadIdx.x; n < f.n_write; n += (uint64_t)gridDim.x * kThreads) {
-        float v;
-        if (f.copy) v = in[n];
-        else if (f.mode == 2) v = linear_sample(in, f.n_in, f.ratio, n);
-        else v = sinc_sample(in, f.n_in, f.ratio, f.scale, f.half, res, table, table_n, n);
-        out[n] = v;
+    for (uint64_t n0 = (uint64_t)blockIdx.x * kThreads; n0 < f.n_write; n0 += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t n = n0 + threadIdx.x;
+        const bool active = n < f.n_write;
+        float v = 0.0f;
+        if (f.copy) {
+            if (active) v = in[n];
+        } else if (f.mode == 2) {
+            if (active) v = linear_sample(in, f.n_in, f.ratio, n);
+        } else {
+            v = sinc_sample_tiled(in, f.n_in, f.ratio, f.scale, f.half, res, table, table_n, n, active, s_rows, s_lo, s_stat, s_in);
+        }
+        if (active) out[n] = v;
     }
 }
 
 }  // namespace
-
-hipError_t launch_resample(const float* d_in, uint64_t n_in, uint32_t mode, double ratio, double scale, double half,
-                           int res, const double* d_table, uint64_t table_n, float* d_out, uint64_t n_out,
-                           hipStream_t stream) {
-    if (n_out == 0) return hipSuccess;
-    const uint64_t blocks = (n_out + kThreads - 1) / kThreads;
-    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    if (mode == 2)
-        hipLaunchKernelGGL(resample_linear_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_in, n_in, ratio, d_out, n_out);
-    else
-        hipLaunchKernelGGL(resample_sinc_kernel, dim3((uint32_t)blocks), dim3(kThreads), 0, stream, d_in, n_in, ratio, scale,
-                           half, res, d_table, table_n, d_out, n_out);
-    return hipGetLastError();
-}
 
 // d_files: n_files descriptors (all with the same converter mode, hence one table); max_out: the largest n_write
 hipError_t launch_resample_batch(const FileDesc* d_files, uint32_t n_files, uint64_t max_out, const float* d_decoded, int res,
