@@ -300,7 +300,7 @@ static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& 
     f.total_frames = a.total_frames; f.first = a.first; f.n_in = a.count;
     f.n_write = rp.n_out; f.mode = rp.mode; f.copy = rp.copy ? 1u : 0u;
     f.ratio = rp.ratio; f.scale = rp.scale; f.half = rp.half;
-    LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, a.file.data() + a.off, a.len, hipMemcpyHostToDevice, stream));
+    LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, a.bytes + a.off, a.len, hipMemcpyHostToDevice, stream));
     LBAD_HIP(hipMemcpyAsync(d->d_rs_desc, &f, sizeof(f), hipMemcpyHostToDevice, stream));
     const double* d_table = nullptr;
     uint64_t table_n = 0;
@@ -363,6 +363,7 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->d_rs_tail) (void)hipFree(inDetective->d_rs_tail);
     if (inDetective->d_rs_desc) (void)hipFree(inDetective->d_rs_desc);
     if (inDetective->h_files) (void)hipHostFree(inDetective->h_files);
+    if (inDetective->h_packed) (void)hipHostFree(inDetective->h_packed);
     for (double* t : inDetective->d_rs_table)
         if (t) (void)hipFree(t);
     if (inDetective->io_stream) (void)hipStreamDestroy(inDetective->io_stream);

@@ -30,6 +30,7 @@ struct Job {
     uint64_t n_client = 0;     // samples at the processing rate
     uint64_t slot_frames = 0, frame0 = 0;   // frames of the clip the file owns, first of them
     uint64_t bytes0 = 0, dec0 = 0;          // offsets of its payload / decoded samples in the batch buffers
+    uint64_t file_off = 0, file_size = 0;   // the whole file inside the pinned block
     uint64_t first_short = 0;
     size_t tbl0 = 0, tbl_n = 0;             // tail mode 2: its table inside the batch's table block (words)
 };
@@ -63,15 +64,13 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     const uint64_t G = (uint64_t)kRowsPerFrame * hop;
     const uint64_t gap = (W + G - 1) / G;
     uint64_t total_frames = 0;
-    size_t bytes_total = 0, dec_total = 0, tbl_words = 0;
+    size_t dec_total = 0, tbl_words = 0;
     const bool stale = d->hop_mode == 1 && d->tail_mode == 2;
     for (size_t i : idx) {
         Job& j = jobs[i];
         j.frame0 = total_frames;
         j.slot_frames = j.frames + gap;
         total_frames += j.slot_frames;
-        j.bytes0 = bytes_total;
-        bytes_total += align_up(j.a.len);
         j.dec0 = dec_total;
         dec_total += (size_t)align_up(j.a.total_frames * sizeof(float)) / sizeof(float);
         j.first_short = j.n_client >= W ? (j.n_client - W) / hop + 1 : 0;
@@ -86,45 +85,13 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     const uint64_t T = total_frames * G + W;                       // samples of the clip: exactly total_frames frames
     const size_t packed_bytes = (size_t)total_frames * LBAD_PACKED_BYTES;
 
-    OSStatus st = grow_device(&d->d_rs_bytes, &d->d_rs_bytes_cap, bytes_total);
-    if (st == noErr) st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, dec_total * sizeof(float));
+    OSStatus st = grow_device(&d->d_rs_in, &d->d_rs_in_cap, dec_total * sizeof(float));
     if (st == noErr) st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, T * sizeof(float));
     if (st == noErr) st = grow_device(reinterpret_cast<void**>(&d->d_io_packed), &d->d_io_packed_cap, packed_bytes);
     if (st == noErr && tbl_words) st = grow_device(&d->d_rs_tail, &d->d_rs_tail_cap, tbl_words * sizeof(uint32_t));
-    if (st == noErr) st = grow_pinned(&d->h_files, &d->h_files_cap, bytes_total > packed_bytes ? bytes_total : packed_bytes);
+    if (st == noErr) st = grow_pinned(&d->h_packed, &d->h_packed_cap, packed_bytes);
     if (st != noErr) return st;
-    if (!d->io_stream) LBAD_HIP(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking));
-    hipStream_t stream = d->io_stream;
-
-    // payloads -> pinned block -> device, in one copy
-    char* stage = static_cast<char*>(d->h_files);
-    auto copy_range = [&](size_t b, size_t e) {
-        for (size_t k = b; k < e; ++k) {
-            const Job& j = jobs[idx[k]];
-            std::memcpy(stage + j.bytes0, j.a.file.data() + j.a.off, j.a.len);
-        }
-    };
-    unsigned copiers = std::thread::hardware_concurrency();
-    if (copiers > 8) copiers = 8;
-    if (bytes_total < (8u << 20) || copiers < 2 || idx.size() < 2 * copiers) {
-        copy_range(0, idx.size());
-    } else {                                                     // a memcpy per core: 100 MB of payloads in ~2 ms
-        std::vector<std::thread> pool;
-        const size_t per = (idx.size() + copiers - 1) / copiers;
-        size_t next = per;
-        try {
-            for (unsigned w = 1; w < copiers && next < idx.size(); ++w) {
-                const size_t e = next + per < idx.size() ? next + per : idx.size();
-                pool.emplace_back(copy_range, next, e);
-                next = e;
-            }
-        } catch (const std::system_error&) {
-        }
-        copy_range(0, per < idx.size() ? per : idx.size());
-        if (next < idx.size()) copy_range(next, idx.size());
-        for (std::thread& t : pool) t.join();
-    }
-    LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, stage, bytes_total, hipMemcpyHostToDevice, stream));
+    hipStream_t stream = d->io_stream;                             // the payload bytes are on their way on this stream
     float* pcm = static_cast<float*>(d->d_rs_out);
     LBAD_HIP(hipMemsetAsync(pcm, 0, T * sizeof(float), stream));   // the slots' zero padding
 
@@ -225,7 +192,7 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
                                           tails.empty() ? nullptr : tails.data(), tails.size());
     }
     if (st != noErr) return st;
-    uint32_t* packed = static_cast<uint32_t*>(d->h_files);
+    uint32_t* packed = static_cast<uint32_t*>(d->h_packed);
     LBAD_HIP(hipMemcpyAsync(packed, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
     LBAD_HIP(hipStreamSynchronize(stream));
     std::vector<Boolean> bools;
@@ -240,67 +207,13 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     return noErr;
 }
 
-}  // namespace
-
-OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size_t n, LBAudioDetectiveFingerprintRef* out,
-                             OSStatus* statuses) {
-    if (!d || !paths || !out) return kLBAudioDetectiveArgumentInvalid;
-    for (size_t i = 0; i < n; ++i) out[i] = NULL;
-    const double rate = d->format.mSampleRate;
-    if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
-    OSStatus st = noErr;
-    std::vector<Job> jobs(n);
-
-    // containers: read + parse on the host, several files at a time
-    auto parse_range = [&](size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) {
-            Job& j = jobs[i];
-            if (!paths[i]) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }   // :211-214
-            const AudioFileStatus fs = parse_audio_file(paths[i], j.a);
-            if (fs == AudioFileStatus::NotFound) { j.st = -43; continue; }            // fnfErr, what ExtAudioFileOpenURL reports
-            if (fs != AudioFileStatus::Ok) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
-            if (!resample_plan(j.a.count, j.a.sample_rate, rate, d->resampler, j.rp)) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }
-            j.n_client = j.a.count == 0 ? 0 : j.rp.n_out;
-        }
-    };
-    unsigned workers = std::thread::hardware_concurrency();
-    if (workers > 8) workers = 8;
-    if (n < 4 || workers < 2) {
-        parse_range(0, n);
-    } else {
-        std::vector<std::thread> pool;
-        const size_t per = (n + workers - 1) / workers;
-        size_t next = per;
-        try {
-            for (unsigned w = 1; w < workers && next < n; ++w) {
-                const size_t e = next + per < n ? next + per : n;
-                pool.emplace_back(parse_range, next, e);
-                next = e;
-            }
-        } catch (const std::system_error&) {
-        }
-        parse_range(0, per < n ? per : n);
-        if (next < n) parse_range(next, n);
-        for (std::thread& t : pool) t.join();
-    }
-
-    // a missing or unreadable file is reported as such whether or not a device exists (like ExtAudioFileOpenURL);
-    // everything after this point needs the GPU
-    bool any = false;
-    for (const Job& j : jobs) any = any || j.st == noErr;
-    if (any) {
-        st = ensure_plan(d);
-        if (st != noErr) {
-            for (Job& j : jobs)
-                if (j.st == noErr) j.st = st;
-        }
-    }
-
+// the files [run_b, n) of one pinned block, already on their way to the device: framing, then one clip per hop
+void process_run(LBAudioDetective* d, std::vector<Job>& jobs, size_t run_b, size_t n, uint64_t budget, std::vector<bool>& done,
+                 LBAudioDetectiveFingerprintRef* out) {
     // framing per file (:236,250-255), then one clip per hop value, cut where the inter-stage buffer would overflow
-    const uint64_t frame_bytes = (uint64_t)kRowsPerFrame * d->bands * sizeof(float);
-    const uint64_t budget = d->scratch_limit / frame_bytes ? d->scratch_limit / frame_bytes : 1;
-    std::vector<bool> done(n, false);
-    for (size_t i = 0; i < n; ++i) {
+    const double rate = d->format.mSampleRate;
+    OSStatus st = noErr;
+    for (size_t i = run_b; i < n; ++i) {
         Job& j = jobs[i];
         if (j.st != noErr) { done[i] = true; continue; }
         if (d->hop_mode == 0) {
@@ -319,7 +232,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
             done[i] = true;
         }
     }
-    for (size_t i = 0; i < n; ++i) {
+    for (size_t i = run_b; i < n; ++i) {
         if (done[i]) continue;
         const uint32_t hop = jobs[i].hop;
         const uint64_t gap = (d->window + (uint64_t)kRowsPerFrame * hop - 1) / ((uint64_t)kRowsPerFrame * hop);
@@ -339,6 +252,123 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
                 if (out[k]) { LBAudioDetectiveFingerprintDispose(out[k]); out[k] = NULL; }
             }
         }
+    }
+}
+
+}  // namespace
+
+OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size_t n, LBAudioDetectiveFingerprintRef* out,
+                             OSStatus* statuses) {
+    if (!d || !paths || !out) return kLBAudioDetectiveArgumentInvalid;
+    for (size_t i = 0; i < n; ++i) out[i] = NULL;
+    const double rate = d->format.mSampleRate;
+    if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = noErr;
+    std::vector<Job> jobs(n);
+
+    // sizes first: a missing or unreadable file is reported as such whether or not a device exists (like
+    // ExtAudioFileOpenURL); everything after that needs the GPU
+    bool any = false;
+    for (size_t i = 0; i < n; ++i) {
+        Job& j = jobs[i];
+        if (!paths[i]) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }       // :211-214
+        FILE* f = std::fopen(paths[i], "rb");
+        if (!f) { j.st = -43; continue; }                                             // fnfErr
+        std::fseek(f, 0, SEEK_END);
+        const long sz = std::ftell(f);
+        std::fclose(f);
+        if (sz <= 0) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
+        j.file_size = (uint64_t)sz;
+        any = true;
+    }
+    if (any) {
+        st = ensure_plan(d);
+        if (st == noErr && !d->io_stream) st = hip_status(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking), "stream", __LINE__);
+        if (st != noErr) {
+            // no usable device: a file that could never be read is still reported as such, the others get the
+            // device's status
+            for (size_t i = 0; i < n; ++i) {
+                Job& j = jobs[i];
+                if (j.st != noErr) continue;
+                AudioPayload probe;
+                j.st = parse_audio_file(paths[i], probe) == AudioFileStatus::Ok ? st : kLBAudioDetectiveUnsupportedFile;
+            }
+            any = false;
+        }
+    }
+    // the files of a call go through in runs of at most 512 MB of file bytes: read straight into ONE pinned block
+    // (threads), parsed in place, uploaded with one copy
+    const uint64_t kRunBytes = 512ull << 20;
+    std::vector<bool> done(n, false);
+    const uint64_t frame_bytes = (uint64_t)kRowsPerFrame * d->bands * sizeof(float);
+    const uint64_t budget = d->scratch_limit / frame_bytes ? d->scratch_limit / frame_bytes : 1;
+    for (size_t run_b = 0; any && run_b < n;) {
+        size_t run_e = run_b;
+        uint64_t total = 0;
+        while (run_e < n && (run_e == run_b || total + align_up(jobs[run_e].file_size) <= kRunBytes)) {
+            if (jobs[run_e].st == noErr) {
+                jobs[run_e].file_off = total;
+                total += align_up(jobs[run_e].file_size);
+            }
+            ++run_e;
+        }
+        st = total ? grow_pinned(&d->h_files, &d->h_files_cap, total) : noErr;
+        if (st == noErr && total) st = grow_device(&d->d_rs_bytes, &d->d_rs_bytes_cap, total);
+        if (st != noErr) {
+            for (size_t i = run_b; i < run_e; ++i)
+                if (jobs[i].st == noErr) jobs[i].st = st;
+            run_b = run_e;
+            continue;
+        }
+        uint8_t* stage = static_cast<uint8_t*>(d->h_files);
+        auto read_range = [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                Job& j = jobs[i];
+                if (j.st != noErr) continue;
+                FILE* f = std::fopen(paths[i], "rb");
+                const size_t got = f ? std::fread(stage + j.file_off, 1, j.file_size, f) : 0;
+                if (f) std::fclose(f);
+                if (got != j.file_size) { j.st = f ? kLBAudioDetectiveUnsupportedFile : -43; continue; }
+                const AudioFileStatus fs = parse_audio_bytes(stage + j.file_off, j.file_size, j.a);
+                if (fs != AudioFileStatus::Ok) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
+                if (!resample_plan(j.a.count, j.a.sample_rate, rate, d->resampler, j.rp)) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }
+                j.n_client = j.a.count == 0 ? 0 : j.rp.n_out;
+                j.bytes0 = j.file_off + j.a.off;
+            }
+        };
+        unsigned workers = std::thread::hardware_concurrency();
+        if (workers > 8) workers = 8;
+        const size_t count = run_e - run_b;
+        if (count < 4 || workers < 2) {
+            read_range(run_b, run_e);
+        } else {
+            std::vector<std::thread> pool;
+            const size_t per = (count + workers - 1) / workers;
+            size_t next = run_b + per;
+            try {
+                for (unsigned w = 1; w < workers && next < run_e; ++w) {
+                    const size_t e = next + per < run_e ? next + per : run_e;
+                    pool.emplace_back(read_range, next, e);
+                    next = e;
+                }
+            } catch (const std::system_error&) {
+            }
+            read_range(run_b, run_b + per < run_e ? run_b + per : run_e);
+            if (next < run_e) read_range(next, run_e);
+            for (std::thread& t : pool) t.join();
+        }
+        if (total) {
+            const hipError_t e = hipMemcpyAsync(d->d_rs_bytes, stage, total, hipMemcpyHostToDevice, d->io_stream);
+            if (e != hipSuccess) {
+                st = hip_status(e, "payload upload", __LINE__);
+                for (size_t i = run_b; i < run_e; ++i)
+                    if (jobs[i].st == noErr) jobs[i].st = st;
+                run_b = run_e;
+                continue;
+            }
+        }
+        process_run(d, jobs, run_b, run_e, budget, done, out);
+        run_b = run_e;
     }
     OSStatus first = noErr;
     for (size_t i = 0; i < n; ++i) {

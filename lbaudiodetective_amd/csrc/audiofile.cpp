@@ -124,7 +124,7 @@ AudioFileStatus parse_audio_file(const char* path, AudioPayload& out) {
     out = AudioPayload();
     FILE* f = std::fopen(path, "rb");
     if (!f) return AudioFileStatus::NotFound;
-    std::vector<uint8_t>& buf = out.file;
+    std::vector<uint8_t> buf;
     std::fseek(f, 0, SEEK_END);
     const long sz = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
@@ -132,9 +132,17 @@ AudioFileStatus parse_audio_file(const char* path, AudioPayload& out) {
     buf.resize((size_t)sz);
     const size_t got = std::fread(buf.data(), 1, buf.size(), f);
     std::fclose(f);
-    if (got != buf.size() || buf.size() < 12) return AudioFileStatus::Unsupported;
-    const uint8_t* p = buf.data();
-    const size_t n = buf.size();
+    if (got != buf.size()) return AudioFileStatus::Unsupported;
+    const AudioFileStatus st = parse_audio_bytes(buf.data(), buf.size(), out);
+    out.file = std::move(buf);                                // the vector's storage does not move with it
+    out.bytes = out.file.data();
+    return st;
+}
+
+AudioFileStatus parse_audio_bytes(const uint8_t* p, size_t n, AudioPayload& out) {
+    out = AudioPayload();
+    out.bytes = p;
+    if (!p || n < 12) return AudioFileStatus::Unsupported;
     auto pcm_ok = [&]() {
         if (out.channels == 0 || out.bits == 0 || out.bits % 8 != 0 || out.bits > 64) return false;
         if (out.is_float && out.bits != 32 && out.bits != 64) return false;
@@ -243,7 +251,7 @@ AudioFileStatus parse_audio_file(const char* path, AudioPayload& out) {
 }
 
 bool decode_payload(const AudioPayload& a, std::vector<float>& mono) {
-    const uint8_t* data = a.file.data() + a.off;
+    const uint8_t* data = a.bytes + a.off;
     switch (a.kind) {
         case AudioPayload::Ima4: return decode_ima4(data, a.len, a.channels, a.valid_frames, a.priming, mono);
         case AudioPayload::Pcm: return decode_pcm(data, a.len, a.channels, a.bits, a.is_float, a.little, mono);

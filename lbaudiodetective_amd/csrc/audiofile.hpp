@@ -15,7 +15,8 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
 struct AudioPayload {
     enum Kind { None = 0, Ima4 = 1, Pcm = 2, WavU8 = 3 };
     Kind kind = None;
-    std::vector<uint8_t> file;        // the whole file
+    std::vector<uint8_t> file;        // the whole file (empty when the caller supplied the bytes)
+    const uint8_t* bytes = nullptr;   // the file's bytes: file.data() or the caller's buffer
     size_t off = 0, len = 0;          // payload bytes within it
     uint32_t channels = 0, bits = 0;
     bool is_float = false, little = false;
@@ -25,6 +26,9 @@ struct AudioPayload {
     uint64_t total_frames = 0, first = 0, count = 0;
 };
 AudioFileStatus parse_audio_file(const char* path, AudioPayload& out);
+// the same on a file already in memory (the batch path reads files straight into pinned memory); `data` must
+// outlive `out`
+AudioFileStatus parse_audio_bytes(const uint8_t* data, size_t size, AudioPayload& out);
 bool decode_payload(const AudioPayload& payload, std::vector<float>& mono);
 // Sample-rate conversion (documented stand-ins for Apple's converter): mode 0 long Kaiser sinc, 1 short
 // sinc, 2 linear interpolation.  False for an unknown mode or a rate ratio outside [1/4096, 4096].

@@ -296,8 +296,10 @@ struct LBAudioDetective {
     size_t d_rs_desc_cap = 0;
     void* d_rs_tail = nullptr;        // tail-mode-2 tables of a file batch
     size_t d_rs_tail_cap = 0;
-    void* h_files = nullptr;          // pinned staging of a file batch's payload bytes / packed results
+    void* h_files = nullptr;          // pinned block a file batch is read into
     size_t h_files_cap = 0;
+    void* h_packed = nullptr;         // pinned landing area of a file batch's packed results
+    size_t h_packed_cap = 0;
     // optional per-stage timing (hipEvents on the caller's stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2
