@@ -288,12 +288,16 @@ OSStatus LBAudioDetectiveFingerprintClips(LBAudioDetectiveRef inDetective, const
 OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective, const void* inClips,
                                                 UInt32 inSampleFormat, UInt64 inNumberOfClips,
                                                 UInt64 inSamplesPerClip, Boolean* outBooleans);
-/* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band count),
- * 2 = specialised kernels only (stride 64: pruned 1024-point FFT for bands that read only bins 0..21; streaming
- * 2048- / 4096-point kernels that share the early FFT stages between consecutive windows (clips that start on 8-byte boundaries: an even clip length or a single clip,
- * <= 32 bands); register-resident FFT of 256- to 2048-sample windows for any other band table; register Haar / select for
- * 128 x 32 frames) -- ArgumentInvalid when the configuration has no specialised stage-1 kernel; 3 = like 2 but
- * the register-resident 2048-point kernel instead of the streaming one (measurement). */
+/* Kernel selection for the batch path: 0 = automatic, 1 = generic kernels (any window size / band count / stride),
+ * 2 = specialised kernels only -- ArgumentInvalid when the configuration has no specialised stage-1 kernel:
+ *   - stride 64: pruned 1024-point FFT for bands that read only bins 0..21; streaming 2048- / 4096-point kernels that
+ *     share the early FFT stages between consecutive windows (clips that start on 8-byte boundaries: an even clip
+ *     length or a single clip; <= 32 bands);
+ *   - register-resident FFT of 256- to 2048-sample windows for any band table at ANY EVEN stride (float32 input when
+ *     the stride is not 64; the span of a workgroup's windows must fit the LDS budget) -- among them the hop of 8
+ *     samples the file entry points use for 44.1 kHz material at the defaults;
+ *   - register Haar / select for 128 x 32 frames.
+ * 3 = like 2 but the register-resident 2048-point kernel instead of the streaming one (measurement). */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
 /* Measurement knobs of the generic stage-1 kernel (the LDS-tile sizing sweep of tools/sweep_lds_tiles.py):
  * waves per workgroup (0 = automatic; a value the configuration cannot hold falls back to automatic) and

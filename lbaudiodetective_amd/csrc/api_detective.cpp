@@ -139,9 +139,10 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     const bool pairs_ok = reinterpret_cast<uintptr_t>(d_pcm_raw) % (2 * elem) == 0 && ((spc & 1) == 0 || n_clips == 1);
     const bool stream_ok = p.stream_ok && pairs_ok;
     const bool stream2_ok = p.stream2_ok && pairs_ok && d->variant != 3;
-    bool special = p.pruned_ok || p.full_ok || stream_ok || stream2_ok;
+    const bool full_ok = p.full_ok && rows_full_supported_fmt(p, fmt);
+    bool special = p.pruned_ok || full_ok || stream_ok || stream2_ok;
     if (d->variant == 3) {                       // measurement: the non-streaming specialised kernel where both exist
-        if (!p.full_ok && !p.pruned_ok) return kLBAudioDetectiveArgumentInvalid;
+        if (!full_ok && !p.pruned_ok) return kLBAudioDetectiveArgumentInvalid;
     }
     if (d->variant == 1) special = false;
     if (d->variant >= 2 && !special) return kLBAudioDetectiveArgumentInvalid;
@@ -149,7 +150,7 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
         if (special && p.pruned_ok)
             return launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         if (special && stream2_ok) return launch_rows_stream2(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
-        if (special && p.full_ok) return launch_rows_full(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
+        if (special && full_ok) return launch_rows_full(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         if (special) return launch_rows_stream(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         return launch_fft_bands(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
     };

@@ -125,6 +125,7 @@ hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const 
 
 // specialised stage 1 without pruning (k_rows_full.hip): 1024- and 2048-sample windows, any band table
 bool rows_full_supported(const Plan& plan);
+bool rows_full_supported_fmt(const Plan& plan, uint32_t fmt);   // strides other than 64: float32 input only
 hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips,
                             uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames, hipStream_t stream);
 

@@ -1,4 +1,4 @@
-// k_rows_full.hip -- specialised stage 1 for 1024- and 2048-sample windows with ANY band table
+// k_rows_full.hip -- specialised stage 1 for 256- to 2048-sample windows with ANY band table and ANY stride
 // (the reference's default 5512 Hz / 2048 among them): windows -> 128 x bands frame rows.
 //
 // Same arithmetic as k_fft_bands.hip / oracle rfft_exec (radix-2 DIT, nested-fma butterflies), laid out
@@ -38,11 +38,16 @@ template <int LOG2L> struct Shape {
     static constexpr int R = 64 / L;                   // rows (k64 values) per lane = transpose passes
     static constexpr int WPW = 64 / L;                 // windows per wave
     static constexpr int UW = kWaves * WPW;            // windows per workgroup
-    static constexpr int kSpan = (UW - 1) * kStride + W;
-    // the L lanes of a window read 2 L consecutive floats; the windows of a 32-lane group must land on
-    // disjoint banks: skew every run of 64 samples by 2 L dwords
+    // Stride 64 (S64): the L lanes of a window read 2 L consecutive floats; the windows of a 32-lane group must land
+    // on disjoint banks: skew every run of 64 samples by 2 L dwords.  Any other stride (run-time value): the span
+    // is stored as it is -- windows that overlap read the SAME addresses (broadcast, no conflict).
     static constexpr int kSkew = 2 * L;
+    static constexpr int kSpan = (UW - 1) * kStride + W;
     static constexpr int kSpanDw = kSpan + kSkew * (kSpan >> 6);
+    static constexpr uint32_t span_len(uint32_t stride) { return (uint32_t)(UW - 1) * stride + (uint32_t)W; }
+    static constexpr uint32_t span_dw(uint32_t stride, bool s64) {
+        return s64 ? (uint32_t)kSpanDw : ((span_len(stride) + 63u) & ~63u);
+    }
     static constexpr int kRowDw = 2 * L + 4;           // transpose row: L values of 8 B, padded by 16 B
     // one pass of one window; the windows a 32-lane group writes together must start 2 L banks apart
     static constexpr int kWinDw = L * kRowDw + (L == 8 ? 16 : 32);
@@ -82,7 +87,7 @@ template <int L> __device__ __forceinline__ constexpr int brevL(int v) {
     return r;
 }
 
-template <int LOG2L, int M>
+template <int LOG2L, bool S64, int M>
 __device__ __forceinline__ void load_points64(cplx (&x)[64], const float* src) {
     using S = Shape<LOG2L>;
     if constexpr (M < 64) {
@@ -90,9 +95,9 @@ __device__ __forceinline__ void load_points64(cplx (&x)[64], const float* src) {
         // the window, i.e. 2 L m floats after the lane base plus the skew of the 64-sample runs crossed
         // (2 r + (2 L m mod 64) < 64, so the lane offset never crosses a run itself)
         constexpr int m = brev6(M);
-        constexpr int off = 2 * S::L * m + S::kSkew * ((2 * S::L * m) >> 6);
+        constexpr int off = 2 * S::L * m + (S64 ? S::kSkew * ((2 * S::L * m) >> 6) : 0);
         x[M] = *(const lds_vf32x2*)(src + off);
-        load_points64<LOG2L, M + 1>(x, src);
+        load_points64<LOG2L, S64, M + 1>(x, src);
     }
 }
 
@@ -114,9 +119,22 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 
 // span of one unit -> LDS, every run of 64 samples followed by kSkew pad dwords.  float32: one
 // global_load_lds_dword per run (no registers, the wave does not wait); int16 / int32 convert in registers.
-template <int LOG2L, int FMT>
-__device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, uint64_t first, float* span, int wave, int lane) {
+template <int LOG2L, int FMT, bool S64>
+__device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, uint64_t first, float* span, int wave, int lane,
+                                            uint32_t stride) {
     using S = Shape<LOG2L>;
+    if constexpr (!S64) {
+        // any stride, float32: runs of 64 samples, unskewed; the last run may be partial (never read past the span:
+        // the clip buffer may end there)
+        static_assert(FMT == 0, "strides other than 64 take float32 input");
+        const uint32_t len = S::span_len(stride);
+        const float* src = static_cast<const float*>(pcm_raw) + first;
+        for (uint32_t run = wave; 64u * run < len; run += kWaves) {
+            if (64u * run + (uint32_t)lane < len)
+                __builtin_amdgcn_global_load_lds((gvoid_t*)(src + 64u * run + lane), (lvoid_t*)(span + 64u * run), 4, 0, 0);
+        }
+        return;
+    }
     constexpr int kPitch = 64 + S::kSkew;
     if constexpr (FMT == 0) {
         const float* src = static_cast<const float*>(pcm_raw) + first + lane + 64 * wave;
@@ -141,8 +159,9 @@ __device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, ui
 // frames, the first ones are static, the rest is claimed a frame at a time from a per-XCD counter; the
 // span of unit u + 1 streams into the span buffer as soon as every wave holds its points of unit u.  The
 // twiddle tables are built once per workgroup.
-template <int LOG2L, int FMT>
-__global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint64_t samples_per_clip,
+template <int LOG2L, int FMT, bool S64>
+__global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint32_t stride_arg,
+                                                                 uint64_t samples_per_clip,
                                                                  uint32_t frames_per_clip, uint64_t n_units,
                                                                  uint64_t units_per_xcd, const float* __restrict__ tw,
                                                                  const uint32_t* __restrict__ band_tbl, uint32_t nbands,
@@ -156,9 +175,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    const uint32_t stride = S64 ? (uint32_t)kStride : stride_arg;
     // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][claim slot][per wave: transpose pass / power terms]
     float* span = smem;
-    float* ctw = smem + S::kSpanDw;
+    float* ctw = smem + S::span_dw(stride, S64);
     // split-pass twiddles in consumption order: entry e = (slot q, pair u, half) of lane r at [e * L + r]
     float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
     uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + 64 * L);
@@ -178,14 +198,14 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         const uint32_t part = (uint32_t)(u % kUnitsPerFrame);
         const uint32_t clip = frame / frames_per_clip;
         const uint32_t fi = frame - clip * frames_per_clip;
-        return (uint64_t)clip * samples_per_clip + (uint64_t)(fi * 128 + part * S::UW) * kStride;
+        return (uint64_t)clip * samples_per_clip + (uint64_t)(fi * 128 + part * S::UW) * stride;
     };
     uint32_t* my_ctr = claim_ctr + (blockIdx.x & 7);
     const bool claimer = threadIdx.x == 0;
     uint32_t claimed = 0;
 
     // ---- once per workgroup: first span, twiddle tables ----------------------------------------------
-    span_to_lds<LOG2L, FMT>(pcm_raw, span_start(unit), span, wave, lane);
+    span_to_lds<LOG2L, FMT, S64>(pcm_raw, span_start(unit), span, wave, lane, stride);
     // cross-lane stage t = 1..log2 L (overall stage s = 6 + t): butterfly jj of row k64 uses
     // W_(2^s)^(k64 + 64 jj) = tw[(k64 + 64 jj) << (LOG2W - s)]
     for (int i = threadIdx.x; i < 64 * (L - 1); i += kThreads) {
@@ -245,14 +265,14 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // ---- B: 64 points of this lane; once every wave has its points the span buffer is free -----------
     cplx x[64];
     {
-        // window w of the workgroup starts at sample 64 w, i.e. at float (64 + kSkew) w
+        // window w of the workgroup starts at sample stride w (stride 64: at float (64 + kSkew) w of the skewed copy)
         const int w = wave * WPW + wl;
-        load_points64<LOG2L, 0>(x, span + (64 + S::kSkew) * w + 2 * r);
+        load_points64<LOG2L, S64, 0>(x, span + (S64 ? (64 + S::kSkew) : (int)stride) * w + 2 * r);
     }
     const uint64_t next = part == kUnitsPerFrame - 1
                               ? xcd_begin + kUnitsPerFrame * ((uint64_t)wg_per_xcd + claim_slot[0]) : unit + 1;
     __syncthreads();
-    if (next < xcd_end) span_to_lds<LOG2L, FMT>(pcm_raw, span_start(next), span, wave, lane);
+    if (next < xcd_end) span_to_lds<LOG2L, FMT, S64>(pcm_raw, span_start(next), span, wave, lane, stride);
     if (part == 0 && claimer) claimed = atomicAdd(my_ctr, 1u);
     __builtin_amdgcn_s_setprio(0);     // arithmetic-heavy phase: let the co-resident wave's LDS work go first
     stage_blocks<1, 0>(x);
@@ -411,21 +431,22 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     }
 }
 
-template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax) {
+template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax, uint32_t stride) {
     using S = Shape<LOG2L>;
     const uint32_t nread = (kmax - kmin + 63u) & ~63u;
     const uint32_t wave_dw = ((uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread) + 64u;
-    return ((size_t)S::kSpanDw + 64 * S::kTwRowDw + 2 * 64 * (size_t)S::L + 4 + (size_t)kWaves * wave_dw) * sizeof(float);
+    return ((size_t)S::span_dw(stride, stride == (uint32_t)kStride) + 64 * S::kTwRowDw + 2 * 64 * (size_t)S::L + 4 +
+            (size_t)kWaves * wave_dw) * sizeof(float);
 }
 
-template <int LOG2L, int FMT>
+template <int LOG2L, int FMT, bool S64>
 hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frames, uint64_t samples_per_clip,
                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     using S = Shape<LOG2L>;
-    const size_t lds = lds_bytes<LOG2L>(plan.table.kmin, plan.table.kmax);
+    const size_t lds = lds_bytes<LOG2L>(plan.table.kmin, plan.table.kmax, plan.stride);
     static PerDevice attr;
     if (attr.changed(lds)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT, S64>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -438,8 +459,8 @@ hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frame
     if (wg_per_xcd > units_per_xcd / U) wg_per_xcd = units_per_xcd / U;
     hipError_t e = hipMemsetAsync(plan.d_claim, 0, 8 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT>), dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), lds, stream,
-                       d_pcm, samples_per_clip, frames_per_clip, n_units, units_per_xcd, plan.d_tw, plan.d_bands,
+    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT, S64>), dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), lds, stream,
+                       d_pcm, plan.stride, samples_per_clip, frames_per_clip, n_units, units_per_xcd, plan.d_tw, plan.d_bands,
                        plan.bands, plan.table.kmin, plan.table.kmax, plan.d_claim, d_frames);
     return hipGetLastError();
 }
@@ -447,10 +468,13 @@ hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frame
 template <int LOG2L>
 hipError_t launch_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_frames, uint64_t samples_per_clip,
                        uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
+    if (plan.stride != (uint32_t)kStride)                  // any other stride: float32 input only (rows_full_supported_fmt)
+        return fmt == 0 ? launch_full_fmt<LOG2L, 0, false>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream)
+                        : hipErrorInvalidValue;
     switch (fmt) {
-        case 0: return launch_full_fmt<LOG2L, 0>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 1: return launch_full_fmt<LOG2L, 1>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 2: return launch_full_fmt<LOG2L, 2>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 0: return launch_full_fmt<LOG2L, 0, true>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 1: return launch_full_fmt<LOG2L, 1, true>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 2: return launch_full_fmt<LOG2L, 2, true>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -460,7 +484,8 @@ hipError_t launch_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64
 // 1024- and 2048-sample windows at the reference's stride; the compile-time W_64 table must be
 // bit-identical to the run-time master table and the LDS budget must allow two workgroups per CU
 bool rows_full_supported(const Plan& p) {
-    if (p.stride != (uint32_t)kStride || p.bands > 64 || p.bands == 0) return false;
+    // even strides: a lane reads its points as aligned sample pairs (ds_read_b64)
+    if (p.stride == 0 || (p.stride & 1u) || p.stride > 1024 || p.bands > 64 || p.bands == 0) return false;
     if (p.window != 256 && p.window != 512 && p.window != 1024 && p.window != 2048) return false;
     if (p.table.kmax <= p.table.kmin) return false;
     std::vector<float> re, im;
@@ -468,12 +493,15 @@ bool rows_full_supported(const Plan& p) {
     const uint32_t step = p.window / 64;
     for (int t = 0; t < 32; ++t)
         if (re[step * t] != kTw64Re[t] || im[step * t] != kTw64Im[t]) return false;
-    const size_t lds = p.window == 256    ? lds_bytes<1>(p.table.kmin, p.table.kmax)
-                       : p.window == 512  ? lds_bytes<2>(p.table.kmin, p.table.kmax)
-                       : p.window == 1024 ? lds_bytes<3>(p.table.kmin, p.table.kmax)
-                                          : lds_bytes<4>(p.table.kmin, p.table.kmax);
+    const size_t lds = p.window == 256    ? lds_bytes<1>(p.table.kmin, p.table.kmax, p.stride)
+                       : p.window == 512  ? lds_bytes<2>(p.table.kmin, p.table.kmax, p.stride)
+                       : p.window == 1024 ? lds_bytes<3>(p.table.kmin, p.table.kmax, p.stride)
+                                          : lds_bytes<4>(p.table.kmin, p.table.kmax, p.stride);
     return lds <= 80 * 1024;
 }
+
+// strides other than 64 take float32 input (integer PCM at those strides runs on the generic kernel)
+bool rows_full_supported_fmt(const Plan& p, uint32_t fmt) { return p.stride == (uint32_t)kStride || fmt == 0; }
 
 hipError_t launch_rows_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_clips, uint64_t samples_per_clip,
                             uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {

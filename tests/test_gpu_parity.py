@@ -65,10 +65,19 @@ CONFIGS = {
     # the Haar pre-scale divides by sqrtf(bands), which therefore comes from the host
     "bands_14": dict(sample_rate=22050, window=256, stride=277, bands=14, subfp_len=180),
     "bands_11": dict(sample_rate=16000, window=512, stride=64, bands=11, subfp_len=64),
+    # strides other than 64 on k_rows_full.hip (round 3): the file hop of 44.1 kHz material at the defaults (8), the
+    # strides the round-2 review named (32, 128), an odd one, and one whose span does not fit the LDS budget (generic)
+    "hop_8_default": dict(stride=8),
+    "stride_32": dict(sample_rate=11025, window=1024, stride=32),
+    "stride_128": dict(sample_rate=22050, window=2048, stride=128, bands=48, subfp_len=256),
+    "stride_6": dict(sample_rate=8000, window=512, stride=6, bands=20, subfp_len=150),
+    "stride_7": dict(sample_rate=8000, window=512, stride=7, bands=20, subfp_len=150),
+    "stride_200_w256": dict(sample_rate=8000, window=256, stride=200),
 }
 # configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, C -> k_rows_stream.hip, A -> k_rows_stream2.hip,
 # the others (stride 64, 256 .. 2048 samples) -> k_rows_full.hip
-SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64", "C_48k_4096", "tiny_bands", "bands_11"}
+SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64", "C_48k_4096", "tiny_bands", "bands_11",
+               "hop_8_default", "stride_32", "stride_128", "stride_6"}
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))

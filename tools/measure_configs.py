@@ -28,6 +28,31 @@ for name, rate, window, samples, n, stereo in [("A_5512_2048", 5512, 2048, 5512 
     del clips, packed
     torch.cuda.empty_cache()
 
+# strides other than 64 (round 3: k_rows_full.hip at any even stride): generic stage-1 kernel against the specialised one,
+# same batch, stage-1 time from the library's own events
+for name, rate, window, stride, seconds, n in [("hop8_5512_2048", 5512, 2048, 8, 9, 2500), ("stride32_11025_1024", 11025, 1024, 32, 4, 20000),
+                                               ("stride128_22050_2048", 22050, 2048, 128, 8, 20000), ("stride16_5512_2048", 5512, 2048, 16, 9, 5000)]:
+    samples = int(rate * seconds)
+    clips = lb.synth_clips_device(0x4C424144, 0, n, rate, samples)
+    row = {"clips": n, "seconds_per_clip": seconds}
+    for label, variant in (("generic", 1), ("specialised", 2)):
+        det = lb.Detective().configure(sample_rate=rate, window=window, stride=stride)
+        det.set_kernel_variant(variant)
+        packed = det.fingerprint_clips_device(clips)
+        torch.cuda.synchronize()
+        det.set_stage_timing(True)
+        for _ in range(3):
+            det.fingerprint_clips_device(clips, out=packed)
+        s1, s2, ln = det.stage_times()
+        row[label + "_stage1_ms"] = round(s1 / ln, 3)
+        row["windows"] = int(n * packed.shape[1] * 128)
+        row[label + "_bits_sum"] = int(packed.to(torch.int64).sum().item())
+    row["speedup"] = round(row["generic_stage1_ms"] / row["specialised_stage1_ms"], 2)
+    row["identical"] = row.pop("generic_bits_sum") == row.pop("specialised_bits_sum")
+    out[name] = row
+    del clips, packed
+    torch.cuda.empty_cache()
+
 # host buffers in, Booleans out (H2D of the PCM and D2H of the packed bits inside the timed region)
 det = lb.Detective().configure(sample_rate=44100, window=1024)
 host = lb.synth_clips_device(0x4C424144, 0, 4000, 44100, 44100).cpu().numpy()
