@@ -330,6 +330,15 @@ def sliding_leg(args, torch, np):
     lat_ms = (time.perf_counter() - t1) * 1e3 / 20
     scores = corpus.scores_device(fq).cpu().numpy()
     alg = 25 * total                                     # 25 B per sub-fingerprint
+    traffic, traffic_src = None, None
+    try:                                                 # HBM bytes from the committed PMC passes, with provenance
+        raw = open(os.path.join(ROOT, "profiles", "traffic.json"), "rb").read()
+        tj = json.loads(raw)
+        traffic = round(tj["sliding_q21"]["hbm_bytes_per_record"] * total)
+        traffic_src = {"file": "profiles/traffic.json", "sha256": hashlib.sha256(raw).hexdigest()[:16], "entry": "sliding_q21",
+                       "round": tj["sliding_q21"].get("round"), "measured_by": "committed rocprofv3 --pmc passes, not this run"}
+    except (OSError, ValueError, KeyError):
+        pass
     out = {
         "workload": f"1 query of {nq} sub-fingerprints vs {n} entries of {lo}..{hi} sub-fingerprints "
                     f"({total} records, {32 * total / 1e9:.2f} GB in HBM), every sliding offset of every entry",
@@ -339,7 +348,7 @@ def sliding_leg(args, torch, np):
         "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel<4> (k_sliding.hip): integer VALU "
                      "(2 v_bitop3 + 1 v_bcnt per 32 sign pairs), not HBM",
                      "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes": alg, "layout_GBps": round(32 * total / (ms * 1e-3) / 1e9, 1)},
     }
     assert api == best, (api, best)

@@ -304,7 +304,7 @@ OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt3
  * whether the shared per-lane twiddle cache is used (default 1).  Results never depend on them. */
 OSStatus LBAudioDetectiveSetKernelTuning(LBAudioDetectiveRef inDetective, UInt32 inWavesPerWorkgroup,
                                          UInt32 inTwiddleCache);
-/* HBM the frame-row buffer between the two kernels may take (default 16 GiB; 16 KiB per frame at 32
+/* HBM the frame-row buffer between the two kernels may take (default 512 MiB; 16 KiB per frame at 32
  * bands).  Batches that need more are processed in several launches. */
 OSStatus LBAudioDetectiveSetScratchLimit(LBAudioDetectiveRef inDetective, UInt64 inBytes);
 /* Measurement aid: once enabled, every batch call records HIP events on its stream around the two
