@@ -296,7 +296,7 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef inDetective,
  *   - register-resident FFT of 256- to 2048-sample windows for any band table at ANY EVEN stride (float32 input when
  *     the stride is not 64; the span of a workgroup's windows must fit the LDS budget) -- among them the hop of 8
  *     samples the file entry points use for 44.1 kHz material at the defaults;
- *   - register Haar / select for 128 x 32 frames.
+ *   - register Haar / select for frames of 16, 32 or 64 bands.
  * 3 = like 2 but the register-resident 2048-point kernel instead of the streaming one (measurement). */
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef inDetective, UInt32 inVariant);
 /* Measurement knobs of the generic stage-1 kernel (the LDS-tile sizing sweep of tools/sweep_lds_tiles.py):

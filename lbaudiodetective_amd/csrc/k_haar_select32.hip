@@ -1,10 +1,12 @@
-// k_haar_select32.hip -- specialised stage 2 for 128 x 32 frames: 2-D Haar + ranked top-K signs.
+// k_haar_select32.hip -- specialised stage 2 for 128 x 32 frames (and, since round 3, 128 x 16 and 128 x 64):
+// 2-D Haar + ranked top-K signs.
 //
 // Same results as k_haar_select.hip (LBAudioDetectiveFrame.m:113-153,165-191 and the truncating
 // copy at LBAudioDetective.m:326-328), restructured for the default frame shape:
 //
-//   * row pass: two threads per row, 16 values each, Haar levels 1..4 in registers, level 5 with
-//     one lane exchange; results go to LDS already transposed (column-major, 16-row chunks);
+//   * row pass: COLS / 16 threads per row (one, two or four), 16 values each, Haar levels 1..4 in registers, the
+//     remaining log2(COLS / 16) levels with lane exchanges; results go to LDS already transposed (column-major,
+//     16-row chunks);
 //   * column pass: eight threads per column, 16 values each, levels 1..4 in registers, levels
 //     5..7 with three lane exchanges; every thread ends up owning 16 final coefficients whose
 //     flat positions are known in closed form, so the select works on registers;
@@ -19,8 +21,6 @@
 namespace lbad {
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kCols = 32;
 constexpr uint32_t kCand = 128;     // candidates ranked exhaustively
 constexpr int kChunkDw = 20;        // 16 floats + 4 pad: conflict-free ds_read_b128 across lanes
 
@@ -61,13 +61,22 @@ __device__ __forceinline__ float div_c(float x, float d, float r) {
     }
 }
 
+template <int WAVES>
+__device__ __forceinline__ uint32_t slots_sum(const uint32_t* slot) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) c += slot[w];
+    return c;
+}
+
+template <int WAVES>
 __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red, int parity) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    uint32_t* slot = s_red + 4 * parity;   // double-buffered: one barrier per reduction
+    uint32_t* slot = s_red + 8 * parity;   // double-buffered: one barrier per reduction
     if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
     __syncthreads();
-    return slot[0] + slot[1] + slot[2] + slot[3];
+    return slots_sum<WAVES>(slot);
 }
 
 // levels 1..4 of a 16-value line held in registers.  On return d[0..7] = level-1 details,
@@ -111,15 +120,21 @@ __device__ __forceinline__ float haar16(const float (&in)[16], float (&d)[15], f
     return s4;
 }
 
-// 72 VGPRs -> seven workgroups per CU, which is also what the 22 KB of LDS allow (90 VGPRs and five
-// workgroups without the bound: 4.33 -> 3.81 ms per 500 k frames)
-__global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
-                                                                 uint32_t subfp_len, uint32_t* __restrict__ packed,
-                                                                 float* __restrict__ haar_out) {
+// 32 columns: 72 VGPRs -> seven workgroups per CU, which is also what the 22 KB of LDS allow (90 VGPRs and five
+// workgroups without the bound: 4.33 -> 3.81 ms per 500 k frames; the second bound is waves per SIMD).
+template <int COLS>
+__global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
+                                                                          uint32_t subfp_len, uint32_t* __restrict__ packed,
+                                                                          float* __restrict__ haar_out) {
+    constexpr int kCols = COLS;
+    constexpr int kThreads = COLS * 8;
+    constexpr int kWavesPerWg = kThreads / 64;
+    constexpr int H = COLS / 16;                     // threads per row in the row pass
+    constexpr uint32_t kIdxBits = COLS == 16 ? 11 : COLS == 32 ? 12 : 13;   // flat index of a coefficient
     __shared__ __attribute__((aligned(16))) float s_t[kCols * 8 * kChunkDw];   // [col][chunk][20]
     __shared__ __attribute__((aligned(16))) unsigned long long s_cand[kCand];
     __shared__ uint32_t s_rank[kCand];
-    __shared__ uint32_t s_red[8];
+    __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_bits[kPackedWords];
 
@@ -140,11 +155,12 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
     if (t < (int)kPackedWords) s_bits[t] = 0;
     if (t < (int)kCand) s_rank[t] = 0;
     if (t == 0) s_ncand = 0;
-    reinterpret_cast<uint32_t*>(s_cand)[t] = 0;   // zero keys pad the list to a multiple of 8 for the ranking loop
+    for (int i = t; i < 2 * (int)kCand; i += kThreads)
+        reinterpret_cast<uint32_t*>(s_cand)[i] = 0;   // zero keys pad the list to a multiple of 8 for the ranking loop
 
-    // ---- row pass: thread = (row, half) ---------------------------------------------------------
+    // ---- row pass: thread = (row, sixteenth h of the row) ------------------------------------------------
     {
-        const int row = t >> 1, h = t & 1;
+        const int row = t / H, h = t % H;
         const float4* src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + row * kCols + 16 * h);
         float a[16], d[15];
 #pragma unroll
@@ -152,21 +168,34 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
             const float4 v = src[q];
             a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         }
-        const float s4 = haar16(a, d, __fsqrt_rn((float)kCols), root2);
-        // level 5 pairs the two halves of the row
-        const float other = __shfl_xor(s4, 1, 64);
-        const float lo = h ? other : s4, hi = h ? s4 : other;
-        const float last = h ? div_root(__fsub_rn(lo, hi), root2) : div_root(__fadd_rn(lo, hi), root2);
+        float cur = haar16(a, d, __fsqrt_rn((float)kCols), root2);       // (16, 32, 64: the device root is exact for these)
+        // the remaining levels pair the H sixteenths of the row; a lane leaves with its detail value as soon as
+        // its index has the level's bit set
+        float fin = 0.0f;
+        bool done = false;
+#pragma unroll
+        for (int m = 1; m < H; m <<= 1) {
+            const float other = __shfl_xor(cur, m, 64);
+            const bool upper = (h & m) != 0;
+            const float lo = upper ? other : cur, hi = upper ? cur : other;
+            const float sm = div_root(__fadd_rn(lo, hi), root2);
+            const float df = div_root(__fsub_rn(lo, hi), root2);
+            if (!done && upper) { fin = df; done = true; }
+            cur = sm;
+        }
+        if (!done) fin = cur;   // sixteenth 0 keeps the row's average
+        // sixteenth -> ordered position of its cross-lane value (H = 4: 0, 2, 1, 3)
+        const int cross = H == 1 ? 0 : (h & 1) ? H / 2 + (h >> 1) : (h & 2) ? H / 4 + (h >> 2) : 0;
         // transposed store: coefficient at ordered position p of this row -> s_t[p][row >> 4][row & 15]
         float* base = s_t + (row >> 4) * kChunkDw + (row & 15);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) base[(16 + 8 * h + i) * (8 * kChunkDw)] = d[i];
+        for (int i = 0; i < 8; ++i) base[(8 * H + 8 * h + i) * (8 * kChunkDw)] = d[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) base[(8 + 4 * h + i) * (8 * kChunkDw)] = d[8 + i];
+        for (int i = 0; i < 4; ++i) base[(4 * H + 4 * h + i) * (8 * kChunkDw)] = d[8 + i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) base[(4 + 2 * h + i) * (8 * kChunkDw)] = d[12 + i];
-        base[(2 + h) * (8 * kChunkDw)] = d[14];
-        base[h * (8 * kChunkDw)] = last;
+        for (int i = 0; i < 2; ++i) base[(2 * H + 2 * h + i) * (8 * kChunkDw)] = d[12 + i];
+        base[(H + h) * (8 * kChunkDw)] = d[14];
+        base[cross * (8 * kChunkDw)] = fin;
     }
     __syncthreads();
     STAMP(1);
@@ -233,10 +262,10 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
 #pragma unroll
         for (int i = 0; i < 16; ++i) c += (uint32_t)__popcll(__ballot(key[i] >= mid));
         {
-            uint32_t* slot = s_red + 4 * parity;
+            uint32_t* slot = s_red + 8 * parity;
             if ((t & 63) == 0) slot[t >> 6] = c;
             __syncthreads();
-            c = slot[0] + slot[1] + slot[2] + slot[3];
+            c = slots_sum<kWavesPerWg>(slot);
         }
         parity ^= 1;
         COUNT_STEP();
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
         uint32_t g = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) g += key[i] > lo ? 1u : 0u;
-        g = block_sum(g, s_red, parity);
+        g = block_sum<kWavesPerWg>(g, s_red, parity);
         parity ^= 1;
         uint32_t ilo = 0, ihi = kRowsPerFrame * kCols;
         while (ilo < ihi) {
@@ -257,14 +286,14 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
             uint32_t c = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) c += (key[i] == lo && pos[i] * kCols + col < im) ? 1u : 0u;
-            c = block_sum(c, s_red, parity);
+            c = block_sum<kWavesPerWg>(c, s_red, parity);
             parity ^= 1;
             if (g + c >= keep) ihi = im; else ilo = im + 1;
         }
         idx_bound = ilo;
     }
 
-    // ---- gather candidates: composite = key << 14 | (4095 - idx) << 2 | sign code -------------------
+    // ---- gather candidates: composite = key << (idx bits + 2) | (max idx - idx) << 2 | sign code ----------
     // one LDS atomic per wave: the slots of a wave's candidates follow from lane-mask popcounts
     {
         bool sel[16];
@@ -285,7 +314,8 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
                 const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 const uint32_t idx = pos[i] * kCols + col;
                 const uint32_t sg = v[i] > 0.0f ? 1u : (v[i] < 0.0f ? 2u : 0u);
-                s_cand[at] = ((unsigned long long)key[i] << 14) | ((unsigned long long)(4095u - idx) << 2) | sg;
+                s_cand[at] = ((unsigned long long)key[i] << (kIdxBits + 2)) |
+                             ((unsigned long long)(((1u << kIdxBits) - 1u) - idx) << 2) | sg;
             }
             base += (uint32_t)__popcll(m);
         }
@@ -294,14 +324,15 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
     STAMP(4);
     const uint32_t nc = s_ncand;
 
-    // ---- rank: 2 threads per candidate, each scans half of the list ----------------------------------
+    // ---- rank: kThreads / 128 threads per candidate, each scans its share of the list --------------------
     {
+        constexpr uint32_t kParts = kThreads / 128;
         const uint32_t i = t & 127, part = t >> 7;
         if (i < nc) {
             const unsigned long long mine = s_cand[i];
-            // blocks of 8 keys (the tail is zero-padded and never counts); each part takes half the blocks
-            const uint32_t nblk = (nc + 7) >> 3, hblk = (nblk + 1) >> 1;
-            const uint32_t b0 = part ? hblk : 0, b1 = part ? nblk : hblk;
+            // blocks of 8 keys (the tail is zero-padded and never counts); each part takes its share of the blocks
+            const uint32_t nblk = (nc + 7) >> 3, pblk = (nblk + kParts - 1) / kParts;
+            const uint32_t b0 = part * pblk < nblk ? part * pblk : nblk, b1 = b0 + pblk < nblk ? b0 + pblk : nblk;
             uint32_t r = 0;
             for (uint32_t b = b0; b < b1; ++b) {
                 const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_cand + 8 * b);
@@ -337,14 +368,23 @@ __global__ __launch_bounds__(kThreads, 7) void haar_select32_kernel(const float*
 
 }  // namespace
 
-bool haar_select32_supported(const Plan& p) { return p.bands == (uint32_t)kCols && p.keep <= kCand && p.keep >= 1; }
+bool haar_select32_supported(const Plan& p) {
+    return (p.bands == 16 || p.bands == 32 || p.bands == 64) && p.keep <= kCand && p.keep >= 1;
+}
 
 hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_t n_frames, uint32_t* d_packed,
                                 float* d_haar_out, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(haar_select32_kernel, dim3((uint32_t)n_frames), dim3(kThreads), 0, stream, d_frames, plan.keep,
-                       plan.subfp_len, d_packed, d_haar_out);
+    if (plan.bands == 16)
+        hipLaunchKernelGGL(haar_select32_kernel<16>, dim3((uint32_t)n_frames), dim3(128), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out);
+    else if (plan.bands == 64)
+        hipLaunchKernelGGL(haar_select32_kernel<64>, dim3((uint32_t)n_frames), dim3(512), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out);
+    else
+        hipLaunchKernelGGL(haar_select32_kernel<32>, dim3((uint32_t)n_frames), dim3(256), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out);
     return hipGetLastError();
 }
 

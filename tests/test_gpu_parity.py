@@ -67,6 +67,9 @@ CONFIGS = {
     "bands_11": dict(sample_rate=16000, window=512, stride=64, bands=11, subfp_len=64),
     # strides other than 64 on k_rows_full.hip (round 3): the file hop of 44.1 kHz material at the defaults (8), the
     # strides the round-2 review named (32, 128), an odd one, and one whose span does not fit the LDS budget (generic)
+    # 16 and 64 bands on the register Haar / select kernel (round 3); 64 bands with the widest kept length
+    "bands_16": dict(sample_rate=16000, window=1024, stride=64, bands=16, subfp_len=200),
+    "bands_64_256": dict(sample_rate=22050, window=2048, stride=64, bands=64, subfp_len=256),
     "hop_8_default": dict(stride=8),
     "stride_32": dict(sample_rate=11025, window=1024, stride=32),
     "stride_128": dict(sample_rate=22050, window=2048, stride=128, bands=48, subfp_len=256),
@@ -77,7 +80,7 @@ CONFIGS = {
 # configurations with a specialised stage-1 kernel: B -> k_rows_pruned.hip, C -> k_rows_stream.hip, A -> k_rows_stream2.hip,
 # the others (stride 64, 256 .. 2048 samples) -> k_rows_full.hip
 SPECIALISED = {"B_44k_1024", "A_default", "D_22k_1024", "E_11k_2048_64", "C_48k_4096", "tiny_bands", "bands_11",
-               "hop_8_default", "stride_32", "stride_128", "stride_6"}
+               "hop_8_default", "stride_32", "stride_128", "stride_6", "bands_16", "bands_64_256"}
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
@@ -826,8 +829,8 @@ def test_random_compare_shapes(lb, gpu, oracle):
 # ---------------------------------------------------------------------------------------------
 # stage 2 alone, on frames built to hit the corners of the Haar / select arithmetic
 # ---------------------------------------------------------------------------------------------
-def _frames_cases(rng):
-    base = np.abs(rng.standard_normal((128, 32)).astype(np.float32)) * 100
+def _frames_cases(rng, cols=32):
+    base = np.abs(rng.standard_normal((128, cols)).astype(np.float32)) * 100
     cases = {"typical": base.copy()}
     for name, scale in [("near_fast_division_limit", 2.0 ** -98), ("below_limit", 2.0 ** -104), ("denormal", 2.0 ** -130),
                         ("near_overflow", 2.0 ** 120)]:
@@ -839,31 +842,34 @@ def _frames_cases(rng):
     cases["mixed_magnitudes"] = mixed
     inf = base.copy(); inf[10, 3] = np.inf
     cases["one_inf"] = inf
-    sparse = np.zeros((128, 32), np.float32); sparse[:, 13] = base[:, 13]; sparse[:, 16] = base[:, 16]
+    sparse = np.zeros((128, cols), np.float32); sparse[:, 13] = base[:, 13]; sparse[:, cols // 2] = base[:, cols // 2]
     cases["mostly_empty_bands"] = sparse                   # what 44.1 kHz / 1024 produces (17 empty bands)
-    cases["cancellation"] = np.tile(np.array([1.0, -1.0], np.float32), (128, 16)) * np.float32(3.0)
-    cases["all_equal"] = np.full((128, 32), np.float32(7.5))
-    cases["zeros"] = np.zeros((128, 32), np.float32)
+    cases["cancellation"] = np.tile(np.array([1.0, -1.0], np.float32), (128, cols // 2)) * np.float32(3.0)
+    cases["all_equal"] = np.full((128, cols), np.float32(7.5))
+    cases["zeros"] = np.zeros((128, cols), np.float32)
     neg = -base; cases["negative"] = neg.astype(np.float32)
     return cases
 
 
+@pytest.mark.parametrize("bands,keep_len", [(32, 200), (16, 200), (64, 256), (64, 31), (16, 7)])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_stage2_corner_frames(lb, gpu, oracle, variant):
-    cases = _frames_cases(np.random.default_rng(3))
+def test_stage2_corner_frames(lb, gpu, oracle, variant, bands, keep_len):
+    """Stage 2 alone on frames that stress the division shortcut, the threshold search and the tie rule (plateaus of equal
+    keys, digital silence), for the three frame widths of the register kernel (16, 32, 64 bands) and the generic one."""
+    cases = _frames_cases(np.random.default_rng(3), bands)
     frames = np.stack(list(cases.values()))
-    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    det = lb.Detective().configure(sample_rate=44100, window=1024, bands=bands, subfp_len=keep_len)
     det.set_kernel_variant(variant)
     packed, haar = lb.frames_to_subfingerprints_device(det, gpu.from_numpy(frames).cuda(), want_haar=True)
     gpu.cuda.synchronize()
-    got_bits = lb.unpack_packed(packed.cpu().numpy(), 200)
+    got_bits = lb.unpack_packed(packed.cpu().numpy(), keep_len)
     got_haar = haar.cpu().numpy()
     for i, name in enumerate(cases):
         want_haar = oracle.haar_2d(frames[i])
         with np.errstate(invalid="ignore"):
-            assert np.array_equal(got_haar[i], want_haar, equal_nan=True), f"{name}: Haar differs (variant {variant})"
+            assert np.array_equal(got_haar[i], want_haar, equal_nan=True), f"{name}: Haar differs (variant {variant}, {bands} bands)"
         if not np.isnan(want_haar).any():                   # NaN payloads/signs are not comparable across CPU and GPU
-            assert np.array_equal(got_bits[i], oracle.extract(want_haar, 200)[:200]), f"{name}: bits differ"
+            assert np.array_equal(got_bits[i], oracle.extract(want_haar, keep_len)[:keep_len]), f"{name}: bits differ ({bands} bands)"
 
 
 def test_corpus_batch_queries(lb, gpu, oracle):

@@ -44,10 +44,33 @@ for name, rate, window, stride, seconds, n in [("hop8_5512_2048", 5512, 2048, 8,
         for _ in range(3):
             det.fingerprint_clips_device(clips, out=packed)
         s1, s2, ln = det.stage_times()
-        row[label + "_stage1_ms"] = round(s1 / ln, 3)
+        row[label + "_stage1_ms"] = round(s1 / 3, 3)            # per pass (three passes timed; a pass may be several chunks)
         row["windows"] = int(n * packed.shape[1] * 128)
         row[label + "_bits_sum"] = int(packed.to(torch.int64).sum().item())
     row["speedup"] = round(row["generic_stage1_ms"] / row["specialised_stage1_ms"], 2)
+    row["identical"] = row.pop("generic_bits_sum") == row.pop("specialised_bits_sum")
+    out[name] = row
+    del clips, packed
+    torch.cuda.empty_cache()
+
+# band counts other than 32 on the register Haar / select kernel (round 3): stage-2 time, generic against specialised
+for name, rate, window, bands, subfp, n in [("bands16_16000_1024", 16000, 1024, 16, 200, 100000), ("bands64_22050_2048", 22050, 2048, 64, 256, 50000),
+                                            ("bands32_44100_1024", 44100, 1024, 32, 200, 100000)]:
+    samples = window + 64 * 128 * 5
+    clips = lb.synth_clips_device(0x4C424144, 0, n, rate, samples)
+    row = {"clips": n, "frames": n * 5}
+    for label, variant in (("generic", 1), ("specialised", 0)):
+        det = lb.Detective().configure(sample_rate=rate, window=window, bands=bands, subfp_len=subfp)
+        det.set_kernel_variant(variant)
+        packed = det.fingerprint_clips_device(clips)
+        torch.cuda.synchronize()
+        det.set_stage_timing(True)
+        for _ in range(3):
+            det.fingerprint_clips_device(clips, out=packed)
+        s1, s2, ln = det.stage_times()
+        row[label + "_stage2_ms"] = round(s2 / 3, 3)
+        row[label + "_bits_sum"] = int(packed.to(torch.int64).sum().item())
+    row["speedup"] = round(row["generic_stage2_ms"] / row["specialised_stage2_ms"], 2)
     row["identical"] = row.pop("generic_bits_sum") == row.pop("specialised_bits_sum")
     out[name] = row
     del clips, packed
