@@ -352,6 +352,22 @@ def sliding_leg(args, torch, np):
                      "algorithmic_bytes": alg, "layout_GBps": round(32 * total / (ms * 1e-3) / 1e9, 1)},
     }
     assert api == best, (api, best)
+    # the same corpus against queries of other lengths (scan only): short queries are HBM-bound, a long one meets
+    # entries shorter and longer than itself in the same chunk
+    others = {}
+    for n_other in (5, 48):
+        qo = lb.Fingerprint.from_bools(O.synth_entry(CSEED, PLANTED_1GPU, max(int(counts[PLANTED_1GPU]), n_other), 200)[:n_other])
+        for _ in range(2):
+            corpus.query_key_device(qo, key)
+        e0.record()
+        for _ in range(20):
+            corpus.query_key_device(qo, key)
+        e1.record()
+        torch.cuda.synchronize()
+        mo = e0.elapsed_time(e1) / 20
+        others[f"query_of_{n_other}"] = {"scan_ms": round(mo, 4), "algorithmic_GBps": round(alg / (mo * 1e-3) / 1e9, 1),
+                                         "layout_GBps": round(32 * total / (mo * 1e-3) / 1e9, 1)}
+    out["other_query_lengths"] = others
     if not args.no_cpu_baseline:
         # the oracle's Boolean-per-byte loop (the reference's layout) on a bounded sample of the same corpus;
         # also the parity check of the scores the GPU produced for those entries

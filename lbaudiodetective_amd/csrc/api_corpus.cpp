@@ -43,7 +43,7 @@ OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFinge
 }
 
 // stage the query on the device and launch the scan; key_dst is a device pointer
-OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
+OSStatus run_query_impl(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
                    uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
     if (!c || !q || !key_dst) return kLBAudioDetectiveArgumentInvalid;
     if (q->length != c->subfp_len || q->count == 0) return kLBAudioDetectiveArgumentInvalid;
@@ -83,8 +83,16 @@ OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint*
     return noErr;
 }
 
+// (host allocations -- the packed query, its constant block -- can fail: nothing may unwind through the C boundary)
+OSStatus run_query(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range, uint64_t index_base,
+                   float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
+    LBAD_GUARD_BEGIN
+    return run_query_impl(c, q, range, index_base, d_scores, key_dst, stream);
+    LBAD_GUARD_END
+}
+
 // LBAudioDetectiveCorpusQuery on the specialised scan: one launch, the result arrives in pinned memory
-OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range, unsigned long long* key) {
+OSStatus query_fast_impl(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range, unsigned long long* key) {
     if (!c->h_out) {
         // built in locals and committed only when everything exists: a failure leaves the corpus as it was
         unsigned long long *d_fast = nullptr, *h_out = nullptr, *h_out_dev = nullptr;
@@ -137,6 +145,12 @@ OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint
     return noErr;
 }
 
+OSStatus query_fast(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range, unsigned long long* key) {
+    LBAD_GUARD_BEGIN
+    return query_fast_impl(c, q, range, key);
+    LBAD_GUARD_END
+}
+
 }  // namespace
 }  // namespace lbad
 
@@ -181,7 +195,12 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprin
     c->subfp_len = inSubfingerprintLength;
     c->capacity = inEntryCapacity;
     c->rec_capacity = inSubfingerprintCapacity;
-    c->h_off.assign(1, 0u);
+    try {
+        c->h_off.assign(1, 0u);
+    } catch (const std::bad_alloc&) {
+        delete c;
+        return NULL;
+    }
     if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_recs), (size_t)inSubfingerprintCapacity * 32), "hipMalloc corpus", __LINE__) != noErr ||
         lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_off), (size_t)(inEntryCapacity + 1) * 4), "hipMalloc offsets", __LINE__) != noErr ||
         lbad::hip_status(hipMemset(c->d_off, 0, 4), "offsets", __LINE__) != noErr ||
@@ -278,6 +297,7 @@ OSStatus LBAudioDetectiveCorpusAppendPackedDevice(LBAudioDetectiveCorpusRef c, c
 }
 
 OSStatus LBAudioDetectiveCorpusAppendFingerprint(LBAudioDetectiveCorpusRef c, LBAudioDetectiveFingerprintRef fp) {
+    LBAD_GUARD_BEGIN
     if (!c || !fp || fp->length != c->subfp_len) return kLBAudioDetectiveArgumentInvalid;
     if (c->ragged ? fp->count == 0 : fp->count != c->n_sub) return kLBAudioDetectiveArgumentInvalid;
     std::vector<uint32_t> slots;
@@ -291,6 +311,7 @@ OSStatus LBAudioDetectiveCorpusAppendFingerprint(LBAudioDetectiveCorpusRef c, LB
     if (st == noErr) st = lbad::hip_status(hipStreamSynchronize(nullptr), "sync", __LINE__);
     (void)hipFree(d);
     return st;
+    LBAD_GUARD_END
 }
 
 void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* outScore) {
@@ -319,6 +340,7 @@ OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef c, LBAudio
 OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef c, const LBAudioDetectiveFingerprintRef* inQueries,
                                                     UInt32 inCount, UInt32 inRange, UInt64 inIndexBase, void* outKeys,
                                                     void* inStream) {
+    LBAD_GUARD_BEGIN
     if (!c || !inQueries || !outKeys || inCount == 0) return kLBAudioDetectiveArgumentInvalid;
     if (inIndexBase + c->count > 0x100000000ull) return kLBAudioDetectiveArgumentInvalid;
     hipStream_t stream = static_cast<hipStream_t>(inStream);
@@ -360,15 +382,17 @@ OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef c,
     LBAD_HIP(lbad::launch_compare_planes_batch(c->d_planes, c->capacity, c->count, c->n_sub, c->d_query, inCount,
                                                inIndexBase, keys, stream));
     return noErr;
+    LBAD_GUARD_END
 }
 
 OSStatus LBAudioDetectiveCorpusQueryBatch(LBAudioDetectiveCorpusRef c, const LBAudioDetectiveFingerprintRef* inQueries,
                                           UInt32 inCount, UInt32 inRange, SInt64* outIndices, Float32* outScores) {
+    LBAD_GUARD_BEGIN
     if (!c || inCount == 0) return kLBAudioDetectiveArgumentInvalid;
+    std::vector<unsigned long long> keys(inCount);
     unsigned long long* d_keys = nullptr;
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&d_keys), (size_t)inCount * sizeof(unsigned long long)));
     OSStatus st = LBAudioDetectiveCorpusQueryBatchKeysDevice(c, inQueries, inCount, inRange, 0, d_keys, NULL);
-    std::vector<unsigned long long> keys(inCount);
     if (st == noErr)
         st = lbad::hip_status(hipMemcpy(keys.data(), d_keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost),
                               "copy keys", __LINE__);
@@ -377,6 +401,7 @@ OSStatus LBAudioDetectiveCorpusQueryBatch(LBAudioDetectiveCorpusRef c, const LBA
     for (UInt32 i = 0; i < inCount; ++i)
         LBAudioDetectiveCorpusDecodeKey(keys[i], outIndices ? outIndices + i : NULL, outScores ? outScores + i : NULL);
     return noErr;
+    LBAD_GUARD_END
 }
 
 // ---- corpus file: header + the planes of the stored entries, plane-major ----------------------------
@@ -488,7 +513,13 @@ OSStatus LBAudioDetectiveCorpusSave(LBAudioDetectiveCorpusRef c, const char* inP
     std::memcpy(h.magic, "LBADCRP1", 8);
     h.subfp_len = c->subfp_len; h.n_sub = c->n_sub; h.n_planes = c->n_planes; h.reserved = 0; h.count = c->count;
     OSStatus st = std::fwrite(&h, sizeof(h), 1, f) == 1 ? noErr : kLBAudioDetectiveDeviceError;
-    std::vector<uint4> host(c->count);
+    std::vector<uint4> host;
+    try {
+        host.resize(c->count);
+    } catch (const std::bad_alloc&) {
+        std::fclose(f);
+        return kLBAudioDetectiveMemFull;
+    }
     for (uint32_t p = 0; p < c->n_planes && st == noErr && c->count; ++p) {
         st = lbad::hip_status(hipMemcpy(host.data(), c->d_planes + (size_t)p * c->capacity, c->count * sizeof(uint4),
                                         hipMemcpyDeviceToHost), "corpus plane D2H", __LINE__);
