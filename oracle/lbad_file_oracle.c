@@ -170,9 +170,18 @@ static int ima_magnitude(int step, int code3) {
     return m;
 }
 
+/* How a packet starts: 0 (the model of this oracle and of the product) from its header; 1 (probe only,
+ * tools/ima4_gap_probe.py) like decoders that carry the running predictor across packets whenever the header --
+ * which stores only the predictor's top 9 bits -- agrees with it to within its quantisation step and the step index is
+ * unchanged.  Which of the two Apple's decoder does cannot be observed here; the probe bounds what it could change. */
+static int g_ima4_carry = 0;
+void lbo_file_set_ima4_carry(int on) { g_ima4_carry = on; }
+
 /* frames = packets * 64 mono floats (channels averaged) */
 static void ima4_frames(const uint8_t* bytes, uint64_t packets, uint32_t channels, float* frames) {
     static const int8_t index_move[8] = {-1, -1, -1, -1, 2, 4, 6, 8};
+    int run_sample[64], run_idx[64];
+    for (int c = 0; c < 64; ++c) { run_sample[c] = 0; run_idx[c] = -1; }
     for (uint64_t pk = 0; pk < packets; ++pk) {
         float* dst = frames + pk * 64;
         for (uint32_t ch = 0; ch < channels; ++ch) {
@@ -182,6 +191,8 @@ static void ima4_frames(const uint8_t* bytes, uint64_t packets, uint32_t channel
             if (sample >= 32768) sample -= 65536;     /* two's complement 16-bit */
             int idx = (int)(head & 0x7Fu);
             if (idx > 88) idx = 88;
+            if (g_ima4_carry && ch < 64 && run_idx[ch] == idx && run_sample[ch] - sample > -128 && run_sample[ch] - sample < 128)
+                sample = run_sample[ch];
             for (int k = 0; k < 64; ++k) {
                 const unsigned byte = p[2 + k / 2];
                 const unsigned code = (k % 2 == 0) ? (byte & 15u) : (byte >> 4);
@@ -195,6 +206,7 @@ static void ima4_frames(const uint8_t* bytes, uint64_t packets, uint32_t channel
                 const float v = (float)sample / 32768.0f;
                 dst[k] = ch == 0 ? v : dst[k] + v;    /* float sum in channel order */
             }
+            if (ch < 64) { run_sample[ch] = sample; run_idx[ch] = idx; }
         }
         if (channels > 1)
             for (int k = 0; k < 64; ++k) dst[k] = dst[k] / (float)channels;

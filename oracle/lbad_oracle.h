@@ -160,6 +160,9 @@ uint32_t lbo_synth_ragged_count(uint32_t seed, uint64_t entry, uint32_t lo, uint
 int lbo_file_decode(const char* path, float** out_mono, uint64_t* out_frames, double* out_rate);
 int lbo_file_decode_bytes(const uint8_t* file, uint64_t n_bytes, float** out_mono, uint64_t* out_frames, double* out_rate);
 void lbo_file_free(float* p);
+/* probe only (tools/ima4_gap_probe.py): 1 = carry the running IMA4 predictor across packets when the packet header
+ * agrees with it; 0 (default, the model everything is tested against) = every packet restarts from its header */
+void lbo_file_set_ima4_carry(int on);
 /* Converter models 0 (Kaiser sinc, 24 zero crossings, beta 9, cut-off 0.92), 1 (4 zero crossings, beta 3, cut-off
  * 1.0), 2 (linear interpolation); out holds lbo_resample_count() samples. */
 uint64_t lbo_resample_count(uint64_t n_in, double rate_in, double rate_out);

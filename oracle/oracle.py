@@ -88,6 +88,7 @@ def lib():
     sig("lbo_file_decode_bytes", C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_double)])
     sig("lbo_file_free", None, [C.POINTER(C.c_float)])
+    sig("lbo_file_set_ima4_carry", None, [C.c_int])
     sig("lbo_resample_count", C.c_uint64, [C.c_uint64, C.c_double, C.c_double])
     sig("lbo_resample", C.c_int, [f32p, C.c_uint64, C.c_double, C.c_double, C.c_int, f32p])
     sig("lbo_fingerprint_file", C.c_int, [C.c_char_p, cfgp, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
