@@ -190,6 +190,36 @@ def test_compare_invariants(oracle):
     assert oracle.compare_fp(a[:0], a, 200, subfp_len=200) == 0.0   # empty side: NaN never wins Foundation's MAX
 
 
+def test_ragged_best_match_against_python(oracle):
+    """lbo_corpus_best_ragged (entries of different lengths, the shape of LBAudioDetectiveTests.m:57-91) against the
+    pure-Python restatement of Fp.m:119-176 entry by entry; strict '<' from 0.0 (T.m:60,80): the lowest index wins
+    ties, nothing is selected when every entry scores 0.  And the synthetic ragged corpus's vectorised counts."""
+    rng = np.random.default_rng(17)
+    def fp(n):
+        f = np.zeros((n, 200), np.uint8)
+        pos = rng.random((n, 100)) < 0.5
+        zero = rng.random((n, 100)) < 0.05
+        f[:, 0::2] = pos & ~zero
+        f[:, 1::2] = ~pos & ~zero
+        return f
+    entries = [fp(int(n)) for n in rng.integers(1, 12, 40)]
+    entries[7] = entries[3].copy()                                   # a tie between entries 3 and 7
+    for nq, rg in ((1, 200), (4, 200), (6, 31), (11, 200), (15, 7)):
+        q = fp(nq)
+        k = min(nq, entries[3].shape[0])
+        q[:k] = entries[3][:k]
+        bi, bs, scores = oracle.corpus_best_ragged(q, entries, rg, want_scores=True)
+        want = np.array([_compare_fp_py(q, e, rg) for e in entries], np.float32)
+        assert np.array_equal(scores.view(np.uint32), want.view(np.uint32)), (nq, rg)
+        assert bi == int(np.argmax(want)) and np.float32(bs) == want.max() and bi != 7
+    assert oracle.corpus_best_ragged(np.zeros((2, 200), np.uint8), entries, 200) == (-1, 0.0)
+    counts = oracle.synth_ragged_counts(0x4C424145, 123_456, 5000, 20, 70)
+    assert counts.min() >= 20 and counts.max() <= 70 and len(set(counts.tolist())) == 51
+    assert all(int(counts[i]) == oracle.lib().lbo_synth_ragged_count(0x4C424145, 123_456 + i, 20, 70) for i in range(0, 5000, 97))
+    ent = oracle.synth_ragged_entries(0x4C424145, 9, counts[:3], 200)
+    assert np.array_equal(ent[:int(counts[0])], oracle.synth_entry(0x4C424145, 9, int(counts[0]), 200))
+
+
 def test_framing_counts(oracle):
     # SURVEY section 8: 1 s at 44.1 kHz / 1024 -> 673 windows -> 5 frames; 48 kHz / 4096 -> 686 -> 5
     assert oracle.subfingerprint_count(44100, 1024, 64) == 5
