@@ -1019,12 +1019,13 @@ def test_polled_query_sees_appends_from_other_streams(lb, gpu, oracle):
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("tool,trials", [("fuzz_parity.py", 250), ("fuzz_compare.py", 120), ("fuzz_frame.py", 400),
-                                         ("fuzz_stream.py", 120), ("fuzz_files.py", 200)])
+                                         ("fuzz_stream.py", 120), ("fuzz_files.py", 300), ("fuzz_ragged.py", 400)])
 def test_randomized_sweeps(tool, trials):
     """Each sweep compares the device path with the oracle on inputs nobody picked by hand and exits non-zero on the
     first kind of mismatch: fingerprint configurations and shapes (all stage-1 / stage-2 kernels, the file loop), the
     compare leg, the Frame API, streaming and host batches, files of every payload format through the device decoder
-    and converter."""
+    and converter (against the oracle's own file front end), ragged corpora (every mode of the sliding scan, save / load,
+    the sharded entry point)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
