@@ -732,7 +732,18 @@ def run_rank(args) -> int:
             # the exchange step runs INSIDE the library: its own RCCL communicator (ncclCommInitRank through
             # LBAudioDetectiveCommInitRank; torch.distributed only carries the 128-byte id) and
             # LBAudioDetectiveCorpusQuerySharded = scan + ncclAllReduce(ncclUint64, ncclMax) + 8-byte read-back
-            comm = quiet_stdout(lambda: sharded.make_comm(rank, world))   # RCCL prints a version banner on stdout
+            comm, comm_note = None, None
+            try:
+                comm = quiet_stdout(lambda: sharded.make_comm(rank, world))   # RCCL prints a version banner on stdout
+            except Exception as e:                          # noqa: BLE001 -- keep the scaling run alive, say what happened
+                comm_note = f"LBAudioDetectiveCommInitRank failed ({e}); keys reduced through torch.distributed instead"
+                sys.stderr.write("bench.py: " + comm_note + "\n")
+            if world > 1:                                   # all ranks on the same path, or none
+                ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and comm is not None:
+                    comm.dispose()
+                    comm, comm_note = None, "another rank could not create the library's communicator; torch.distributed instead"
             sc = lb.ShardedCorpus(200, per, total, rank=rank, world_size=world, comm=comm)
             chunk = 1 << 20
             for b in range(sc.begin, sc.end, chunk):
@@ -795,9 +806,10 @@ def run_rank(args) -> int:
                     "scan_ms": round(scan_ms, 4), "allreduce_ms": (round(ar_max, 4) if world > 1 else None),
                     "query_latency_ms": round(api_lat_ms if api_lat_ms is not None else lat_ms, 4),
                     "query_latency_sharded_path_ms": round(lat_ms, 4),
-                    "collective": "ncclAllReduce(count 1, ncclUint64, ncclMax) inside LBAudioDetectiveCorpusQuerySharded, "
-                                  f"communicator of {world} rank(s) from ncclCommInitRank; allreduce_ms is the same 8 bytes "
-                                  "through torch.distributed, for reference",
+                    "collective": (comm_note if comm is None else
+                                   "ncclAllReduce(count 1, ncclUint64, ncclMax) inside LBAudioDetectiveCorpusQuerySharded, "
+                                   f"communicator of {world} rank(s) from ncclCommInitRank; allreduce_ms is the same 8 bytes "
+                                   "through torch.distributed, for reference"),
                     "entries_per_s": round(total / ((api_lat_ms if api_lat_ms is not None else lat_ms) * 1e-3), 1),
                     "scan_entries_per_s": round(total / (scan_ms * 1e-3), 1),
                     "achieved_GBps_algorithmic_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9, 2),
