@@ -427,8 +427,9 @@ OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef in
 /* Per-entry scores (debug / parity): device pointer to count float32. */
 OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                             UInt32 inRange, Float32* outScores, void* inStream);
-/* Binary corpus file ("LBADCRP1" header + the stored entries' planes); Load reserves
- * max(inCapacity, stored count) entries. */
+/* Binary corpus file ("LBADCRP1" header + the stored entries' planes; a ragged corpus: "LBADCRP2" header + the
+ * entries' sub-fingerprint counts + the records); Load recognises both, reserves max(inCapacity, stored count)
+ * entries and, for a ragged corpus, records in proportion. */
 OSStatus LBAudioDetectiveCorpusSave(LBAudioDetectiveCorpusRef inCorpus, const char* inPath);
 LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 inCapacity);
 /* Kernel selection: 0 = automatic, 1 = generic kernel, 2 = specialised plane kernel. */
