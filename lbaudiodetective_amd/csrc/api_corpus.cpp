@@ -24,21 +24,36 @@ OSStatus reserve_query(LBAudioDetectiveCorpus* c, size_t words) {
     return noErr;
 }
 
-// ragged corpus: the sliding scan of k_sliding.hip (any query length, any entry lengths)
+// ragged corpus: the sliding scan of k_sliding.hip (any query length, any entry lengths).  The query block travels
+// through a ring of kQuerySlots pinned + device slots, one event per slot: a call waits only for the copy that used
+// its slot kQuerySlots queries ago (long done), not for the stream -- back-to-back queries leave no gap on the GPU.
+constexpr uint32_t kQuerySlots = 8;
+
 OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
                           uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
     std::vector<uint32_t> block;
     build_sliding_query(q->data.data(), q->count, c->subfp_len, range, block);
-    OSStatus st = reserve_query(c, block.size());
-    if (st != noErr) return st;
-    LBAD_HIP(hipStreamSynchronize(stream));   // the pinned staging block is reused by every query
-    std::memcpy(c->h_query, block.data(), block.size() * sizeof(uint32_t));
-    LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, block.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    const size_t slot_words = (block.size() + 63) & ~(size_t)63;
+    if (c->query_slot_words < slot_words) {               // (re)size the ring: everything that used it must be done
+        for (hipEvent_t e : c->query_ev)
+            if (e) LBAD_HIP(hipEventSynchronize(e));
+        c->query_slot_words = 0;
+        OSStatus st = reserve_query(c, slot_words * kQuerySlots);
+        if (st != noErr) return st;
+        c->query_slot_words = slot_words;
+    }
+    const uint32_t slot = (uint32_t)(c->query_seq++ % kQuerySlots);
+    if (!c->query_ev[slot]) LBAD_HIP(hipEventCreateWithFlags(&c->query_ev[slot], hipEventDisableTiming));
+    else LBAD_HIP(hipEventSynchronize(c->query_ev[slot]));
+    uint32_t* h = c->h_query + (size_t)slot * c->query_slot_words;
+    uint32_t* dq = c->d_query + (size_t)slot * c->query_slot_words;
+    std::memcpy(h, block.data(), block.size() * sizeof(uint32_t));
+    LBAD_HIP(hipMemcpyAsync(dq, h, block.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    LBAD_HIP(hipEventRecord(c->query_ev[slot], stream));
     LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
     if (d_scores) LBAD_HIP(hipMemsetAsync(d_scores, 0, c->count * sizeof(float), stream));
-    LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, c->subfp_len, c->d_query,
-                                    q->count, range, index_base, reinterpret_cast<unsigned int*>(d_scores), key_dst,
-                                    stream));
+    LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, c->subfp_len, dq, q->count, range,
+                                    index_base, reinterpret_cast<unsigned int*>(d_scores), key_dst, stream));
     return noErr;
 }
 
@@ -256,6 +271,8 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_planes) (void)hipFree(c->d_planes);
+    for (hipEvent_t e : c->query_ev)
+        if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
     if (c->d_query) (void)hipFree(c->d_query);
     if (c->h_query) (void)hipHostFree(c->h_query);
     if (c->d_key) (void)hipFree(c->d_key);

@@ -339,4 +339,8 @@ struct LBAudioDetectiveCorpus {
     uint32_t* d_off = nullptr;                   // capacity + 1 record positions (entry e = [off[e], off[e + 1]))
     std::vector<uint32_t> h_off;                 // count + 1
     uint32_t ne_max = 0;                         // longest entry
+    // ring of query slots in h_query / d_query (ragged scan): slot size in words, one event per slot, queries so far
+    size_t query_slot_words = 0;
+    hipEvent_t query_ev[8] = {};
+    uint64_t query_seq = 0;
 };
