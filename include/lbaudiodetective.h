@@ -14,12 +14,15 @@
  * device-resident reference-fingerprint corpus with a top-1 query that returns a key a
  * host can all-reduce (max) across GPUs.
  *
- * Threading: like upstream, nothing here is re-entrant per object -- one call at a time per detective,
- * fingerprint, frame, stream or corpus; distinct objects are independent.  One process drives one GPU
- * (the current HIP device at the time of the call).  A detective also serves ONE HIP STREAM at a time: the
- * frame-row buffer between its two kernels, the kernels' claim counters, its conversion buffers and its timing
- * events belong to it, so two batch calls in flight on different streams of the same detective would share them.
- * Use one detective per stream or thread (they are cheap: a plan of a few tables).
+ * Threading: fingerprints, frames, streams and corpora are, like upstream's objects, not re-entrant -- one call at a
+ * time per object; distinct objects are independent.  One process drives one GPU (the current HIP device at the time
+ * of the call).  A DETECTIVE may be called from several threads and on several HIP streams (round 3): the frame-row
+ * buffer between its two kernels, the kernels' claim counters, its conversion buffers and its timing events exist
+ * once per detective, so the library serialises such calls -- a mutex around the host side of every entry point, and a
+ * batch call that arrives on another stream than its predecessor first waits on the device (hipStreamWaitEvent) for
+ * the predecessor's last kernel.  Results are correct; the calls do not overlap.  For overlap use one detective per
+ * stream (they are cheap: a plan of a few tables).  Exception: while a stream is being captured into a hipGraph
+ * nothing is recorded or awaited -- ordering replays against other work of the same detective is the caller's.
  *
  * Plain C, plain pointers and sizes only.  "Device pointer" means memory of the current
  * HIP device (e.g. torch.Tensor.data_ptr()); "stream" is a hipStream_t passed as void*

@@ -120,12 +120,37 @@ static hipError_t apply_file_tail(const Plan& p, const FileTail& t, const void* 
     return hipSuccess;
 }
 
+// Orders a batch call behind its predecessor when the two run on different streams (internal.hpp, "Concurrent use").
+struct StreamOrder {
+    LBAudioDetective* d;
+    hipStream_t stream;
+    bool active = false;
+    hipError_t begin() {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) != hipSuccess) { (void)hipGetLastError(); return hipSuccess; }
+        if (cap != hipStreamCaptureStatusNone) return hipSuccess;
+        if (!d->done) {
+            hipError_t e = hipEventCreateWithFlags(&d->done, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        active = true;
+        if (d->done_valid && d->done_stream != stream) return hipStreamWaitEvent(stream, d->done, 0);
+        return hipSuccess;
+    }
+    ~StreamOrder() {
+        if (!active) return;
+        d->done_valid = hipEventRecord(d->done, stream) == hipSuccess;
+        d->done_stream = stream;
+    }
+};
+
 // The batch hot path: every clip -> frames_per_clip packed sub-fingerprints.
 OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, uint32_t fmt, uint64_t n_clips,
                                   uint64_t spc, uint32_t* d_packed, float* d_raw, float* d_haar, hipStream_t stream,
                                   const FileTail* tail, size_t n_tails) {
     if (fmt > 2) return kLBAudioDetectiveArgumentInvalid;
     if (tail && (n_clips != 1 || fmt != 0)) return kLBAudioDetectiveArgumentInvalid;
+    LBAD_LOCK(d);
     const size_t elem = fmt == 1 ? 2 : 4;
     const char* d_pcm = static_cast<const char*>(d_pcm_raw);
     OSStatus st = ensure_plan(d);
@@ -146,6 +171,8 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     }
     if (d->variant == 1) special = false;
     if (d->variant >= 2 && !special) return kLBAudioDetectiveArgumentInvalid;
+    StreamOrder order{d, stream};
+    LBAD_HIP(order.begin());
     auto stage1 = [&](const void* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
         if (special && p.pruned_ok)
             return launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
@@ -369,6 +396,7 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
         if (t) (void)hipFree(t);
     if (inDetective->io_stream) (void)hipStreamDestroy(inDetective->io_stream);
     for (hipEvent_t e : inDetective->ev) (void)hipEventDestroy(e);
+    if (inDetective->done) (void)hipEventDestroy(inDetective->done);
     delete inDetective;
     return noErr;
 }
@@ -397,34 +425,41 @@ UInt32 LBAudioDetectiveGetAnalysisStride(LBAudioDetectiveRef d) { return d->stri
 // The upstream setters store whatever they are given and return noErr (:156-201); range checks
 // happen when the configuration is used.
 OSStatus LBAudioDetectiveSetProcessingSampleRate(LBAudioDetectiveRef d, Float64 inSampleRate) {
+    LBAD_LOCK(d);
     d->format.mSampleRate = inSampleRate;
     return noErr;
 }
 OSStatus LBAudioDetectiveSetNumberOfPitchSteps(LBAudioDetectiveRef d, UInt32 inNumberOfPitchSteps) {
+    LBAD_LOCK(d);
     d->bands = inNumberOfPitchSteps;
     return noErr;
 }
 OSStatus LBAudioDetectiveSetSubfingerprintLength(LBAudioDetectiveRef d, UInt32 inSubfingerprintLength) {
+    LBAD_LOCK(d);
     d->subfp_len = inSubfingerprintLength;
     return noErr;
 }
 OSStatus LBAudioDetectiveSetWindowSize(LBAudioDetectiveRef d, UInt32 inWindowSize) {  // :174-195, status inverted on purpose
+    LBAD_LOCK(d);
     if (!lbad::valid_window(inWindowSize)) return kLBAudioDetectiveArgumentInvalid;
     d->window = inWindowSize;
     return noErr;
 }
 OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef d, UInt32 inAnalysisStride) {
+    LBAD_LOCK(d);
     d->stride = inAnalysisStride;
     return noErr;
 }
 
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef d, UInt32 inVariant) {
+    LBAD_LOCK(d);
     if (inVariant > 3) return kLBAudioDetectiveArgumentInvalid;
     d->variant = inVariant;
     return noErr;
 }
 
 OSStatus LBAudioDetectiveSetKernelTuning(LBAudioDetectiveRef d, UInt32 inWavesPerWorkgroup, UInt32 inTwiddleCache) {
+    LBAD_LOCK(d);
     if (!d || inWavesPerWorkgroup > 16) return kLBAudioDetectiveArgumentInvalid;
     d->tune_waves = inWavesPerWorkgroup;
     d->tune_cache = inTwiddleCache != 0;
@@ -432,12 +467,14 @@ OSStatus LBAudioDetectiveSetKernelTuning(LBAudioDetectiveRef d, UInt32 inWavesPe
 }
 
 OSStatus LBAudioDetectiveSetScratchLimit(LBAudioDetectiveRef d, UInt64 inBytes) {
+    LBAD_LOCK(d);
     if (!d || inBytes == 0) return kLBAudioDetectiveArgumentInvalid;
     d->scratch_limit = inBytes;
     return noErr;
 }
 
 OSStatus LBAudioDetectiveSetStageTiming(LBAudioDetectiveRef d, UInt32 inEnabled) {
+    LBAD_LOCK(d);
     if (!d) return kLBAudioDetectiveArgumentInvalid;
     d->timing = inEnabled != 0;
     d->ev_used = 0;
@@ -446,6 +483,7 @@ OSStatus LBAudioDetectiveSetStageTiming(LBAudioDetectiveRef d, UInt32 inEnabled)
 
 OSStatus LBAudioDetectiveGetStageTimes(LBAudioDetectiveRef d, Float32* outStage1Ms, Float32* outStage2Ms,
                                        UInt32* outLaunches) {
+    LBAD_LOCK(d);
     if (!d || !d->timing || d->ev_used < 3) return kLBAudioDetectiveArgumentInvalid;
     float s1 = 0.0f, s2 = 0.0f;
     LBAD_HIP(hipEventSynchronize(d->ev[d->ev_used - 1]));
@@ -477,6 +515,7 @@ OSStatus LBAudioDetectiveFingerprintClipsDeviceTaps(LBAudioDetectiveRef d, const
 
 OSStatus LBAudioDetectiveFramesToSubfingerprintsDevice(LBAudioDetectiveRef d, const Float32* inFrames, UInt64 inNumberOfFrames,
                                                        void* outPacked, Float32* outFramesHaar, void* inStream) {
+    LBAD_LOCK(d);
     if (!d || (!inFrames && inNumberOfFrames) || (!outPacked && inNumberOfFrames)) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
@@ -518,6 +557,7 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef d, const voi
                                                 UInt64 inNumberOfClips, UInt64 inSamplesPerClip,
                                                 Boolean* outBooleans) {
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(d);
     if (!d || !inClips || !outBooleans || inSampleFormat > 2) return kLBAudioDetectiveArgumentInvalid;
     return lbad::fingerprint_clips_host(d, inClips, inSampleFormat, inNumberOfClips, inSamplesPerClip, outBooleans);
     LBAD_GUARD_END
@@ -526,6 +566,7 @@ OSStatus LBAudioDetectiveFingerprintClipsFormat(LBAudioDetectiveRef d, const voi
 OSStatus LBAudioDetectiveProcessPCM(LBAudioDetectiveRef d, const Float32* inSamples, UInt64 inNumberOfSamples,
                                     LBAudioDetectiveFingerprintRef* outFingerprint) {
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(d);
     if (!d || !outFingerprint || (!inSamples && inNumberOfSamples)) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
@@ -544,6 +585,7 @@ OSStatus LBAudioDetectiveComparePCM(LBAudioDetectiveRef d, const Float32* inSamp
                                     const Float32* inSamples2, UInt64 inCount2, UInt32 inComparisonRange,
                                     Float32* outMatch) {  // :442-464 on PCM
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(d);
     if (inComparisonRange == 0) inComparisonRange = d->subfp_len;  // :443-445
     LBAudioDetectiveFingerprintRef fp1 = NULL, fp2 = NULL;
     OSStatus st = LBAudioDetectiveProcessPCM(d, inSamples1, inCount1, &fp1);
@@ -564,18 +606,21 @@ static OSStatus read_url(const char* path, std::vector<float>& mono, double& rat
 }
 
 OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef d, UInt32 inMode) {
+    LBAD_LOCK(d);
     if (!d || inMode > 1) return kLBAudioDetectiveArgumentInvalid;
     d->hop_mode = inMode;
     return noErr;
 }
 
 OSStatus LBAudioDetectiveSetFileTailMode(LBAudioDetectiveRef d, UInt32 inMode) {
+    LBAD_LOCK(d);
     if (!d || inMode > 2) return kLBAudioDetectiveArgumentInvalid;
     d->tail_mode = inMode;
     return noErr;
 }
 
 OSStatus LBAudioDetectiveSetResamplerMode(LBAudioDetectiveRef d, UInt32 inMode) {
+    LBAD_LOCK(d);
     if (!d || inMode > 2) return kLBAudioDetectiveArgumentInvalid;
     d->resampler = inMode;
     return noErr;
@@ -619,6 +664,7 @@ void LBAudioDetectiveFreeSamples(Float32* inSamples) { std::free(inSamples); }
 OSStatus LBAudioDetectiveProcessFileStream(LBAudioDetectiveRef d, const Float32* inClientSamples, UInt64 inClientCount,
                                            UInt64 inFileFrames, UInt32 inHop, LBAudioDetectiveFingerprintRef* outFingerprint) {
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(d);
     if (!d || !outFingerprint || (!inClientSamples && inClientCount) || inHop == 0) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
@@ -697,6 +743,7 @@ OSStatus LBAudioDetectiveProcessAudioPath(LBAudioDetectiveRef d, const char* inF
 OSStatus LBAudioDetectiveConvertAudioURL(LBAudioDetectiveRef d, const char* inFileURL, Float32** outSamples, UInt64* outCount,
                                          UInt64* outFileFrames, Float64* outFileSampleRate) {
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(d);
     if (!d || !inFileURL || !outSamples || !outCount) return kLBAudioDetectiveArgumentInvalid;
     lbad::AudioPayload file;
     const lbad::AudioFileStatus fs = lbad::parse_audio_file(inFileURL, file);
@@ -721,6 +768,7 @@ OSStatus LBAudioDetectiveConvertAudioURL(LBAudioDetectiveRef d, const char* inFi
 OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef d, const char* inFileURL1, const char* inFileURL2,
                                           UInt32 inComparisonRange, Float32* outMatch) {  // :442-464
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(d);
     if (!d) return kLBAudioDetectiveArgumentInvalid;
     if (inComparisonRange == 0) inComparisonRange = d->subfp_len;
     // both files in one launch chain; like upstream the status is the SECOND file's (:449-456) and outMatch is
@@ -770,6 +818,7 @@ OSStatus LBAudioDetectiveStreamPush(LBAudioDetectiveStreamRef s, const Float32* 
     if (outNewSubfingerprints) *outNewSubfingerprints = 0;
     if (!s || (!inSamples && inNumberOfSamples)) return kLBAudioDetectiveArgumentInvalid;
     LBAudioDetective* d = s->detective;
+    LBAD_LOCK(d);
     OSStatus st = ensure_plan(d);
     if (st != noErr) return st;
     s->pending.insert(s->pending.end(), inSamples, inSamples + inNumberOfSamples);

@@ -386,6 +386,7 @@ OSStatus LBAudioDetectiveProcessAudioURLs(LBAudioDetectiveRef inDetective, const
                                           UInt32 inCount, LBAudioDetectiveFingerprintRef* outFingerprints,
                                           OSStatus* outStatuses) {
     LBAD_GUARD_BEGIN
+    LBAD_LOCK(inDetective);
     if (!inDetective || (!inFileURLs && inCount) || (!outFingerprints && inCount)) return kLBAudioDetectiveArgumentInvalid;
     if (inCount == 0) return noErr;
     return lbad::process_audio_files(inDetective, inFileURLs, inCount, outFingerprints, outStatuses);

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <new>
 #include <stdexcept>
+#include <mutex>
 #include <vector>
 
 #include "../../include/lbaudiodetective.h"
@@ -308,7 +309,20 @@ struct LBAudioDetective {
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2
     size_t ev_used = 0;
+    // Concurrent use (round 3).  The claim counters of the plan, the inter-stage rows and the io / converter buffers
+    // are ONE set per detective: `mutex` serialises the host side of every entry point, and a batch call that arrives
+    // on another stream than its predecessor first waits (on the device, hipStreamWaitEvent) for `done` -- the
+    // predecessor's last kernel.  Two threads with two streams therefore get correct results, one after the other;
+    // for overlap use one detective per stream.  Nothing is recorded or awaited while the stream is being captured
+    // into a graph (a replay is the caller's to order).
+    std::recursive_mutex mutex;
+    hipEvent_t done = nullptr;
+    hipStream_t done_stream = nullptr;
+    bool done_valid = false;
 };
+
+// first statement of every entry point that touches a detective's state
+#define LBAD_LOCK(d) std::unique_lock<std::recursive_mutex> lbad_lock_; if (d) lbad_lock_ = std::unique_lock<std::recursive_mutex>((d)->mutex)
 
 struct LBAudioDetectiveCorpus {
     uint32_t subfp_len = 0;

@@ -947,6 +947,44 @@ def test_batch_call_captures_into_a_hip_graph(lb, gpu, oracle):
         assert np.array_equal(got, want[first:first + 3])
 
 
+def test_one_detective_from_two_threads_and_two_streams(lb, gpu, oracle):
+    """Two host threads drive ONE detective on two streams (the claim counters, the inter-stage rows and the io buffers
+    exist once per detective): the calls are serialised -- a mutex on the host, an event wait on the device -- and every
+    result is the oracle's.  Before round 3 this dropped rows."""
+    import threading
+    cfg = oracle.Config(44100, 1024)
+    det = lb.Detective().configure(sample_rate=44100, window=1024)
+    det.set_scratch_limit(4 << 20)                                   # several chunks per call: long stretches on the scratch rows
+    pcm = oracle.synth_clips(SEED, 900, 8, 44100, 44100)
+    want = oracle.fingerprint_batch(pcm, cfg)
+    host_want = oracle.fingerprint_batch(pcm[:1, :20000], cfg)
+    errors = []
+
+    def worker(k):
+        try:
+            stream = gpu.cuda.Stream()
+            clips = gpu.from_numpy(pcm[4 * k:4 * k + 4]).cuda()
+            gpu.cuda.synchronize()
+            for it in range(12):
+                with gpu.cuda.stream(stream):
+                    out = det.fingerprint_clips_device(clips, stream=stream)
+                if it % 4 == k:                                       # a host entry point (the detective's own stream) in between
+                    got = det.process_pcm(pcm[0, :20000]).to_bools()
+                    assert np.array_equal(got.reshape(host_want[0].shape), host_want[0])
+                stream.synchronize()
+                got = lb.unpack_packed(out.cpu().numpy(), cfg.subfp_len).reshape(4, -1, cfg.subfp_len)
+                assert np.array_equal(got, want[4 * k:4 * k + 4]), (k, it)
+        except BaseException as e:                                    # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_upstream_test_suite_matches_essay(lb, gpu, oracle):
     """Upstream's whole XCTest suite (LBAudioDetectiveTests.m:95-117: Tests 1, 2, 3.1, 3.2, 4) on its own sixty
     fixtures through the HIP library with upstream's file loop, against the fifty numbers the essay publishes
