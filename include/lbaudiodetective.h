@@ -403,7 +403,9 @@ void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* ou
  * (LBAudioDetectiveTests.m:80-83 across shards).  inComm is an ncclComm_t passed as void* -- the caller's own, or
  * one made with LBAudioDetectiveCommInitRank.  RCCL is loaded on first use (librccl.so.1; a copy already in the
  * process is reused).  ArgumentInvalid when inIndexBase + the shard's entry count exceeds 2^32 (the key carries
- * a 32-bit global index). */
+ * a 32-bit global index).  The call is COLLECTIVE: a rank whose own scan cannot run (that error, a NULL corpus, a
+ * failed launch) still takes part in the exchange with empty keys, so the other ranks return their result, and
+ * reports its own status afterwards; only a NULL communicator or a count of zero returns without the exchange. */
 OSStatus LBAudioDetectiveCorpusQuerySharded(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                             UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
                                             SInt64* outIndex, Float32* outScore);

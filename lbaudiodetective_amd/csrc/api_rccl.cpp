@@ -113,9 +113,7 @@ OSStatus LBAudioDetectiveCorpusQueryBatchSharded(LBAudioDetectiveCorpusRef inCor
                                                  const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
                                                  UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
                                                  SInt64* outIndices, Float32* outScores) {
-    if (!inCorpus || !inQueries || inCount == 0 || !inComm) return kLBAudioDetectiveArgumentInvalid;
-    // the key carries a 32-bit GLOBAL index
-    if (inIndexBase + LBAudioDetectiveCorpusGetCount(inCorpus) > 0x100000000ull) return kLBAudioDetectiveArgumentInvalid;
+    if (inCount == 0 || !inComm) return kLBAudioDetectiveArgumentInvalid;
     lbad::Rccl& r = lbad::rccl();
     if (!r.ok) return kLBAudioDetectiveCollectiveError;
     const int dev = lbad::current_device();
@@ -134,14 +132,25 @@ OSStatus LBAudioDetectiveCorpusQueryBatchSharded(LBAudioDetectiveCorpusRef inCor
         k.d = nd; k.h = nh; k.cap = inCount;
     }
     hipStream_t stream = static_cast<hipStream_t>(inStream);
-    OSStatus st = inCount == 1
-        ? LBAudioDetectiveCorpusQueryKeyDevice(inCorpus, inQueries[0], inRange, inIndexBase, k.d, stream)
-        : LBAudioDetectiveCorpusQueryBatchKeysDevice(inCorpus, inQueries, inCount, inRange, inIndexBase, k.d, stream);
-    if (st != noErr) return st;
+    // From here on the other ranks are (or will be) waiting in the exchange: a rank whose OWN scan cannot run -- bad
+    // arguments, a shard whose indices do not fit the key's 32 bits, a failed launch -- still takes part, with keys of
+    // zero ("nothing found here"), and reports its error afterwards.  Returning early would hang the other ranks.
+    OSStatus local = noErr;
+    if (!inCorpus || !inQueries) local = kLBAudioDetectiveArgumentInvalid;
+    else if (inIndexBase + LBAudioDetectiveCorpusGetCount(inCorpus) > 0x100000000ull) local = kLBAudioDetectiveArgumentInvalid;
+    else
+        local = inCount == 1
+            ? LBAudioDetectiveCorpusQueryKeyDevice(inCorpus, inQueries[0], inRange, inIndexBase, k.d, stream)
+            : LBAudioDetectiveCorpusQueryBatchKeysDevice(inCorpus, inQueries, inCount, inRange, inIndexBase, k.d, stream);
+    if (local != noErr) LBAD_HIP(hipMemsetAsync(k.d, 0, (size_t)inCount * 8, stream));
     // the one exchange step: MAX over ranks of the unsigned 64-bit keys, in place, on the caller's stream
-    st = lbad::nccl_status(r.AllReduce(k.d, k.d, inCount, ncclUint64, ncclMax, static_cast<ncclComm_t>(inComm), stream),
-                           "ncclAllReduce");
+    OSStatus st = lbad::nccl_status(r.AllReduce(k.d, k.d, inCount, ncclUint64, ncclMax, static_cast<ncclComm_t>(inComm), stream),
+                                    "ncclAllReduce");
     if (st != noErr) return st;
+    if (local != noErr) {
+        (void)hipStreamSynchronize(stream);
+        return local;
+    }
     LBAD_HIP(hipMemcpyAsync(k.h, k.d, (size_t)inCount * 8, hipMemcpyDeviceToHost, stream));
     LBAD_HIP(hipStreamSynchronize(stream));
     for (UInt32 i = 0; i < inCount; ++i)

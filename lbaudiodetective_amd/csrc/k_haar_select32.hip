@@ -24,8 +24,6 @@ namespace {
 constexpr uint32_t kCand = 128;     // candidates ranked exhaustively
 constexpr int kChunkDw = 20;        // 16 floats + 4 pad: conflict-free ds_read_b128 across lanes
 
-__device__ __forceinline__ float div_root(float x, float root) { return __fdiv_rn(x, root); }
-
 // x / d for the Haar's three constant divisors without the ~11-instruction IEEE division sequence:
 //     q0 = x * r;  e = fma(-d, q0, x);  q = fma(e, r, q0)        with r = RN(1 / d).
 // tools/verify_const_div.c checks ALL 2^32 inputs for d = sqrtf(2), sqrtf(32), sqrtf(128): q equals the
@@ -113,11 +111,50 @@ __device__ __forceinline__ float haar16_impl(const float (&in)[16], float (&d)[1
     return s4;
 }
 
-__device__ __forceinline__ float haar16(const float (&in)[16], float (&d)[15], float root, float root2) {
+// `fast` (wave-uniform) tells the caller whether the shortcut held for the whole wave
+__device__ __forceinline__ float haar16(const float (&in)[16], float (&d)[15], float root, float root2, bool& fast) {
     DivGuard g;
     float s4 = haar16_impl<true>(in, d, root, __fdiv_rn(1.0f, root), root2, __fdiv_rn(1.0f, root2), g);
-    if (__any(g.bad())) s4 = haar16_impl<false>(in, d, root, 0.0f, root2, 0.0f, g);   // rare: tiny / inf / NaN
+    fast = !__any(g.bad());
+    if (!fast) s4 = haar16_impl<false>(in, d, root, 0.0f, root2, 0.0f, g);   // rare: tiny / inf / NaN
     return s4;
+}
+
+// The levels that pair the LANES lanes of one line (their level-4 averages).  At the level with lane distance m the
+// lower lane of a pair continues with (lo + hi) / sqrt 2 and the upper one leaves with (lo - hi) / sqrt 2: ONE
+// division per lane and level (until round 3 both lanes computed both).  lo - hi is formed as lo + (-hi), the same
+// float for every input.  Returns the coefficient the lane ends up owning.
+template <bool FAST, int LANES>
+__device__ __forceinline__ float cross_levels_impl(float cur, int h, float root2, float r_root2, DivGuard& g) {
+    float fin = 0.0f;
+    bool done = false;
+#pragma unroll
+    for (int m = 1; m < LANES; m <<= 1) {
+        const float other = __shfl_xor(cur, m, 64);
+        const bool upper = (h & m) != 0;
+        const float lo = upper ? other : cur, hi = upper ? -cur : other;
+        const float s = __fadd_rn(lo, hi);
+        if constexpr (FAST) g.dividends(s, s);
+        const float q = div_c<FAST>(s, root2, r_root2);
+        if (!done && upper) { fin = q; done = true; }
+        cur = q;
+    }
+    if (!done) fin = cur;   // lane 0 keeps the line's average
+    return fin;
+}
+
+// `fast`: the line's haar16 ran on the shortcut, i.e. its 16 inputs are finite and <= 2^126 -- the sums here stay
+// finite (at most 2^127.5 after seven levels) and only the tiny-dividend guard is needed.
+template <int LANES>
+__device__ __forceinline__ float cross_levels(float cur, int h, float root2, bool fast) {
+    if constexpr (LANES == 1) return cur;
+    if (fast) {
+        DivGuard g;
+        const float fin = cross_levels_impl<true, LANES>(cur, h, root2, __fdiv_rn(1.0f, root2), g);
+        if (!__any(g.bad())) return fin;
+    }
+    DivGuard g;
+    return cross_levels_impl<false, LANES>(cur, h, root2, 0.0f, g);
 }
 
 // 32 columns: 72 VGPRs -> seven workgroups per CU, which is also what the 22 KB of LDS allow (90 VGPRs and five
@@ -168,22 +205,11 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
             const float4 v = src[q];
             a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         }
-        float cur = haar16(a, d, __fsqrt_rn((float)kCols), root2);       // (16, 32, 64: the device root is exact for these)
+        bool fast;
+        const float cur = haar16(a, d, __fsqrt_rn((float)kCols), root2, fast);   // (16, 32, 64: the device root is exact for these)
         // the remaining levels pair the H sixteenths of the row; a lane leaves with its detail value as soon as
-        // its index has the level's bit set
-        float fin = 0.0f;
-        bool done = false;
-#pragma unroll
-        for (int m = 1; m < H; m <<= 1) {
-            const float other = __shfl_xor(cur, m, 64);
-            const bool upper = (h & m) != 0;
-            const float lo = upper ? other : cur, hi = upper ? cur : other;
-            const float sm = div_root(__fadd_rn(lo, hi), root2);
-            const float df = div_root(__fsub_rn(lo, hi), root2);
-            if (!done && upper) { fin = df; done = true; }
-            cur = sm;
-        }
-        if (!done) fin = cur;   // sixteenth 0 keeps the row's average
+        // its index has the level's bit set, sixteenth 0 keeps the row's average
+        const float fin = cross_levels<H>(cur, h, root2, fast);
         // sixteenth -> ordered position of its cross-lane value (H = 4: 0, 2, 1, 3)
         const int cross = H == 1 ? 0 : (h & 1) ? H / 2 + (h >> 1) : (h & 2) ? H / 4 + (h >> 2) : 0;
         // transposed store: coefficient at ordered position p of this row -> s_t[p][row >> 4][row & 15]
@@ -212,22 +238,10 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
             const float4 x = src[q];
             a[4 * q] = x.x; a[4 * q + 1] = x.y; a[4 * q + 2] = x.z; a[4 * q + 3] = x.w;
         }
-        float cur = haar16(a, d, __fsqrt_rn((float)kRowsPerFrame), root2);
-        // levels 5..7 across the 8 chunks of the column; a lane leaves with its detail value as soon
-        // as its chunk index has the level's bit set
-        float fin = 0.0f;
-        bool done = false;
-#pragma unroll
-        for (int m = 1; m <= 4; m <<= 1) {
-            const float other = __shfl_xor(cur, m, 64);
-            const bool upper = (j & m) != 0;
-            const float lo = upper ? other : cur, hi = upper ? cur : other;
-            const float sm = div_root(__fadd_rn(lo, hi), root2);
-            const float df = div_root(__fsub_rn(lo, hi), root2);
-            if (!done && upper) { fin = df; done = true; }
-            cur = sm;
-        }
-        if (!done) fin = cur;   // chunk 0 keeps the overall average
+        bool fast;
+        const float cur = haar16(a, d, __fsqrt_rn((float)kRowsPerFrame), root2, fast);
+        // levels 5..7 across the 8 chunks of the column; chunk 0 keeps the overall average
+        const float fin = cross_levels<8>(cur, j, root2, fast);
 #pragma unroll
         for (int i = 0; i < 8; ++i) { v[i] = d[i]; pos[i] = 64 + 8 * j + i; }
 #pragma unroll
@@ -298,12 +312,15 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     {
         bool sel[16];
         uint32_t wave_total = 0;
+        if (idx_bound == kRowsPerFrame * kCols) {   // (workgroup-uniform) no plateau: one compare per key
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t idx = pos[i] * kCols + col;
-            sel[i] = key[i] > lo || (key[i] == lo && idx < idx_bound);
-            wave_total += (uint32_t)__popcll(__ballot(sel[i]));
+            for (int i = 0; i < 16; ++i) sel[i] = key[i] >= lo;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sel[i] = key[i] > lo || (key[i] == lo && pos[i] * kCols + col < idx_bound);
         }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wave_total += (uint32_t)__popcll(__ballot(sel[i]));
         uint32_t base = 0;
         if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
         base = __builtin_amdgcn_readfirstlane(base);

@@ -97,10 +97,17 @@ def make_comm(rank: int = 0, world_size: int = 1, group=None):
     the 128-byte id; torch.distributed -- plumbing, whatever backend it runs on -- carries it to the other ranks.
     The current CUDA/HIP device must already be this rank's."""
     from .api import Comm
-    uid = [Comm.unique_id() if rank == 0 else None]
+    uid, err = [None], None
+    if rank == 0:
+        try:
+            uid[0] = Comm.unique_id()
+        except Exception as e:          # noqa: BLE001 -- the other ranks are waiting in the broadcast: tell them
+            err = e
     if world_size > 1:
         import torch.distributed as dist
         dist.broadcast_object_list(uid, src=0, group=group)
+    if uid[0] is None:
+        raise err if err is not None else RuntimeError("rank 0 could not obtain an RCCL unique id")
     return Comm(world_size, uid[0], rank)
 
 
