@@ -174,6 +174,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     __shared__ uint32_t s_red[16];
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_bits[kPackedWords];
+    __shared__ uint8_t s_pos[128];   // [i][j]: row position of coefficient i of the thread that owns chunk j (column pass)
 
     const int t = threadIdx.x;
     const uint64_t frame = blockIdx.x;
@@ -192,6 +193,11 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     if (t < (int)kPackedWords) s_bits[t] = 0;
     if (t < (int)kCand) s_rank[t] = 0;
     if (t == 0) s_ncand = 0;
+    if (t < 128) {   // the closed form of pos[] below, as a table for step (b) of the gather
+        const int i = t >> 3, jj = t & 7;
+        const int cross = (jj & 1) ? 4 + (jj >> 1) : (jj & 2) ? 2 + (jj >> 2) : (jj ? 1 : 0);
+        s_pos[t] = (uint8_t)(i < 8 ? 64 + 8 * jj + i : i < 12 ? 32 + 4 * jj + (i - 8) : i < 14 ? 16 + 2 * jj + (i - 12) : i == 14 ? 8 + jj : cross);
+    }
     for (int i = t; i < 2 * (int)kCand; i += kThreads)
         reinterpret_cast<uint32_t*>(s_cand)[i] = 0;   // zero keys pad the list to a multiple of 8 for the ranking loop
 
@@ -259,9 +265,12 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         for (int i = 0; i < 16; ++i) dst[pos[i] * kCols + col] = v[i];
     }
 
+    // key = the value's bits rotated left by one: |v| bits in the upper 31 bits, the sign in bit 0.  key >= 2 m  <=>
+    // |v| bits >= m, so the search and the gather compare against doubled thresholds, and the coefficients themselves
+    // need not stay in registers next to their keys.
     uint32_t key[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) key[i] = __float_as_uint(v[i]) & 0x7fffffffu;
+    for (int i = 0; i < 16; ++i) key[i] = __builtin_rotateleft32(__float_as_uint(v[i]), 1);
 
     STAMP(2);
     // ---- threshold search ---------------------------------------------------------------------------
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         // adds and the cross-lane reduction run on the scalar unit instead of the VALU
         uint32_t c = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c += (uint32_t)__popcll(__ballot(key[i] >= mid));
+        for (int i = 0; i < 16; ++i) c += (uint32_t)__popcll(__ballot(key[i] >= (mid << 1)));   // mid < 2^31
         {
             uint32_t* slot = s_red + 8 * parity;
             if ((t & 63) == 0) slot[t >> 6] = c;
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         // every key above it, then the tied ones in ascending flat-index order until `keep` is reached.
         uint32_t g = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) g += key[i] > lo ? 1u : 0u;
+        for (int i = 0; i < 16; ++i) g += (key[i] >> 1) > lo ? 1u : 0u;
         g = block_sum<kWavesPerWg>(g, s_red, parity);
         parity ^= 1;
         uint32_t ilo = 0, ihi = kRowsPerFrame * kCols;
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
             const uint32_t im = ilo + ((ihi - ilo) >> 1);
             uint32_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) c += (key[i] == lo && pos[i] * kCols + col < im) ? 1u : 0u;
+            for (int i = 0; i < 16; ++i) c += ((key[i] >> 1) == lo && pos[i] * kCols + col < im) ? 1u : 0u;
             c = block_sum<kWavesPerWg>(c, s_red, parity);
             parity ^= 1;
             if (g + c >= keep) ihi = im; else ilo = im + 1;
@@ -307,39 +316,54 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         idx_bound = ilo;
     }
 
-    // ---- gather candidates: composite = key << (idx bits + 2) | (max idx - idx) << 2 | sign code ----------
-    // one LDS atomic per wave: the slots of a wave's candidates follow from lane-mask popcounts
+    // ---- gather candidates, in two steps ---------------------------------------------------------------------
+    // (a) every thread drops (key, where it came from) of its selected coefficients into the list: per coefficient a
+    //     compare, the slot from lane-mask popcounts (one LDS atomic per wave) and one 8-byte store.  A wave holds ~26
+    //     candidates among 1024 coefficients, so whatever else is done per coefficient here runs with one or two lanes
+    //     active -- until round 3 that was the whole composite key (16 instructions, 16 times);
+    // (b) one thread per CANDIDATE turns its entry into the composite
+    //     |v| bits << (idx bits + 2) | (max idx - idx) << 2 | sign code        (sign code: 1 for v > 0, 2 for v < 0).
     {
-        bool sel[16];
-        uint32_t wave_total = 0;
-        if (idx_bound == kRowsPerFrame * kCols) {   // (workgroup-uniform) no plateau: one compare per key
+        const uint32_t origin = ((uint32_t)col << 7) | (uint32_t)j;    // + (i << 3): index into s_pos, column above it
+        auto gather = [&](auto selected) {
+            // the lane masks are taken once and kept (scalar registers)
+            unsigned long long mask[16];
+            uint32_t wave_total = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sel[i] = key[i] >= lo;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sel[i] = key[i] > lo || (key[i] == lo && pos[i] * kCols + col < idx_bound);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) wave_total += (uint32_t)__popcll(__ballot(sel[i]));
-        uint32_t base = 0;
-        if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
-        base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const unsigned long long m = __ballot(sel[i]);
-            if (sel[i]) {
-                const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                const uint32_t idx = pos[i] * kCols + col;
-                const uint32_t sg = v[i] > 0.0f ? 1u : (v[i] < 0.0f ? 2u : 0u);
-                s_cand[at] = ((unsigned long long)key[i] << (kIdxBits + 2)) |
-                             ((unsigned long long)(((1u << kIdxBits) - 1u) - idx) << 2) | sg;
+            for (int i = 0; i < 16; ++i) {
+                mask[i] = __ballot(selected(i));
+                wave_total += (uint32_t)__popcll(mask[i]);
             }
-            base += (uint32_t)__popcll(m);
-        }
+            uint32_t base = 0;
+            if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const unsigned long long m = mask[i];
+                if (selected(i)) {
+                    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s_cand[at] = ((unsigned long long)key[i] << 32) | (origin + (uint32_t)(i << 3));
+                }
+                base += (uint32_t)__popcll(m);
+            }
+        };
+        // (workgroup-uniform) without a plateau one compare per key decides; two copies of the loop, so that the masks
+        // stay in scalar registers
+        if (idx_bound == kRowsPerFrame * kCols) gather([&](int i) { return key[i] >= (lo << 1); });
+        else gather([&](int i) { return (key[i] >> 1) > lo || ((key[i] >> 1) == lo && pos[i] * kCols + col < idx_bound); });
+    }
+    __syncthreads();
+    const uint32_t nc = s_ncand;
+    if (t < (int)nc) {   // nc <= kCand <= kThreads
+        const unsigned long long raw = s_cand[t];
+        const uint32_t k = (uint32_t)(raw >> 32), from = (uint32_t)raw;
+        const uint32_t idx = (uint32_t)s_pos[from & 127u] * kCols + (from >> 7);
+        // |v| bits in [1, 0x7F800000] (not +-0, not NaN: neither v > 0 nor v < 0 holds for those)  <=>  k - 2 < 0xFF000000
+        const uint32_t sg = k - 2u < 0xFF000000u ? (k & 1u) + 1u : 0u;
+        s_cand[t] = ((unsigned long long)(k & ~1u) << (kIdxBits + 1)) | ((unsigned long long)(((1u << kIdxBits) - 1u) - idx) << 2) | sg;
     }
     __syncthreads();
     STAMP(4);
-    const uint32_t nc = s_ncand;
 
     // ---- rank: kThreads / 128 threads per candidate, each scans its share of the list --------------------
     {

@@ -14,7 +14,7 @@ lb.lib()
 out = {"lib": N.LIB_PATH}
 
 
-def run(det, frames, reps=40):
+def run(det, frames, reps=200):
     packed = lb.frames_to_subfingerprints_device(det, frames)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,7 +32,7 @@ _, raw, _ = det.fingerprint_clips_device(clips, taps=True)
 torch.cuda.synchronize()
 frames = raw.reshape(-1, 128, 32).contiguous()
 del clips
-for rnd in range(3):
+for rnd in range(4):
     us, h = run(det, frames)
     out[f"B_32_bands_{frames.shape[0]}_frames_round{rnd}"] = {"us": round(us, 1), "bits": h}
 del frames, raw
