@@ -77,9 +77,31 @@ __device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t* s_red, int p
     return slots_sum<WAVES>(slot);
 }
 
-// levels 1..4 of a 16-value line held in registers.  On return d[0..7] = level-1 details,
-// d[8..11] = level 2, d[12..13] = level 3, d[14] = level 4 and the return value is the level-4
-// average that continues into the cross-lane levels.
+// Most lines need far fewer checks (round 3).  A sum or difference of two floats a, b is 0 or at least
+// min(ulp a, ulp b) > min(|a|, |b|) 2^-24, and a quotient by sqrt 2 loses another half binade; the pre-scale divides by
+// at most 2^3.5.  So when every NON-ZERO input of a line is >= 2^-52, the dividends of levels 1 and 2 are 0 or
+// >= 2^-79.5, 2^-104 -- inside the verified range without looking at them.  The light guard therefore checks the 16
+// inputs (min over t as above against 2^-52; magnitudes with one v_max3_f32 per pair, which ignores NaN -- a NaN input
+// reaches the level-4 average through every sum and is caught there) and the six dividends of levels 3 and 4.  A line
+// that fails it is redone with the full guard, and with true divisions if that fails too.
+constexpr uint32_t kLightLo = 0x25800000u;     // 2^-52
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct LightGuard {
+    uint32_t lo_in = 0xFFFFFFFFu, lo_4 = 0xFFFFFFFFu;
+    float hi = 0.0f;
+    __device__ __forceinline__ void levels34(f2 a, f2 b, f2 c) {
+        auto t = [](float x) { return (__float_as_uint(x) << 1) - 1u; };
+        lo_4 = min(min(min(t(a.x), t(a.y)), min(t(b.x), t(b.y))), min(t(c.x), t(c.y)));
+    }
+    __device__ __forceinline__ bool bad(float s4) const {
+        return lo_in < 2u * kLightLo - 1u || lo_4 < 2u * kFastDivLo - 1u || !(hi <= __uint_as_float(kFastDivHi)) || s4 != s4;
+    }
+};
+
+// levels 1..4 of a 16-value line held in registers, compiler-scheduled: FAST = the shortcut with every dividend guarded,
+// otherwise true divisions.  On return d[0..7] = level-1 details, d[8..11] = level 2, d[12..13] = level 3, d[14] = level 4
+// and the return value is the level-4 average that continues into the cross-lane levels.
 template <bool FAST>
 __device__ __forceinline__ float haar16_impl(const float (&in)[16], float (&d)[15], float root, float r_root,
                                              float root2, float r_root2, DivGuard& g) {
@@ -111,12 +133,195 @@ __device__ __forceinline__ float haar16_impl(const float (&in)[16], float (&d)[1
     return s4;
 }
 
-// `fast` (wave-uniform) tells the caller whether the shortcut held for the whole wave
-__device__ __forceinline__ float haar16(const float (&in)[16], float (&d)[15], float root, float root2, bool& fast) {
+// ---- the light tier, written out (round 3) ---------------------------------------------------------------------------
+// The compiler's version of the shortcut spends 35 v_mov per line on pairing registers for the packed instructions
+// and canonicalises every operand of fmaxf.  Here a line is 8 register PAIRS from start to end:
+//   pre-scale   (x0, x1)            -> (x0, x1) / root                                   3 packed per pair
+//   level 1     (x, y) of one pair  -> (x + y, x - y) -> / sqrt 2 = (sum, detail)        1 + 3 packed per pair
+//   level 2..4  lows of two pairs   -> (a + b, a - b) -> / sqrt 2 = (sum, detail)        1 + 3 packed per butterfly
+// with op_sel picking the halves, so nothing is ever moved: 84 packed instructions per line.  a - b is formed as
+// a + (-b) (neg_hi), the same float.  gfx950 needs one wait state between a packed instruction and a consumer of its
+// result (the compiler's own s_nop 0 in such chains): inside a block consumers are at least two instructions behind
+// their producers except in the last butterfly, which carries explicit s_nop; every block ends with one.
+
+// RN(1 / d) and -d in the low halves of scalar register pairs (the packed operand form op_sel_hi:[1,0] reads the low half twice)
+struct DivConst {
+    unsigned long long r, nd;
+    __device__ __forceinline__ explicit DivConst(float d)
+        : r(__builtin_amdgcn_readfirstlane(__float_as_uint(__fdiv_rn(1.0f, d)))),
+          nd(__builtin_amdgcn_readfirstlane(__float_as_uint(-d))) {}
+};
+
+// x[i] / root for 8 pairs: q0 = x r; e = fma(-d, q0, x) (over x); q = fma(e, r, q0)
+__device__ __forceinline__ void pk_prescale8(f2 (&x)[8], f2 (&q)[8], const DivConst& c) {
+    asm("v_pk_mul_f32 %0, %8, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %1, %9, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %2, %10, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %3, %11, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %4, %12, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %5, %13, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %6, %14, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %7, %15, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_fma_f32 %8, %0, %[nd], %8 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %9, %1, %[nd], %9 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %10, %2, %[nd], %10 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %11, %3, %[nd], %11 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %12, %4, %[nd], %12 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %13, %5, %[nd], %13 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %14, %6, %[nd], %14 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %15, %7, %[nd], %15 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %0, %8, %[r], %0 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %1, %9, %[r], %1 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %2, %10, %[r], %2 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %3, %11, %[r], %3 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %4, %12, %[r], %4 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %5, %13, %[r], %5 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %6, %14, %[r], %6 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %7, %15, %[r], %7 op_sel_hi:[1,0,1]\n"
+        "s_nop 0"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]),
+          "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
+        : [r] "s"(c.r), [nd] "s"(c.nd));
+}
+
+// level 1: every pair (x, y) -> ((x + y) / sqrt 2, (x - y) / sqrt 2); p is used up
+__device__ __forceinline__ void pk_level1(f2 (&p)[8], f2 (&q)[8], const DivConst& c) {
+    asm("v_pk_add_f32 %8, %8, %8 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %9, %9, %9 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %10, %10, %10 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %11, %11, %11 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %12, %12, %12 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %13, %13, %13 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %14, %14, %14 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %15, %15, %15 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n"
+        "v_pk_mul_f32 %0, %8, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %1, %9, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %2, %10, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %3, %11, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %4, %12, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %5, %13, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %6, %14, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %7, %15, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_fma_f32 %8, %0, %[nd], %8 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %9, %1, %[nd], %9 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %10, %2, %[nd], %10 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %11, %3, %[nd], %11 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %12, %4, %[nd], %12 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %13, %5, %[nd], %13 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %14, %6, %[nd], %14 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %15, %7, %[nd], %15 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %0, %8, %[r], %0 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %1, %9, %[r], %1 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %2, %10, %[r], %2 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %3, %11, %[r], %3 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %4, %12, %[r], %4 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %5, %13, %[r], %5 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %6, %14, %[r], %6 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %7, %15, %[r], %7 op_sel_hi:[1,0,1]\n"
+        "s_nop 0"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]),
+          "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7])
+        : [r] "s"(c.r), [nd] "s"(c.nd));
+}
+
+// level 2: the sums (low halves) of pairs 2 i and 2 i + 1 -> ((a + b) / sqrt 2, (a - b) / sqrt 2), four times
+__device__ __forceinline__ void pk_level2(const f2 (&p)[8], f2 (&q)[4], const DivConst& c) {
+    f2 t0, t1, t2, t3;
+    asm("v_pk_add_f32 %4, %8, %9 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %5, %10, %11 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %6, %12, %13 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %7, %14, %15 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "v_pk_mul_f32 %0, %4, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %1, %5, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %2, %6, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %3, %7, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_fma_f32 %4, %0, %[nd], %4 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %5, %1, %[nd], %5 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %6, %2, %[nd], %6 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %7, %3, %[nd], %7 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %0, %4, %[r], %0 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %1, %5, %[r], %1 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %2, %6, %[r], %2 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %3, %7, %[r], %3 op_sel_hi:[1,0,1]\n"
+        "s_nop 0"
+        : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), [r] "s"(c.r), [nd] "s"(c.nd));
+}
+
+// levels 3 and 4; s3 and s4 return their dividends for the guard
+__device__ __forceinline__ void pk_level34(const f2 (&p)[4], f2 (&q3)[2], f2& q4, f2 (&s3)[2], f2& s4, const DivConst& c) {
+    f2 e0, e1, e4;
+    asm("v_pk_add_f32 %3, %9, %10 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "v_pk_add_f32 %4, %11, %12 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "v_pk_mul_f32 %0, %3, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_mul_f32 %1, %4, %[r] op_sel_hi:[1,0]\n"
+        "v_pk_fma_f32 %6, %0, %[nd], %3 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %7, %1, %[nd], %4 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %0, %6, %[r], %0 op_sel_hi:[1,0,1]\n"
+        "v_pk_fma_f32 %1, %7, %[r], %1 op_sel_hi:[1,0,1]\n"
+        "s_nop 0\n"
+        "v_pk_add_f32 %5, %0, %1 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]\n"
+        "s_nop 0\n"
+        "v_pk_mul_f32 %2, %5, %[r] op_sel_hi:[1,0]\n"
+        "s_nop 0\n"
+        "v_pk_fma_f32 %8, %2, %[nd], %5 op_sel_hi:[1,0,1]\n"
+        "s_nop 0\n"
+        "v_pk_fma_f32 %2, %8, %[r], %2 op_sel_hi:[1,0,1]\n"
+        "s_nop 0"
+        : "=&v"(q3[0]), "=&v"(q3[1]), "=&v"(q4), "=&v"(s3[0]), "=&v"(s3[1]), "=&v"(s4), "=&v"(e0), "=&v"(e1), "=&v"(e4)
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), [r] "s"(c.r), [nd] "s"(c.nd));
+}
+
+// |a|, |b| into a running float maximum without the canonicalising v_max the compiler puts in front of fmaxf
+__device__ __forceinline__ float max3_abs(float m, float a, float b) {
+    float o;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(o) : "v"(m), "v"(a), "v"(b));
+    return o;
+}
+
+// One 16-value line: `load` fills the 16 inputs (it is called again when the line has to be redone).  `fast`
+// (wave-uniform) tells the caller whether the shortcut held for the whole wave.
+template <typename Load>
+__device__ __forceinline__ float haar16(Load load, float (&d)[15], float root, float root2, bool& fast) {
+    const DivConst c_root(root), c_root2(root2);
+    {
+        f2 x[8], q[8], u[8], v2[4], w[2], z, s3[2], s4;
+        {
+            float in[16];
+            load(in);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = f2{in[2 * i], in[2 * i + 1]};
+        }
+        LightGuard lg;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            lg.lo_in = min(lg.lo_in, min((__float_as_uint(x[i].x) << 1) - 1u, (__float_as_uint(x[i].y) << 1) - 1u));
+            lg.hi = max3_abs(lg.hi, x[i].x, x[i].y);
+        }
+        pk_prescale8(x, q, c_root);
+        pk_level1(q, u, c_root2);
+        pk_level2(u, v2, c_root2);
+        pk_level34(v2, w, z, s3, s4, c_root2);
+        lg.levels34(s3[0], s3[1], s4);
+        fast = !__any(lg.bad(z.x));
+        if (fast) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = u[i].y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[8 + i] = v2[i].y;
+            d[12] = w[0].y; d[13] = w[1].y; d[14] = z.y;
+            return z.x;
+        }
+    }
+    // small inputs: the shortcut with every dividend checked; tiny / inf / NaN: true divisions.  The inputs are read
+    // AGAIN (the barrier keeps the compiler from holding the first copies in registers across the light tier)
+    asm volatile("" ::: "memory");
+    float in[16];
+    load(in);
     DivGuard g;
     float s4 = haar16_impl<true>(in, d, root, __fdiv_rn(1.0f, root), root2, __fdiv_rn(1.0f, root2), g);
     fast = !__any(g.bad());
-    if (!fast) s4 = haar16_impl<false>(in, d, root, 0.0f, root2, 0.0f, g);   // rare: tiny / inf / NaN
+    if (!fast) s4 = haar16_impl<false>(in, d, root, 0.0f, root2, 0.0f, g);
     return s4;
 }
 
@@ -205,14 +410,16 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     {
         const int row = t / H, h = t % H;
         const float4* src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + row * kCols + 16 * h);
-        float a[16], d[15];
+        float d[15];
+        auto load = [&](float (&a)[16]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = src[q];
-            a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
-        }
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = src[q];
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+        };
         bool fast;
-        const float cur = haar16(a, d, __fsqrt_rn((float)kCols), root2, fast);   // (16, 32, 64: the device root is exact for these)
+        const float cur = haar16(load, d, __fsqrt_rn((float)kCols), root2, fast);   // (16, 32, 64: the device root is exact for these)
         // the remaining levels pair the H sixteenths of the row; a lane leaves with its detail value as soon as
         // its index has the level's bit set, sixteenth 0 keeps the row's average
         const float fin = cross_levels<H>(cur, h, root2, fast);
@@ -237,15 +444,17 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     float v[16];
     uint32_t pos[16];
     {
-        float a[16], d[15];
+        float d[15];
         const float4* src = reinterpret_cast<const float4*>(s_t + (col * 8 + j) * kChunkDw);
+        auto load = [&](float (&a)[16]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 x = src[q];
-            a[4 * q] = x.x; a[4 * q + 1] = x.y; a[4 * q + 2] = x.z; a[4 * q + 3] = x.w;
-        }
+            for (int q = 0; q < 4; ++q) {
+                const float4 x = src[q];
+                a[4 * q] = x.x; a[4 * q + 1] = x.y; a[4 * q + 2] = x.z; a[4 * q + 3] = x.w;
+            }
+        };
         bool fast;
-        const float cur = haar16(a, d, __fsqrt_rn((float)kRowsPerFrame), root2, fast);
+        const float cur = haar16(load, d, __fsqrt_rn((float)kRowsPerFrame), root2, fast);
         // levels 5..7 across the 8 chunks of the column; chunk 0 keeps the overall average
         const float fin = cross_levels<8>(cur, j, root2, fast);
 #pragma unroll

@@ -848,6 +848,15 @@ def _frames_cases(rng, cols=32):
     cases["all_equal"] = np.full((128, cols), np.float32(7.5))
     cases["zeros"] = np.zeros((128, cols), np.float32)
     neg = -base; cases["negative"] = neg.astype(np.float32)
+    # the three tiers of the division shortcut (k_haar_select32.hip): inputs around the light guard's 2^-52, and lines whose
+    # sums cancel level after level down to dividends below 2^-100 although every input is ordinary
+    cases["near_light_limit"] = (base * np.float32(2.0 ** -56)).astype(np.float32)      # ~100 x: straddles 2^-52
+    cases["below_light_limit"] = (base * np.float32(2.0 ** -64)).astype(np.float32)
+    ulps = rng.integers(-3, 4, (128, cols)).astype(np.float32)
+    cases["cancelling_levels"] = (np.float32(2.0 ** -45) * (np.float32(1.0) + ulps * np.float32(2.0 ** -23))).astype(np.float32)
+    cases["cancelling_levels_small"] = (np.float32(2.0 ** -70) * (np.float32(1.0) + ulps * np.float32(2.0 ** -23))).astype(np.float32)
+    nan = base.copy(); nan[77, cols - 1] = np.nan
+    cases["one_nan"] = nan
     return cases
 
 

@@ -39,7 +39,7 @@ del frames, raw
 torch.manual_seed(5)
 for bands, n in ((16, 31250), (64, 15625)):
     d2 = lb.Detective().configure(sample_rate=44100, window=1024, bands=bands)
-    fr = (torch.rand(n, 128, bands, device="cuda") ** 4) * 50.0
+    fr = (torch.rand(n, 128, bands, device="cuda") ** 4) * 50.0 + 1e-6
     fr[:, :, ::3] = 0.0
     us, h = run(d2, fr)
     out[f"{bands}_bands_{n}_frames"] = {"us": round(us, 1), "bits": h}
