@@ -1,5 +1,5 @@
-// Issue rate of the double-precision instructions the file converter (k_resample.hip) is made of: 8 independent
-// chains per wave, one and four waves per SIMD.
+// Issue rate of the double-precision instructions the file converter (k_resample.hip) is made of, next to single-precision,
+// packed and integer ones: 8 independent chains per wave, 1 / 2 / 4 / 8 waves per SIMD.
 // build: hipcc --offload-arch=gfx950 -O3 -o f64_rates f64_rates.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,6 +26,8 @@
 #define A_CVTF(d, s) "v_cvt_f64_f32 %" #d ", %" #s "\n"
 #define A_F32(d, s) "v_fma_f32 %" #s ", %" #s ", %17, %" #s "\n"
 #define A_MOV(d, s) "v_mov_b32 %" #s ", %17\n"
+#define A_PK(d, s) "v_pk_fma_f32 %" #d ", %" #d ", %16, %" #d "\n"
+#define A_INT(d, s) "v_lshl_add_u32 %" #s ", %" #s ", 1, %17\n"
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(double* out, int iters, long long* cyc) {
@@ -49,6 +51,8 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, long long* cyc)
     if (OP == 8) { BODY(A_CVTF) }
     if (OP == 9) { BODY(A_F32) }
     if (OP == 10) { BODY(A_MOV) }
+    if (OP == 11) { BODY(A_PK) }
+    if (OP == 12) { BODY(A_INT) }
     const long long t1 = __builtin_readcyclecounter();
     double s = 0;
     for (int i = 0; i < 8; ++i) s += r[i] + f[i];
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void k(double* out, int iters, long long* cyc)
 template <int OP>
 void run(const char* name, double* d_out, long long* d_cyc) {
     const int iters = 2000;
-    for (int waves = 1; waves <= 4; waves *= 4) {            // blocks of 4 waves: 1 or 4 waves per SIMD
+    for (int waves = 1; waves <= 8; waves *= 2) {            // blocks of 4 waves: 1, 2, 4, 8 waves per SIMD
         hipLaunchKernelGGL(k<OP>, dim3(256 * waves), dim3(256), 0, 0, d_out, iters, d_cyc);
         (void)hipDeviceSynchronize();
         hipEvent_t e0, e1;
@@ -82,10 +86,12 @@ void run(const char* name, double* d_out, long long* d_cyc) {
 int main() {
     double* d_out;
     long long* d_cyc;
-    (void)hipMalloc(&d_out, 256 * 4 * 256 * 8);
+    (void)hipMalloc(&d_out, 256 * 8 * 256 * 8);
     (void)hipMalloc(&d_cyc, 8);
     run<9>("v_fma_f32", d_out, d_cyc);
     run<10>("v_mov_b32", d_out, d_cyc);
+    run<12>("v_lshl_add_u32", d_out, d_cyc);
+    run<11>("v_pk_fma_f32", d_out, d_cyc);
     run<0>("v_add_f64", d_out, d_cyc);
     run<1>("v_fma_f64", d_out, d_cyc);
     run<2>("v_mul_f64", d_out, d_cyc);
