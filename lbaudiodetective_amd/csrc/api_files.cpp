@@ -14,9 +14,24 @@
 #include "internal.hpp"
 #include "audiofile.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cmath>
+#include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
+#ifdef LBAD_EXP_FILE_TIMES   // experiment builds: where a batch call spends its host time (stderr, microseconds)
+#include <chrono>
+#define LBAD_T(name) const auto name = std::chrono::steady_clock::now()
+#define LBAD_US(a, b) (long)std::chrono::duration_cast<std::chrono::microseconds>((b) - (a)).count()
+#else
+#define LBAD_T(name)
+#endif
 
 namespace lbad {
 namespace {
@@ -53,6 +68,81 @@ OSStatus grow_pinned(void** ptr, size_t* cap, size_t bytes) {
     *cap = want;
     return noErr;
 }
+
+// The threads that read and parse the files of a batch: started once (a std::thread costs ~20 us to create, sixteen of them
+// were a third of the read phase), parked on a condition variable between calls, shared by every detective of the process.
+class ReadPool {
+public:
+    static ReadPool& get() {
+        static ReadPool pool;
+        return pool;
+    }
+    // fn(0) .. fn(n_tasks - 1), each exactly once, on the pool's threads and the caller's; returns when all are done
+    void run(size_t n_tasks, const std::function<void(size_t, bool)>& fn) {
+        std::lock_guard<std::mutex> one_batch(batch_);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            n_ = n_tasks;
+            next_.store(0);
+            pending_ = threads_.size();
+            ++generation_;
+        }
+        start_.notify_all();
+        for (size_t i; (i = next_.fetch_add(1)) < n_tasks;) fn(i, false);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    size_t threads() const { return threads_.size() + 1; }
+
+private:
+    ReadPool() {
+        unsigned n = std::thread::hardware_concurrency();
+        n = n > 16 ? 16 : n;
+        try {
+            for (unsigned i = 1; i < n; ++i) threads_.emplace_back([this] { work(); });
+        } catch (const std::system_error&) {   // fewer threads than wanted: the caller's thread takes the rest
+        }
+    }
+    ~ReadPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        start_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    void work() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t, bool)>* fn;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                start_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                fn = fn_;
+                n = n_;
+            }
+            for (size_t i; (i = next_.fetch_add(1)) < n;) (*fn)(i, true);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                --pending_;
+            }
+            done_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_, batch_;
+    std::condition_variable start_, done_;
+    const std::function<void(size_t, bool)>* fn_ = nullptr;
+    size_t n_ = 0, pending_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
 
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
@@ -91,6 +181,7 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     if (st == noErr && tbl_words) st = grow_device(&d->d_rs_tail, &d->d_rs_tail_cap, tbl_words * sizeof(uint32_t));
     if (st == noErr) st = grow_pinned(&d->h_packed, &d->h_packed_cap, packed_bytes);
     if (st != noErr) return st;
+    LBAD_T(g0);
     hipStream_t stream = d->io_stream;                             // the payload bytes are on their way on this stream
     float* pcm = static_cast<float*>(d->d_rs_out);
     LBAD_HIP(hipMemsetAsync(pcm, 0, T * sizeof(float), stream));   // the slots' zero padding
@@ -194,7 +285,9 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     if (st != noErr) return st;
     uint32_t* packed = static_cast<uint32_t*>(d->h_packed);
     LBAD_HIP(hipMemcpyAsync(packed, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
+    LBAD_T(g1);
     LBAD_HIP(hipStreamSynchronize(stream));
+    LBAD_T(g2);
     std::vector<Boolean> bools;
     for (size_t i : idx) {
         const Job& j = jobs[i];
@@ -204,6 +297,11 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
                                                  bools.data() + (size_t)s * d->subfp_len);
         out[i] = fingerprint_from_bools(d, bools.data(), j.frames);
     }
+#ifdef LBAD_EXP_FILE_TIMES
+    LBAD_T(g3);
+    fprintf(stderr, "  group of %zu files: tables + launches %ld us, wait for the device %ld us, unpack %ld us\n", idx.size(),
+            LBAD_US(g0, g1), LBAD_US(g1, g2), LBAD_US(g2, g3));
+#endif
     return noErr;
 }
 
@@ -264,6 +362,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     const double rate = d->format.mSampleRate;
     if (!(rate > 0.0)) return kLBAudioDetectiveArgumentInvalid;
     OSStatus st = noErr;
+    LBAD_T(t0);
     std::vector<Job> jobs(n);
 
     // sizes first: a missing or unreadable file is reported as such whether or not a device exists (like
@@ -272,11 +371,9 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     for (size_t i = 0; i < n; ++i) {
         Job& j = jobs[i];
         if (!paths[i]) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }       // :211-214
-        FILE* f = std::fopen(paths[i], "rb");
-        if (!f) { j.st = -43; continue; }                                             // fnfErr
-        std::fseek(f, 0, SEEK_END);
-        const long sz = std::ftell(f);
-        std::fclose(f);
+        struct stat sb;
+        if (::stat(paths[i], &sb) != 0) { j.st = -43; continue; }                     // fnfErr
+        const long long sz = (long long)sb.st_size;
         if (sz <= 0) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
         j.file_size = (uint64_t)sz;
         any = true;
@@ -298,6 +395,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     }
     // the files of a call go through in runs of at most 512 MB of file bytes: read straight into ONE pinned block
     // (threads), parsed in place, uploaded with one copy
+    LBAD_T(t1);
     const uint64_t kRunBytes = 512ull << 20;
     std::vector<bool> done(n, false);
     const uint64_t frame_bytes = (uint64_t)kRowsPerFrame * d->bands * sizeof(float);
@@ -321,53 +419,67 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
             continue;
         }
         uint8_t* stage = static_cast<uint8_t*>(d->h_files);
-        auto read_range = [&](size_t b, size_t e) {
+        int device = 0;
+        (void)hipGetDevice(&device);
+        std::atomic<int> upload_error{0};
+        // every worker reads its files (read(2) straight into the pinned block), parses them in place and sends ITS part of
+        // the block on its way: the uploads of the first workers overlap the reads of the last
+        auto read_range = [&](size_t b, size_t e, bool own_thread) {
+            if (own_thread) (void)hipSetDevice(device);
+            uint64_t lo = ~0ull, hi = 0;
             for (size_t i = b; i < e; ++i) {
                 Job& j = jobs[i];
                 if (j.st != noErr) continue;
-                FILE* f = std::fopen(paths[i], "rb");
-                const size_t got = f ? std::fread(stage + j.file_off, 1, j.file_size, f) : 0;
-                if (f) std::fclose(f);
-                if (got != j.file_size) { j.st = f ? kLBAudioDetectiveUnsupportedFile : -43; continue; }
+                if (j.file_off < lo) lo = j.file_off;
+                if (j.file_off + j.file_size > hi) hi = j.file_off + j.file_size;
+                const int fd = ::open(paths[i], O_RDONLY | O_CLOEXEC);
+                uint64_t got = 0;
+                while (fd >= 0 && got < j.file_size) {
+                    const ssize_t r = ::read(fd, stage + j.file_off + got, j.file_size - got);
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                if (fd >= 0) ::close(fd);
+                if (got != j.file_size) { j.st = fd >= 0 ? kLBAudioDetectiveUnsupportedFile : -43; continue; }
                 const AudioFileStatus fs = parse_audio_bytes(stage + j.file_off, j.file_size, j.a);
                 if (fs != AudioFileStatus::Ok) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
                 if (!resample_plan(j.a.count, j.a.sample_rate, rate, d->resampler, j.rp)) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }
                 j.n_client = j.a.count == 0 ? 0 : j.rp.n_out;
                 j.bytes0 = j.file_off + j.a.off;
             }
+            if (hi > lo) {
+                const hipError_t err = hipMemcpyAsync(static_cast<uint8_t*>(d->d_rs_bytes) + lo, stage + lo, hi - lo, hipMemcpyHostToDevice, d->io_stream);
+                if (err != hipSuccess) upload_error.store((int)err);
+            }
         };
-        unsigned workers = std::thread::hardware_concurrency();
-        if (workers > 8) workers = 8;
         const size_t count = run_e - run_b;
-        if (count < 4 || workers < 2) {
-            read_range(run_b, run_e);
+        if (count < 4) {
+            read_range(run_b, run_e, false);
         } else {
-            std::vector<std::thread> pool;
-            const size_t per = (count + workers - 1) / workers;
-            size_t next = run_b + per;
-            try {
-                for (unsigned w = 1; w < workers && next < run_e; ++w) {
-                    const size_t e = next + per < run_e ? next + per : run_e;
-                    pool.emplace_back(read_range, next, e);
-                    next = e;
-                }
-            } catch (const std::system_error&) {
-            }
-            read_range(run_b, run_b + per < run_e ? run_b + per : run_e);
-            if (next < run_e) read_range(next, run_e);
-            for (std::thread& t : pool) t.join();
+            ReadPool& pool = ReadPool::get();
+            const size_t per = (count + 2 * pool.threads() - 1) / (2 * pool.threads());    // about two tasks per thread
+            const size_t n_tasks = (count + per - 1) / per;
+            pool.run(n_tasks, [&](size_t task, bool own_thread) {
+                const size_t b = run_b + task * per, e = b + per < run_e ? b + per : run_e;
+                read_range(b, e, own_thread);
+            });
         }
-        if (total) {
-            const hipError_t e = hipMemcpyAsync(d->d_rs_bytes, stage, total, hipMemcpyHostToDevice, d->io_stream);
-            if (e != hipSuccess) {
-                st = hip_status(e, "payload upload", __LINE__);
-                for (size_t i = run_b; i < run_e; ++i)
-                    if (jobs[i].st == noErr) jobs[i].st = st;
-                run_b = run_e;
-                continue;
-            }
+        LBAD_T(t2);
+        if (upload_error.load() != 0) {
+            st = hip_status((hipError_t)upload_error.load(), "payload upload", __LINE__);
+            (void)hipStreamSynchronize(d->io_stream);
+            for (size_t i = run_b; i < run_e; ++i)
+                if (jobs[i].st == noErr) jobs[i].st = st;
+            run_b = run_e;
+            continue;
         }
+        LBAD_T(t3);
         process_run(d, jobs, run_b, run_e, budget, done, out);
+#ifdef LBAD_EXP_FILE_TIMES
+        LBAD_T(t4);
+        fprintf(stderr, "run of %zu files, %llu bytes: sizes + plan %ld us, read + parse %ld us, upload call %ld us, groups %ld us\n",
+                run_e - run_b, (unsigned long long)total, LBAD_US(t0, t1), LBAD_US(t1, t2), LBAD_US(t2, t3), LBAD_US(t3, t4));
+#endif
         run_b = run_e;
     }
     OSStatus first = noErr;

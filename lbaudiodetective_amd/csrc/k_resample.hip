@@ -91,6 +91,7 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
         s_stat[2] = 0u;
         s_stat[3] = 0x7FFFFFFFu;                              // smallest first tap (as int)
         s_stat[4] = 0x80000001u;                              // largest last tap (as int)
+        s_stat[5] = 0xFFFFFFFFu;                              // smallest tap count
     }
     __syncthreads();
     if (active) {
@@ -99,6 +100,7 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
         atomicMin(&s_stat[0], q);
         atomicMax(&s_stat[1], q + 1u);
         atomicMax(&s_stat[2], (uint32_t)(k1 - k0 + 1));
+        atomicMin(&s_stat[5], (uint32_t)(k1 - k0 + 1));
         atomicMin(reinterpret_cast<int*>(&s_stat[3]), (int)(k0 < -2147483647L ? -2147483647L : (k0 > 2147483647L ? 2147483647L : k0)));
         atomicMax(reinterpret_cast<int*>(&s_stat[4]), (int)(k1 < -2147483647L ? -2147483647L : (k1 > 2147483647L ? 2147483647L : k1)));
     }
@@ -128,6 +130,33 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
     double acc = 0.0, wsum = 0.0;
     double kd = (double)k0;
     long k = k0;
+    uint32_t worst = 0;
+    const int min_taps = (int)s_stat[5];
+    // coord >= 1 table point per input sample and half * coord < 2^31: what the untested rows below rely on
+    const bool fast_ok = stage_in && coord >= 1.0 && half * coord < 2147483648.0 && kend - kbase < 0x7FFFFFFFl;
+    // one tap with every test (the host loop's tap, audiofile.cpp)
+    auto general_tap = [&](int r) {
+        if (!active || k > k1) return;
+        const double t = fabs(kd - pos) * coord;              // table coordinate
+        const uint32_t i = (uint32_t)t;
+        const bool ok = i + 1u < tn && t < 4294967040.0;
+        const uint32_t idx = i - s_lo[r];
+        double ta, tb;
+        if (idx < (uint32_t)(kRowLen - 1)) {                   // unsigned: also false when i < s_lo[r]
+            ta = s_rows[r][idx];
+            tb = s_rows[r][idx + 1u];
+        } else {
+            const uint32_t ic = ok ? i : 0u;
+            ta = table[ic];
+            tb = table[ic + 1u];
+        }
+        const double w = ok ? ta + (tb - ta) * (t - (double)i) : 0.0;
+        wsum += w;
+        const bool inside = k >= 0 && (uint64_t)k < n_in;
+        const long q = k - kbase;
+        const float x = stage_in ? s_in[q + (q >> 6)] : (inside ? in[(uint64_t)k] : 0.0f);
+        acc += w * (ok && inside ? (double)x : 0.0);           // + (+-0.0) leaves acc as it is (acc is never -0.0)
+    };
     for (int g0 = 0; g0 < n_taps; g0 += kTapGroup) {
         __syncthreads();
         if (threadIdx.x < kTapGroup) {                        // first staged point of row r: 2 points below the smallest index
@@ -144,29 +173,36 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
         }
         __syncthreads();
         const int rows = n_taps - g0 < kTapGroup ? n_taps - g0 : kTapGroup;
-        for (int r = 0; r < rows; ++r, ++k, kd += 1.0) {
-            if (!active || k > k1) continue;
-            const double t = fabs(kd - pos) * coord;          // table coordinate
-            const uint32_t i = (uint32_t)t;
-            const bool ok = i + 1u < tn && t < 4294967040.0;
-            const uint32_t idx = i - s_lo[r];
-            double ta, tb;
-            if (idx < (uint32_t)(kRowLen - 1)) {               // unsigned: also false when i < s_lo[r]
-                ta = s_rows[r][idx];
-                tb = s_rows[r][idx + 1u];
-            } else {
-                const uint32_t ic = ok ? i : 0u;
-                ta = table[ic];
-                tb = table[ic + 1u];
+        // Rows every lane of the block treats alike -- not a lane's first tap, not one of its last two, the inputs staged,
+        // the table coordinate far below 2^32 -- run without a test per tap: such a tap lies inside its lane's span
+        // (k0 < k < k1), so the table covers it (|k - pos| <= half - 1: a whole input sample = coord >= 1 table points
+        // short of the end), a sample outside the file was staged as +0.0, and t - (double)i is v_fract_f64 (the exact
+        // difference either way).  The one thing checked is that the two table points came from the staged run: the
+        // largest offset met is kept, and a lane that left the run recomputes its sample the plain way afterwards.
+        int r = 0;
+        if (fast_ok) {
+            const uint32_t my_lo = s_lo[(threadIdx.x & 63u) < (uint32_t)kTapGroup ? (threadIdx.x & 63u) : 0u];
+            const int r_begin = g0 == 0 ? 1 : 0;
+            const int r_end = min_taps - 2 - g0 < rows ? min_taps - 2 - g0 : rows;       // taps g0 + r <= min_taps - 3
+            for (; r < r_begin && r < rows; ++r, ++k, kd += 1.0) general_tap(r);
+            uint32_t q = (uint32_t)(k - kbase);
+            for (; r < r_end; ++r, kd += 1.0, ++q) {             // (unrolling by hand changes nothing: the loop is issue-bound)
+                const double t = fabs(kd - pos) * coord;
+                const uint32_t i = (uint32_t)t;
+                const uint32_t idx = i - (uint32_t)__builtin_amdgcn_readlane((int)my_lo, r);
+                worst = idx > worst ? idx : worst;
+                const double* row = &s_rows[r][idx < (uint32_t)(kRowLen - 1) ? idx : 0u];
+                const double ta = row[0], tb = row[1];
+                const double w = ta + (tb - ta) * __builtin_amdgcn_fract(t);
+                wsum += w;
+                acc += w * (double)s_in[q + (q >> 6)];
             }
-            const double w = ok ? ta + (tb - ta) * (t - (double)i) : 0.0;
-            wsum += w;
-            const bool inside = k >= 0 && (uint64_t)k < n_in;
-            const long q = k - kbase;
-            const float x = stage_in ? s_in[q + (q >> 6)] : (inside ? in[(uint64_t)k] : 0.0f);
-            acc += w * (ok && inside ? (double)x : 0.0);       // + (+-0.0) leaves acc as it is (acc is never -0.0)
+            k = kbase + (long)q;
         }
+        for (; r < rows; ++r, ++k, kd += 1.0) general_tap(r);
     }
+    if (worst >= (uint32_t)(kRowLen - 1))                     // (never seen: the runs are placed with two points to spare)
+        return active ? sinc_sample(in, n_in, ratio, scale, half, res, table, table_n, n) : 0.0f;
     return (float)(wsum != 0.0 ? acc / wsum : 0.0);
 }
 
@@ -191,7 +227,9 @@ __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc
         } else if (f.mode == 2) {
             if (active) v = linear_sample(in, f.n_in, f.ratio, n);
         } else {
-            v = sinc_sample_tiled(in, f.n_in, f.ratio, f.scale, f.half, res, table, table_n, n, active, s_rows, s_lo, s_stat, s_in);
+            // (a lane past the end works on the file's last sample, so that every lane reads inside the staged runs)
+            v = sinc_sample_tiled(in, f.n_in, f.ratio, f.scale, f.half, res, table, table_n, active ? n : f.n_write - 1, active,
+                                  s_rows, s_lo, s_stat, s_in);
         }
         if (active) out[n] = v;
     }
