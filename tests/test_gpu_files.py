@@ -113,3 +113,28 @@ def test_compare_audio_urls_is_one_batch_of_two(lb, gpu, oracle):
     with pytest.raises(lb.LBAudioDetectiveError) as e:
         det.compare_audio_urls(a, "/nonexistent.caf")                         # the SECOND file's status (D.m:449-456)
     assert e.value.status == -43
+
+
+def test_batch_larger_than_one_pinned_run(lb, gpu, tmp_path):
+    """More than 512 MB of files in one call: the batch goes through in RUNS of the pinned block (api_files.cpp), each read
+    by the pooled readers, uploaded in parts and processed before the next is read.  Files on both sides of the run
+    boundary must equal their single-file results."""
+    rng = np.random.default_rng(77)
+    contents = []
+    for k in range(3):
+        n = 8_400_000 + 1000 * k                                            # ~16.8 MB of int16 each
+        x = (rng.standard_normal(n) * 2500 + 7000 * np.sin(np.arange(n) * (0.02 + 0.004 * k))).astype(np.int16)
+        p = str(tmp_path / f"big{k}.wav")
+        _wav(p, x, 11025)
+        contents.append(p)
+    paths = []
+    for i in range(33):                                                     # 33 x 16.8 MB = 554 MB: two runs
+        q = str(tmp_path / f"f{i:02d}.wav")
+        os.link(contents[i % 3], q)
+        paths.append(q)
+    det = lb.Detective()
+    fps, sts = det.process_audio_urls(paths, statuses=True)
+    assert sts == [0] * len(paths)
+    singles = {i: det.process_audio_url(paths[i]) for i in (0, 1, 2)}
+    for i, fp in enumerate(fps):
+        assert fp.number_of_subfingerprints > 0 and fp.equal_to_fingerprint(singles[i % 3]), i
