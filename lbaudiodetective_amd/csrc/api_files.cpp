@@ -3,7 +3,7 @@
 // Upstream fingerprints a file by seeking and reading it window by window through ExtAudioFile
 // (LBAudioDetective/LBAudioDetective.m:208-308); its test suite does that 200 times per test
 // (LBAudioDetectiveTests/LBAudioDetectiveTests.m:57-91).  Here any number of files goes through ONE launch chain:
-//   host    containers parsed (threads), every payload copied into one pinned block, one upload
+//   host    files read into one pinned block and parsed in place by a pool of reader threads, each uploading its part
 //   device  payload decode (k_decode.hip) and sample-rate conversion (k_resample.hip) of every file straight into
 //           its slot of ONE float32 clip; stage 1 over that clip; the files' end-of-file rows; stage 2; 32 bytes per
 //           sub-fingerprint come back
@@ -394,7 +394,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
         }
     }
     // the files of a call go through in runs of at most 512 MB of file bytes: read straight into ONE pinned block
-    // (threads), parsed in place, uploaded with one copy
+    // (pooled threads), parsed in place, uploaded part by part
     LBAD_T(t1);
     const uint64_t kRunBytes = 512ull << 20;
     std::vector<bool> done(n, false);
