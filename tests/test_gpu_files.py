@@ -138,3 +138,34 @@ def test_batch_larger_than_one_pinned_run(lb, gpu, tmp_path):
     singles = {i: det.process_audio_url(paths[i]) for i in (0, 1, 2)}
     for i, fp in enumerate(fps):
         assert fp.number_of_subfingerprints > 0 and fp.equal_to_fingerprint(singles[i % 3]), i
+
+
+def test_file_batches_from_several_threads(lb, gpu, oracle):
+    """The reader pool is shared by every detective of the process and a detective may be called from several threads:
+    three threads (two on ONE detective, one on its own) run batch calls at the same time; every result is the
+    oracle's."""
+    import threading
+    paths = _all_birds()[:24]
+    cfg = oracle.Config()
+    want = [oracle.fingerprint_file(p, cfg) for p in paths[:6]]
+    shared, own = lb.Detective(), lb.Detective()
+    errors = []
+
+    def worker(det, first):
+        try:
+            for it in range(6):
+                sub = paths[first:] + paths[:first]
+                fps = det.process_audio_urls(sub)
+                for i in range(6):
+                    k = (i - first) % len(paths)
+                    got = fps[k].to_bools()
+                    assert got.shape == want[i].shape and np.array_equal(got, want[i]), (first, it, i)
+        except BaseException as e:                                    # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(d, f)) for d, f in ((shared, 0), (shared, 5), (own, 11))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
