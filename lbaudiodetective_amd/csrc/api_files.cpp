@@ -288,14 +288,26 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     LBAD_T(g1);
     LBAD_HIP(hipStreamSynchronize(stream));
     LBAD_T(g2);
-    std::vector<Boolean> bools;
-    for (size_t i : idx) {
-        const Job& j = jobs[i];
-        bools.assign((size_t)j.frames * d->subfp_len, 0);
-        for (uint64_t s = 0; s < j.frames; ++s)
-            LBAudioDetectiveUnpackSubfingerprint(packed + (j.frame0 + s) * LBAD_PACKED_WORDS, d->subfp_len,
-                                                 bools.data() + (size_t)s * d->subfp_len);
-        out[i] = fingerprint_from_bools(d, bools.data(), j.frames);
+    // 32 bytes per sub-fingerprint back into upstream's Boolean rows: a few files per task on the reader pool
+    auto unpack = [&](size_t k_begin, size_t k_end) {
+        std::vector<Boolean> bools;
+        for (size_t k = k_begin; k < k_end; ++k) {
+            const size_t i = idx[k];
+            const Job& j = jobs[i];
+            bools.assign((size_t)j.frames * d->subfp_len, 0);
+            for (uint64_t s = 0; s < j.frames; ++s)
+                LBAudioDetectiveUnpackSubfingerprint(packed + (j.frame0 + s) * LBAD_PACKED_WORDS, d->subfp_len,
+                                                     bools.data() + (size_t)s * d->subfp_len);
+            out[i] = fingerprint_from_bools(d, bools.data(), j.frames);
+        }
+    };
+    constexpr size_t kPerTask = 4;
+    if (idx.size() < 4 * kPerTask) {
+        unpack(0, idx.size());
+    } else {
+        ReadPool::get().run((idx.size() + kPerTask - 1) / kPerTask, [&](size_t task, bool) {
+            unpack(task * kPerTask, (task + 1) * kPerTask < idx.size() ? (task + 1) * kPerTask : idx.size());
+        });
     }
 #ifdef LBAD_EXP_FILE_TIMES
     LBAD_T(g3);
