@@ -138,8 +138,9 @@ OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, LBAud
 #endif
 
 /* Addition: many files in one call -- upstream's tests fingerprint 200 files per test, one call each
- * (LBAudioDetectiveTests.m:57-91).  Every payload is uploaded at once and decode, conversion, the window loop and
- * the Haar / sign stage of ALL files run as one launch chain (one per distinct hop when the files' sample rates
+ * (LBAudioDetectiveTests.m:57-91).  The files are read and parsed by a pool of up to 16 threads that the library starts
+ * on the first batch of four or more files and keeps for the life of the process (shared by all detectives); decode,
+ * conversion, the window loop and the Haar / sign stage of ALL files run as one launch chain (one per distinct hop when the files' sample rates
  * differ); the converted samples never leave the device.  outFingerprints[i] is what
  * LBAudioDetectiveProcessAudioURL returns for file i (NULL if it failed); outStatuses (optional) receives every
  * file's status, and the call then returns noErr whenever the batch itself could run; without it the first
