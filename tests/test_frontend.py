@@ -204,6 +204,8 @@ def test_fingerprint_string_round_trip(lb):
     fp = lb.Fingerprint.from_bools(rows)
     text = fp.to_string()
     assert text == "+".join("".join(map(str, r)) for r in rows)          # LBAudioDetectiveTests.m:22-37
+    # the helper's format written out by hand: "%i" per Boolean, sub-fingerprints joined by "+"
+    assert lb.Fingerprint.from_bools(np.array([[0, 1, 1], [1, 0, 0]], np.uint8)).to_string() == "011+100"
     back = lb.Fingerprint.from_string(text)
     assert back.equal_to_fingerprint(fp)
     assert lb.Fingerprint(0).to_string() == "" and lb.Fingerprint.from_string("").number_of_subfingerprints == 0
