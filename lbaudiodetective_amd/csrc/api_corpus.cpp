@@ -49,11 +49,13 @@ OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFinge
     uint32_t* dq = c->d_query + (size_t)slot * c->query_slot_words;
     std::memcpy(h, block.data(), block.size() * sizeof(uint32_t));
     LBAD_HIP(hipMemcpyAsync(dq, h, block.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    LBAD_HIP(hipEventRecord(c->query_ev[slot], stream));
     LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
     if (d_scores) LBAD_HIP(hipMemsetAsync(d_scores, 0, c->count * sizeof(float), stream));
     LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, c->subfp_len, dq, q->count, range,
                                     index_base, reinterpret_cast<unsigned int*>(d_scores), key_dst, stream));
+    // behind the SCAN, not just the copy: the slot's device half is read by the kernel, and the query that reuses the
+    // slot eight calls later may arrive on another stream
+    LBAD_HIP(hipEventRecord(c->query_ev[slot], stream));
     return noErr;
 }
 
