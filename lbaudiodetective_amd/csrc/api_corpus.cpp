@@ -82,6 +82,7 @@ OSStatus run_query_impl(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerp
         return noErr;
     }
     if (c->query_cap < slots.size()) {
+        if (c->query_ev[0]) LBAD_HIP(hipEventSynchronize(c->query_ev[0]));
         if (c->d_query) (void)hipFree(c->d_query);
         if (c->h_query) (void)hipHostFree(c->h_query);
         c->d_query = nullptr;
@@ -91,12 +92,15 @@ OSStatus run_query_impl(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerp
         LBAD_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_query), slots.size() * sizeof(uint32_t), hipHostMallocDefault));
         c->query_cap = (uint32_t)slots.size();
     }
-    // the pinned staging block is reused by every query: wait for the previous one's copy
-    LBAD_HIP(hipStreamSynchronize(stream));
+    // the staging block and its device copy are reused by every query: wait for the previous one's SCAN (whatever
+    // stream it ran on; slot 0 of the ragged ring's events serves this path, a corpus is either ragged or not)
+    if (!c->query_ev[0]) LBAD_HIP(hipEventCreateWithFlags(&c->query_ev[0], hipEventDisableTiming));
+    else LBAD_HIP(hipEventSynchronize(c->query_ev[0]));
     std::memcpy(c->h_query, slots.data(), slots.size() * sizeof(uint32_t));
     LBAD_HIP(hipMemcpyAsync(c->d_query, c->h_query, slots.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     LBAD_HIP(launch_compare_planes_generic(c->d_planes, c->capacity, c->count, c->n_sub, c->subfp_len, c->d_query,
                                            q->count, range, index_base, d_scores, key_dst, stream));
+    LBAD_HIP(hipEventRecord(c->query_ev[0], stream));
     return noErr;
 }
 
