@@ -15,6 +15,7 @@
 #include "audiofile.hpp"
 
 #include <fcntl.h>
+#include <pthread.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -73,12 +74,21 @@ OSStatus grow_pinned(void** ptr, size_t* cap, size_t bytes) {
 // were a third of the read phase), parked on a condition variable between calls, shared by every detective of the process.
 class ReadPool {
 public:
+    // never destroyed: its threads sleep on a condition variable until the process ends.  In a child of fork() the
+    // threads do not exist; the child runs its tasks on the calling thread.
     static ReadPool& get() {
-        static ReadPool pool;
-        return pool;
+        static ReadPool* pool = [] {
+            (void)pthread_atfork(nullptr, nullptr, [] { forked().store(true); });
+            return new ReadPool;
+        }();
+        return *pool;
     }
     // fn(0) .. fn(n_tasks - 1), each exactly once, on the pool's threads and the caller's; returns when all are done
     void run(size_t n_tasks, const std::function<void(size_t, bool)>& fn) {
+        if (forked().load()) {
+            for (size_t i = 0; i < n_tasks; ++i) fn(i, false);
+            return;
+        }
         std::lock_guard<std::mutex> one_batch(batch_);
         {
             std::lock_guard<std::mutex> g(m_);
@@ -105,13 +115,9 @@ private:
         } catch (const std::system_error&) {   // fewer threads than wanted: the caller's thread takes the rest
         }
     }
-    ~ReadPool() {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        start_.notify_all();
-        for (std::thread& t : threads_) t.join();
+    static std::atomic<bool>& forked() {
+        static std::atomic<bool> f{false};
+        return f;
     }
     void work() {
         uint64_t seen = 0;
