@@ -504,12 +504,17 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         if (c >= keep) { lo = mid; cnt_lo = c; } else { hi = mid; }
     }
     STAMP(3);
+    // |v| bits above / equal to the threshold, in the keys' doubled domain (no shift of the keys: the compiler would
+    // hoist sixteen of them in front of the rare paths that need them)
+    const uint32_t lo2 = lo << 1;
+    auto above = [&](uint32_t k) { return lo != 0x7FFFFFFFu && k >= lo2 + 2u; };
+    auto tied = [&](uint32_t k) { return k - lo2 < 2u; };
     if (cnt_lo > kCand) {
         // plateau: more than kCand coefficients share the threshold key (e.g. digital silence).  Take
         // every key above it, then the tied ones in ascending flat-index order until `keep` is reached.
         uint32_t g = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) g += (key[i] >> 1) > lo ? 1u : 0u;
+        for (int i = 0; i < 16; ++i) g += above(key[i]) ? 1u : 0u;
         g = block_sum<kWavesPerWg>(g, s_red, parity);
         parity ^= 1;
         uint32_t ilo = 0, ihi = kRowsPerFrame * kCols;
@@ -517,7 +522,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
             const uint32_t im = ilo + ((ihi - ilo) >> 1);
             uint32_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) c += ((key[i] >> 1) == lo && pos[i] * kCols + col < im) ? 1u : 0u;
+            for (int i = 0; i < 16; ++i) c += (tied(key[i]) && pos[i] * kCols + col < im) ? 1u : 0u;
             c = block_sum<kWavesPerWg>(c, s_red, parity);
             parity ^= 1;
             if (g + c >= keep) ihi = im; else ilo = im + 1;
@@ -559,7 +564,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         // (workgroup-uniform) without a plateau one compare per key decides; two copies of the loop, so that the masks
         // stay in scalar registers
         if (idx_bound == kRowsPerFrame * kCols) gather([&](int i) { return key[i] >= (lo << 1); });
-        else gather([&](int i) { return (key[i] >> 1) > lo || ((key[i] >> 1) == lo && pos[i] * kCols + col < idx_bound); });
+        else gather([&](int i) { return above(key[i]) || (tied(key[i]) && pos[i] * kCols + col < idx_bound); });
     }
     __syncthreads();
     const uint32_t nc = s_ncand;
