@@ -442,7 +442,6 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     // ---- column pass: thread = (column, chunk of 16 rows) -----------------------------------------
     const int col = t >> 3, j = t & 7;
     float v[16];
-    uint32_t pos[16];
     {
         float d[15];
         const float4* src = reinterpret_cast<const float4*>(s_t + (col * 8 + j) * kChunkDw);
@@ -458,20 +457,31 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         // levels 5..7 across the 8 chunks of the column; chunk 0 keeps the overall average
         const float fin = cross_levels<8>(cur, j, root2, fast);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { v[i] = d[i]; pos[i] = 64 + 8 * j + i; }
+        for (int i = 0; i < 8; ++i) v[i] = d[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { v[8 + i] = d[8 + i]; pos[8 + i] = 32 + 4 * j + i; }
-        v[12] = d[12]; pos[12] = 16 + 2 * j;
-        v[13] = d[13]; pos[13] = 17 + 2 * j;
-        v[14] = d[14]; pos[14] = 8 + j;
-        // chunk -> ordered position of its cross-lane value: 0,4,2,5,1,6,3,7
-        const uint32_t cross = (j & 1) ? 4u + (j >> 1) : (j & 2) ? 2u + (j >> 2) : (j ? 1u : 0u);
-        v[15] = fin; pos[15] = cross;
+        for (int i = 0; i < 4; ++i) v[8 + i] = d[8 + i];
+        v[12] = d[12];
+        v[13] = d[13];
+        v[14] = d[14];
+        v[15] = fin;
     }
+    // Ordered row position of the thread's i-th coefficient (levels 1..4 of its chunk, then the cross-lane value: chunk ->
+    // 0,4,2,5,1,6,3,7).  Only the optional Haar tap and the plateau path need it; `jj` comes through an empty asm there so
+    // that the compiler cannot compute the sixteen positions ahead of the branch for every frame.
+    auto pos_of = [](int i, uint32_t jj) -> uint32_t {
+        return i < 8 ? 64u + 8u * jj + (uint32_t)i : i < 12 ? 32u + 4u * jj + (uint32_t)(i - 8) : i < 14 ? 16u + 2u * jj + (uint32_t)(i - 12)
+             : i == 14 ? 8u + jj : ((jj & 1u) ? 4u + (jj >> 1) : (jj & 2u) ? 2u + (jj >> 2) : (jj ? 1u : 0u));
+    };
+    auto opaque_j = [&]() -> uint32_t {
+        uint32_t jj = (uint32_t)j;
+        asm volatile("" : "+v"(jj));
+        return jj;
+    };
     if (haar_out) {
         float* dst = haar_out + frame * (kRowsPerFrame * kCols);
+        const uint32_t jj = opaque_j();
 #pragma unroll
-        for (int i = 0; i < 16; ++i) dst[pos[i] * kCols + col] = v[i];
+        for (int i = 0; i < 16; ++i) dst[pos_of(i, jj) * kCols + col] = v[i];
     }
 
     // key = the value's bits rotated left by one: |v| bits in the upper 31 bits, the sign in bit 0.  key >= 2 m  <=>
@@ -517,12 +527,13 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         for (int i = 0; i < 16; ++i) g += above(key[i]) ? 1u : 0u;
         g = block_sum<kWavesPerWg>(g, s_red, parity);
         parity ^= 1;
+        const uint32_t jp = opaque_j();
         uint32_t ilo = 0, ihi = kRowsPerFrame * kCols;
         while (ilo < ihi) {
             const uint32_t im = ilo + ((ihi - ilo) >> 1);
             uint32_t c = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) c += (tied(key[i]) && pos[i] * kCols + col < im) ? 1u : 0u;
+            for (int i = 0; i < 16; ++i) c += (tied(key[i]) && pos_of(i, jp) * kCols + col < im) ? 1u : 0u;
             c = block_sum<kWavesPerWg>(c, s_red, parity);
             parity ^= 1;
             if (g + c >= keep) ihi = im; else ilo = im + 1;
@@ -540,31 +551,39 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     {
         const uint32_t origin = ((uint32_t)col << 7) | (uint32_t)j;    // + (i << 3): index into s_pos, column above it
         auto gather = [&](auto selected) {
-            // the lane masks are taken once and kept (scalar registers)
-            unsigned long long mask[16];
-            uint32_t wave_total = 0;
+            // the lane masks are taken once and kept (scalar registers) -- eight at a time, with one LDS atomic per wave and
+            // half: sixteen masks at once push the kernel's arguments out of the scalar registers (v_writelane spills)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                mask[i] = __ballot(selected(i));
-                wave_total += (uint32_t)__popcll(mask[i]);
-            }
-            uint32_t base = 0;
-            if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
-            base = __builtin_amdgcn_readfirstlane(base);
+            for (int h0 = 0; h0 < 16; h0 += 8) {
+                unsigned long long mask[8];
+                uint32_t wave_total = 0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const unsigned long long m = mask[i];
-                if (selected(i)) {
-                    const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    s_cand[at] = ((unsigned long long)key[i] << 32) | (origin + (uint32_t)(i << 3));
+                for (int i = 0; i < 8; ++i) {
+                    mask[i] = __ballot(selected(h0 + i));
+                    wave_total += (uint32_t)__popcll(mask[i]);
                 }
-                base += (uint32_t)__popcll(m);
+                if (wave_total == 0) continue;                              // (wave-uniform)
+                uint32_t base = 0;
+                if ((t & 63) == 0) base = atomicAdd(&s_ncand, wave_total);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned long long m = mask[i];
+                    if (selected(h0 + i)) {
+                        const uint32_t at = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        s_cand[at] = ((unsigned long long)key[h0 + i] << 32) | (origin + (uint32_t)((h0 + i) << 3));
+                    }
+                    base += (uint32_t)__popcll(m);
+                }
             }
         };
         // (workgroup-uniform) without a plateau one compare per key decides; two copies of the loop, so that the masks
         // stay in scalar registers
         if (idx_bound == kRowsPerFrame * kCols) gather([&](int i) { return key[i] >= (lo << 1); });
-        else gather([&](int i) { return above(key[i]) || (tied(key[i]) && pos[i] * kCols + col < idx_bound); });
+        else {
+            const uint32_t jg = opaque_j();
+            gather([&](int i) { return above(key[i]) || (tied(key[i]) && pos_of(i, jg) * kCols + col < idx_bound); });
+        }
     }
     __syncthreads();
     const uint32_t nc = s_ncand;
