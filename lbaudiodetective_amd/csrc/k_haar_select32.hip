@@ -329,21 +329,37 @@ __device__ __forceinline__ float haar16(Load load, float (&d)[15], float root, f
 // lower lane of a pair continues with (lo + hi) / sqrt 2 and the upper one leaves with (lo - hi) / sqrt 2: ONE
 // division per lane and level (until round 3 both lanes computed both).  lo - hi is formed as lo + (-hi), the same
 // float for every input.  Returns the coefficient the lane ends up owning.
-template <bool FAST, int LANES>
-__device__ __forceinline__ float cross_levels_impl(float cur, int h, float root2, float r_root2, DivGuard& g) {
-    float fin = 0.0f;
-    bool done = false;
-#pragma unroll
-    for (int m = 1; m < LANES; m <<= 1) {
-        const float other = __shfl_xor(cur, m, 64);
-        const bool upper = (h & m) != 0;
+// the value of lane (id ^ M), M = 1, 2, 4: a DPP quad permutation or a ds_swizzle -- no address register, no bounds
+// logic (what __shfl_xor compiles to: compare, select, shift, ds_bpermute)
+template <int M>
+__device__ __forceinline__ float lane_xor(float x) {
+    static_assert(M == 1 || M == 2 || M == 4, "lane distance");
+    const int i = __float_as_int(x);
+    if constexpr (M == 1) return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true));         // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __int_as_float(__builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    else return __int_as_float(__builtin_amdgcn_ds_swizzle(i, 0x101F));                                      // bit mode: and 0x1F, xor 4
+}
+
+template <bool FAST, int LANES, int M = 1>
+__device__ __forceinline__ void cross_level_step(float& cur, float& fin, bool& done, int h, float root2, float r_root2, DivGuard& g) {
+    if constexpr (M < LANES) {
+        const float other = lane_xor<M>(cur);
+        const bool upper = (h & M) != 0;
         const float lo = upper ? other : cur, hi = upper ? -cur : other;
         const float s = __fadd_rn(lo, hi);
         if constexpr (FAST) g.dividends(s, s);
         const float q = div_c<FAST>(s, root2, r_root2);
         if (!done && upper) { fin = q; done = true; }
         cur = q;
+        cross_level_step<FAST, LANES, 2 * M>(cur, fin, done, h, root2, r_root2, g);
     }
+}
+
+template <bool FAST, int LANES>
+__device__ __forceinline__ float cross_levels_impl(float cur, int h, float root2, float r_root2, DivGuard& g) {
+    float fin = 0.0f;
+    bool done = false;
+    cross_level_step<FAST, LANES>(cur, fin, done, h, root2, r_root2, g);
     if (!done) fin = cur;   // lane 0 keeps the line's average
     return fin;
 }
