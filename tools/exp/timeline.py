@@ -16,6 +16,10 @@ import collections
 import numpy as np
 import torch
 
+import os, sys
+from lbaudiodetective_amd import _native as _N
+if len(sys.argv) > 1:
+    _N.LIB_PATH = os.path.abspath(sys.argv[1])
 import lbaudiodetective_amd as lb
 
 det = lb.Detective().configure(sample_rate=44100.0, window=1024, stride=64)
