@@ -75,6 +75,45 @@ def algorithmic_bytes_per_clip(n_samples: int, window: int, stride: int) -> int:
     return 4 * n_samples + 25 * per
 
 
+def per_call_stage_times(stage1_ms_sum: float, stage2_ms_sum: float, launches: int, calls: int):
+    """LBAudioDetectiveGetStageTimes sums the two kernels' durations over every LAUNCH since timing was switched on,
+    and a call runs as several launches (chunks) when the inter-stage buffer limit cuts the batch.  Returns what
+    ONE call costs -- (stage-1 ms, stage-2 ms, launches per call) -- and the average duration of one launch of each
+    kernel: (stage-1 ms per launch, stage-2 ms per launch)."""
+    if calls <= 0 or launches <= 0 or launches % calls:
+        raise ValueError(f"{launches} launches do not divide into {calls} calls")
+    return (stage1_ms_sum / calls, stage2_ms_sum / calls, launches // calls), (stage1_ms_sum / launches, stage2_ms_sum / launches)
+
+
+def self_check(result: dict) -> list:
+    """Every figure of the line that has a physical ceiling, checked against it: a fraction above 1, a TFLOP/s
+    figure above the FP32 vector peak, a GB/s figure above the HBM peak or a roofline whose `achieved` exceeds its
+    `peak` means the arithmetic behind the line is wrong (round 3: a per-launch time multiplied by a whole batch).
+    Returns the list of violations (empty = the line may be printed as it is)."""
+    bad = []
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            if {"achieved", "peak"} <= node.keys() and isinstance(node["achieved"], (int, float)) \
+                    and isinstance(node["peak"], (int, float)) and node["achieved"] > node["peak"]:
+                bad.append(f"{path}: achieved {node['achieved']} > peak {node['peak']}")
+            for k, v in node.items():
+                walk(v, f"{path}.{k}" if path else k)
+        elif isinstance(node, list):
+            for i, v in enumerate(node):
+                walk(v, f"{path}[{i}]")
+        elif isinstance(node, (int, float)) and not isinstance(node, bool):
+            key = path.rsplit(".", 1)[-1].lower()
+            if "frac" in key and node > 1.0:
+                bad.append(f"{path} = {node} > 1")
+            if "tflops" in key and "peak" not in key and node > FP32_PEAK_TFLOPS:
+                bad.append(f"{path} = {node} > FP32 vector peak {FP32_PEAK_TFLOPS}")
+            if "gbps" in key and node > HBM_PEAK_GBS:
+                bad.append(f"{path} = {node} > HBM peak {HBM_PEAK_GBS}")
+    walk(result, "")
+    return bad
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,6 +297,8 @@ def launch_ranks(args) -> int:
     rc = proc.wait()
     if rc != 0:
         sys.stderr.write(f"bench.py: torch.distributed.run exited with {rc}\n")
+        if line is not None:                # a rank refused its own line (self-check, collective fallback): show it, fail
+            print(line, flush=True)
         return rc
     if line is None:
         sys.stderr.write("bench.py: the ranks finished without a result line\n")
@@ -672,23 +713,34 @@ def run_rank(args) -> int:
                 p2 = d2.fingerprint_clips_device(c2)
                 torch.cuda.synchronize()
                 d2.set_stage_timing(True)
-                for _ in range(3):
+                for _ in range(3):                              # calls_o below
                     d2.fingerprint_clips_device(c2, out=p2)
                 s1, s2, ln = d2.stage_times()
                 d2.set_stage_timing(False)
                 per2 = int(p2.shape[1])
                 ab = algorithmic_bytes_per_clip(samples, window, STRIDE)
-                ms1, ms2 = s1 / ln, s2 / ln
+                calls_o = 3
+                (ms1, ms2, lpc), (k1, k2) = per_call_stage_times(s1, s2, ln, calls_o)   # one CALL over the n_o clips
+                clips_per_launch_o = n_o / lpc
+                canon = per2 * 128 * 2.5 * window * (window.bit_length() - 1)          # per clip, SURVEY 8d
+                ach = ab * clips_per_launch_o / (k1 * 1e-3) / 1e9
                 want = O.fingerprint_batch(c2[:4].cpu().numpy(), O.Config(rate, window), nthreads=4)
                 got = lb.unpack_packed(p2[:4].cpu().numpy(), 200).reshape(4, per2, 200)
                 others[key] = {
                     "workload": f"{n_o} clips x {seconds} s @ {rate} Hz{' stereo-summed' if stereo else ''}, {window}-pt FFT, stride 64",
+                    "calls_timed": calls_o, "launches_per_call": lpc,
                     "stage1_ms": round(ms1, 3), "stage2_ms": round(ms2, 3),
                     "audio_seconds_per_s": round(n_o * seconds / ((ms1 + ms2) * 1e-3), 1),
                     "clips_per_s": round(n_o / ((ms1 + ms2) * 1e-3), 1),
-                    "stage1_algorithmic_GBps": round(ab * n_o / (ms1 * 1e-3) / 1e9, 2),
-                    "stage1_hbm_frac": round(ab * n_o / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "stage1_fp32_canonical_tflops": round(per2 * 128 * 2.5 * window * (window.bit_length() - 1) * n_o / (ms1 * 1e-3) / 1e12, 2),
+                    "roofline": {
+                        "bound": "valu", "kernel": "stage 1 (rows_stream2_kernel at 2048-sample windows, rows_stream_kernel at 4096)",
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "traffic": None, "algorithmic_bytes_per_clip": ab, "clips_per_launch": clips_per_launch_o,
+                        "kernel_ms_avg": round(k1, 4), "stage2_kernel_ms_avg": round(k2, 4),
+                        "fp32_canonical_tflops": round(canon * clips_per_launch_o / (k1 * 1e-3) / 1e12, 2),
+                        "fp32_peak_tflops": FP32_PEAK_TFLOPS,
+                        "fp32_frac_canonical": round(canon * clips_per_launch_o / (k1 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    },
                     "parity": {"clips_checked": 4, "bit_exact": bool(np.array_equal(got, want))},
                 }
                 del c2, p2
@@ -806,6 +858,7 @@ def run_rank(args) -> int:
                     "scan_ms": round(scan_ms, 4), "allreduce_ms": (round(ar_max, 4) if world > 1 else None),
                     "query_latency_ms": round(api_lat_ms if api_lat_ms is not None else lat_ms, 4),
                     "query_latency_sharded_path_ms": round(lat_ms, 4),
+                    "collective_fallback": comm is None,
                     "collective": (comm_note if comm is None else
                                    "ncclAllReduce(count 1, ncclUint64, ncclMax) inside LBAudioDetectiveCorpusQuerySharded, "
                                    f"communicator of {world} rank(s) from ncclCommInitRank; allreduce_ms is the same 8 bytes "
@@ -829,11 +882,39 @@ def run_rank(args) -> int:
                     t1 = time.perf_counter()
                     ci, cs = O.corpus_best(q, host, 200, nthreads=threads)
                     dt = time.perf_counter() - t1
+                    n_1 = min(total, 250_000)
+                    t1 = time.perf_counter()
+                    O.corpus_best(q, host[:n_1], 200, nthreads=1)
+                    dt1 = time.perf_counter() - t1
+                    # SURVEY 8(d)'s second baseline: the packed popcount scan (4 x 64-bit words per sub-fingerprint,
+                    # 160 B per entry), all cores and one; packing is untimed, like the GPU corpus build
+                    qw, cw = O.pack_bools(q), O.pack_bools(host)
                     del host
+                    O.corpus_best_packed(qw, cw[: 1 << 14], 200, 200, nthreads=threads)
+                    t1 = time.perf_counter()
+                    pi, ps = O.corpus_best_packed(qw, cw, 200, 200, nthreads=threads)
+                    dtp = time.perf_counter() - t1
+                    t1 = time.perf_counter()
+                    O.corpus_best_packed(qw, cw, 200, 200, nthreads=1)
+                    dtp1 = time.perf_counter() - t1
+                    del cw
                     result["compare"]["cpu_baseline"] = {
                         "value": round(total / dt, 1), "unit": "entries/s", "cores": threads, "kind": "port",
-                        "sample": f"all {total} entries as {per} x 200 Booleans (the reference's layout) through "
+                        "single_thread": {"value": round(n_1 / dt1, 1), "unit": "entries/s", "cores": 1,
+                                          "sample": f"first {n_1} entries, {dt1 * 1e3:.0f} ms"},
+                        "sample": f"all {total} entries as {per} x 200 Booleans (the reference's layout, 1000 B per entry) through "
                                   f"oracle/lbad_oracle.c:lbo_corpus_best, {threads} OpenMP threads, {dt * 1e3:.0f} ms",
+                        "cpu_model": cpu_model(),
+                        "packed_popcount": {
+                            "value": round(total / dtp, 1), "unit": "entries/s", "cores": threads, "kind": "port",
+                            "GBps": round(32 * per * total / dtp / 1e9, 2),
+                            "single_thread": {"value": round(total / dtp1, 1), "unit": "entries/s", "cores": 1,
+                                              "GBps": round(32 * per * total / dtp1 / 1e9, 2)},
+                            "agrees_with_boolean_loop": bool(pi == ci and np.float32(ps).view(np.uint32) == np.float32(cs).view(np.uint32)),
+                            "sample": f"all {total} entries as {per} x 4 64-bit words (160 B per entry) through "
+                                      f"oracle/lbad_oracle.c:lbo_corpus_best_packed (two popcounts per word), {threads} OpenMP "
+                                      f"threads {dtp * 1e3:.1f} ms, one thread {dtp1 * 1e3:.1f} ms; packing untimed",
+                        },
                     }
                     result["compare"]["parity"] = {
                         "entries_checked": total,
@@ -879,9 +960,19 @@ def run_rank(args) -> int:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    rc = 0
     if rank == 0:
+        bad = self_check(result)
+        result["self_check"] = {"ok": not bad, "violations": bad}
+        if bad:
+            sys.stderr.write("bench.py: SELF-CHECK FAILED: " + "; ".join(bad) + "\n")
+            rc = 4
+        if world > 1 and result.get("compare", {}).get("collective_fallback"):
+            sys.stderr.write("bench.py: the library's RCCL communicator could not be created; the compare leg fell back to "
+                             "torch.distributed -- a scaling run must not pass like this\n")
+            rc = rc or 5
         print(json.dumps(result), flush=True)
-    return 0
+    return rc
 
 
 def main() -> int:

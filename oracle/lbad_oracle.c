@@ -613,6 +613,76 @@ void lbo_corpus_best_ragged(const uint8_t* query, uint32_t n_query, const uint8_
 }
 
 /* ------------------------------------------------------------------------------------------
+ * The same compare on PACKED sub-fingerprints: the second CPU baseline SURVEY 8(d) asks for ("the packed popcount
+ * CPU version").  Boolean b of a sub-fingerprint is bit b & 63 of word b >> 6 (four 64-bit words, subfp_len <= 256).
+ * With A the first argument's sub-fingerprint (Fingerprint.m:151-176 on bit pairs, the identity SURVEY a-11 verified
+ * against the compiled reference):  NZ = (A | A >> 1) & EVEN & RANGE;  possible = popc(NZ);
+ * Y = (A ^ B) | (A ^ B) >> 1;  hits = popc(NZ & ~Y).  A pair never straddles a word (pairs start at even bits).
+ * Checked against lbo_corpus_best by tests/test_oracle.py.
+ * ---------------------------------------------------------------------------------------- */
+void lbo_pack_bools(const uint8_t* bools, uint64_t n_rows, uint32_t subfp_len, uint64_t* out) {
+    for (uint64_t r = 0; r < n_rows; ++r) {
+        uint64_t w[4] = {0, 0, 0, 0};
+        const uint8_t* row = bools + (size_t)r * subfp_len;
+        for (uint32_t b = 0; b < subfp_len && b < 256u; ++b)
+            if (row[b]) w[b >> 6] |= 1ull << (b & 63u);
+        memcpy(out + 4 * r, w, sizeof w);
+    }
+}
+
+static inline float packed_compare_sub(const uint64_t* a, const uint64_t* b, const uint64_t* range_mask) {
+    uint32_t possible = 0, hits = 0;
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t nz = (a[w] | (a[w] >> 1)) & range_mask[w];
+        const uint64_t x = a[w] ^ b[w];
+        possible += (uint32_t)__builtin_popcountll(nz);
+        hits += (uint32_t)__builtin_popcountll(nz & ~(x | (x >> 1)));
+    }
+    if (possible == 0) return 0.0f;                                  /* Fingerprint.m:171-173 */
+    return (float)hits / (float)possible;
+}
+
+static float packed_compare_fp(const uint64_t* fp1, uint32_t n1, const uint64_t* fp2, uint32_t n2,
+                               const uint64_t* range_mask) {
+    if (n1 < n2) {                                                   /* Fingerprint.m:123-131 */
+        const uint64_t* t = fp1; fp1 = fp2; fp2 = t;
+        const uint32_t u = n1; n1 = n2; n2 = u;
+    }
+    float match = 0.0f;
+    for (uint32_t offset = 0; offset <= n1 - n2; ++offset) {         /* :136 */
+        float sum = 0.0f;
+        for (uint32_t i = 0; i < n2; ++i)
+            sum += packed_compare_sub(fp1 + 4 * (size_t)(i + offset), fp2 + 4 * (size_t)i, range_mask);
+        const float cand = sum / (float)n2;
+        match = (match < cand) ? cand : match;                       /* :144 */
+    }
+    return match;
+}
+
+void lbo_corpus_best_packed(const uint64_t* query, uint32_t n_query, const uint64_t* corpus,
+                            uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len, uint32_t range,
+                            int nthreads, int64_t* best_index, float* best_score) {
+    /* EVEN & RANGE: the even bits below min(range, subfp_len) (Fingerprint.m:155; pairs i = 0, 2, ...) */
+    uint64_t mask[4] = {0, 0, 0, 0};
+    const uint32_t lim = range < subfp_len ? range : subfp_len;
+    for (uint32_t i = 0; i < lim && i < 256u; i += 2) mask[i >> 6] |= 1ull << (i & 63u);
+    float* scores = (float*)malloc(sizeof(float) * (n_entries ? n_entries : 1));
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t e = 0; e < (int64_t)n_entries; ++e)
+        scores[e] = packed_compare_fp(query, n_query, corpus + 4 * (size_t)e * n_sub, n_sub, mask);
+    float best = 0.0f;                                               /* Tests.m:60 */
+    int64_t idx = -1;
+    for (uint64_t e = 0; e < n_entries; ++e)
+        if (best < scores[e]) { best = scores[e]; idx = (int64_t)e; }   /* Tests.m:80-83 */
+    free(scores);
+    *best_index = idx;
+    *best_score = best;
+}
+
+/* ------------------------------------------------------------------------------------------
  * synthetic inputs (integer arithmetic only, so a device generator can match bit for bit)
  * ---------------------------------------------------------------------------------------- */
 static inline uint32_t mix32(uint32_t x) {

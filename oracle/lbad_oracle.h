@@ -142,6 +142,14 @@ void lbo_corpus_best_ragged(const uint8_t* query, uint32_t n_query, const uint8_
                             uint64_t n_entries, uint32_t subfp_len, uint32_t range, int nthreads,
                             int64_t* best_index, float* best_score, float* scores_out);
 
+/* Packed form of the same compare (SURVEY 8d's "packed popcount CPU version"): lbo_pack_bools turns n_rows rows of
+ * subfp_len (<= 256) Booleans into four 64-bit words each (Boolean b = bit b & 63 of word b >> 6);
+ * lbo_corpus_best_packed is lbo_corpus_best on such rows (query n_query x 4 words, corpus n_entries x n_sub x 4). */
+void lbo_pack_bools(const uint8_t* bools, uint64_t n_rows, uint32_t subfp_len, uint64_t* out);
+void lbo_corpus_best_packed(const uint64_t* query, uint32_t n_query, const uint64_t* corpus,
+                            uint64_t n_entries, uint32_t n_sub, uint32_t subfp_len, uint32_t range,
+                            int nthreads, int64_t* best_index, float* best_score);
+
 /* Deterministic integer synthetic PCM (bench/test input, not a reference function). */
 void lbo_synth_sine_table(int16_t* table1024);
 void lbo_synth_clip(uint32_t seed, uint64_t clip, double sample_rate, uint32_t n_samples,

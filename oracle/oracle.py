@@ -83,6 +83,10 @@ def lib():
                                   C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)])
     sig("lbo_corpus_best_ragged", None, [u8p, C.c_uint32, u8p, u32p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
                                          C.POINTER(C.c_int64), C.POINTER(C.c_float), C.c_void_p])
+    u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+    sig("lbo_pack_bools", None, [u8p, C.c_uint64, C.c_uint32, u64p])
+    sig("lbo_corpus_best_packed", None, [u64p, C.c_uint32, u64p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)])
     sig("lbo_synth_ragged_count", C.c_uint32, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32])
     sig("lbo_file_decode", C.c_int, [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64), C.POINTER(C.c_double)])
     sig("lbo_file_decode_bytes", C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint64),
@@ -271,6 +275,29 @@ def corpus_best(query: np.ndarray, corpus: np.ndarray, range_: int, nthreads: in
     bs = C.c_float(0.0)
     lib().lbo_corpus_best(query.reshape(-1), query.shape[0], corpus.reshape(-1), n_entries, n_sub, L, range_,
                           nthreads, C.byref(bi), C.byref(bs))
+    return int(bi.value), float(bs.value)
+
+
+def pack_bools(bools: np.ndarray) -> np.ndarray:
+    """[..., L] Booleans (L <= 256) -> [..., 4] uint64 words, Boolean b = bit b & 63 of word b >> 6."""
+    bools = np.ascontiguousarray(bools, np.uint8)
+    L = bools.shape[-1]
+    rows = bools.size // L if L else 0
+    out = np.zeros((max(rows, 1), 4), np.uint64)
+    if rows:
+        lib().lbo_pack_bools(bools.reshape(-1), rows, L, out.reshape(-1))
+    return out[:rows].reshape(bools.shape[:-1] + (4,))
+
+
+def corpus_best_packed(query_words: np.ndarray, corpus_words: np.ndarray, subfp_len: int, range_: int, nthreads: int = 1):
+    """lbo_corpus_best on packed rows (pack_bools): query [n_query, 4], corpus [n_entries, n_sub, 4] uint64."""
+    query_words = np.ascontiguousarray(query_words, np.uint64)
+    corpus_words = np.ascontiguousarray(corpus_words, np.uint64)
+    n_entries, n_sub, _ = corpus_words.shape
+    bi, bs = C.c_int64(-1), C.c_float(0.0)
+    lib().lbo_corpus_best_packed(query_words.reshape(-1), query_words.shape[0],
+                                 corpus_words.reshape(-1) if corpus_words.size else np.zeros(4, np.uint64),
+                                 n_entries, n_sub, subfp_len, range_, nthreads, C.byref(bi), C.byref(bs))
     return int(bi.value), float(bs.value)
 
 

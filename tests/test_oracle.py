@@ -190,6 +190,27 @@ def test_compare_invariants(oracle):
     assert oracle.compare_fp(a[:0], a, 200, subfp_len=200) == 0.0   # empty side: NaN never wins Foundation's MAX
 
 
+def test_packed_popcount_scan_equals_boolean_loop(oracle):
+    """The packed popcount CPU scan (bench.py's second compare baseline) returns what the Boolean loop
+    restated from Fp.m:119-176 returns -- index and float bits -- for equal and different counts, odd lengths, ranges
+    below / above / equal to the length, range 0, ties and all-zero queries."""
+    rng = np.random.default_rng(23)
+    for nq, ns, n, L, rg in ((5, 5, 3000, 200, 200), (5, 5, 400, 200, 0), (3, 7, 400, 200, 150), (9, 4, 300, 199, 200),
+                             (5, 5, 300, 200, 77), (1, 1, 50, 6, 6), (5, 5, 100, 256, 300), (2, 2, 64, 200, 1)):
+        corpus = oracle.synth_corpus(7, 0, n, ns, L) if L == 200 else (rng.random((n, ns, L)) < 0.4).astype(np.uint8)
+        q = (rng.random((nq, L)) < 0.4).astype(np.uint8)
+        if nq == ns:
+            q = corpus[n // 2].copy()
+            q[0, :10] ^= 1
+            corpus[n // 3] = corpus[n // 2]                                     # a tie: the lower index must win
+        want = oracle.corpus_best(q, corpus, rg)
+        got = oracle.corpus_best_packed(oracle.pack_bools(q), oracle.pack_bools(corpus), L, rg, nthreads=2)
+        assert got[0] == want[0] and np.float32(got[1]).view(np.uint32) == np.float32(want[1]).view(np.uint32), (nq, ns, L, rg)
+    z = np.zeros((5, 200), np.uint8)
+    c = oracle.synth_corpus(7, 0, 10, 5, 200)
+    assert oracle.corpus_best_packed(oracle.pack_bools(z), oracle.pack_bools(c), 200, 200) == oracle.corpus_best(z, c, 200) == (-1, 0.0)
+
+
 def test_ragged_best_match_against_python(oracle):
     """lbo_corpus_best_ragged (entries of different lengths, the shape of LBAudioDetectiveTests.m:57-91) against the
     pure-Python restatement of Fp.m:119-176 entry by entry; strict '<' from 0.0 (T.m:60,80): the lowest index wins
