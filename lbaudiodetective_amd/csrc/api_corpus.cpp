@@ -51,8 +51,34 @@ OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFinge
     LBAD_HIP(hipMemcpyAsync(dq, h, block.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
     if (d_scores) LBAD_HIP(hipMemsetAsync(d_scores, 0, c->count * sizeof(float), stream));
-    LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, c->subfp_len, dq, q->count, range,
-                                    index_base, reinterpret_cast<unsigned int*>(d_scores), key_dst, stream));
+    // groups of four sliding offsets the scan will run, from the histogram of entry lengths (Fp.m:123-136: an entry
+    // longer than the query slides the query along itself, any other entry slides along the query)
+    uint64_t tasks_a = 0, tasks_b = 0;
+    for (const auto& kv : c->len_hist) {
+        const uint64_t ne = kv.first, nq = q->count;
+        if (ne > nq) tasks_a += kv.second * ((ne - nq + 4) / 4);
+        else tasks_b += kv.second * ((nq - ne + 4) / 4);
+    }
+    if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return kLBAudioDetectiveArgumentInvalid;   // the plan counts in 32 bits
+    const SlideShape sh = sliding_shape(tasks_a, tasks_b);
+    // the plan of this query length: kept while the length and the entries stay (queries of one length are the rule)
+    if (c->count && !sliding_short(q->count, c->ne_max) &&
+        (c->plan_nq != q->count || c->plan_count != c->count || c->plan_grid != sh.grid)) {
+        if (c->plan_used) LBAD_HIP(hipEventSynchronize(c->plan_used));       // a scan on another stream may still read it
+        if (!c->plan_built) LBAD_HIP(hipEventCreateWithFlags(&c->plan_built, hipEventDisableTiming));
+        c->plan_nq = 0;
+        LBAD_HIP(launch_sliding_plan(c->d_off, c->count, q->count, sh, c->d_plan, stream));
+        LBAD_HIP(hipEventRecord(c->plan_built, stream));
+        c->plan_stream = stream;
+        c->plan_nq = q->count; c->plan_count = c->count; c->plan_grid = sh.grid;
+    } else if (c->plan_built && c->plan_stream != stream) {
+        LBAD_HIP(hipStreamWaitEvent(stream, c->plan_built, 0));
+    }
+    LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, (uint32_t)(c->rec_capacity + kRecordSlack / 2),
+                                    tasks_a, tasks_b, sh, c->d_plan, c->subfp_len, dq, q->count, range, index_base,
+                                    reinterpret_cast<unsigned int*>(d_scores), key_dst, stream));
+    if (!c->plan_used) LBAD_HIP(hipEventCreateWithFlags(&c->plan_used, hipEventDisableTiming));
+    LBAD_HIP(hipEventRecord(c->plan_used, stream));
     // behind the SCAN, not just the copy: the slot's device half is read by the kernel, and the query that reuses the
     // slot eight calls later may arrive on another stream
     LBAD_HIP(hipEventRecord(c->query_ev[slot], stream));
@@ -203,8 +229,8 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLengt
 
 LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprintLength, UInt64 inEntryCapacity,
                                                           UInt64 inSubfingerprintCapacity) {
-    if (inEntryCapacity == 0 || inEntryCapacity > 0xFFFFFFFFull) return NULL;   // the key carries a 32-bit index
-    if (inSubfingerprintCapacity < inEntryCapacity || inSubfingerprintCapacity > 0xFFFFFFFFull) return NULL;
+    if (inEntryCapacity == 0 || inEntryCapacity > 0xFFFF0000ull) return NULL;   // the key carries a 32-bit index (and the scan's claim cursor a little slack)
+    if (inSubfingerprintCapacity < inEntryCapacity || inSubfingerprintCapacity > 0xFFFFFF00ull) return NULL;
     if (!lbad::sliding_supported(inSubfingerprintLength)) return NULL;
     if (!lbad::device_ready()) {
         fprintf(stderr, "lbaudiodetective: no HIP device, cannot create a corpus\n");
@@ -222,10 +248,14 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprin
         delete c;
         return NULL;
     }
-    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_recs), (size_t)inSubfingerprintCapacity * 32), "hipMalloc corpus", __LINE__) != noErr ||
+    // kRecordSlack zero records behind the capacity: the scan reads up to three records past an entry's end (offsets
+    // that do not exist, never used) and takes its all-zero record from there
+    if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_recs), ((size_t)inSubfingerprintCapacity + lbad::kRecordSlack) * 32), "hipMalloc corpus", __LINE__) != noErr ||
+        lbad::hip_status(hipMemset(c->d_recs + 2 * (size_t)inSubfingerprintCapacity, 0, (size_t)lbad::kRecordSlack * 32), "corpus slack", __LINE__) != noErr ||
         lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_off), (size_t)(inEntryCapacity + 1) * 4), "hipMalloc offsets", __LINE__) != noErr ||
         lbad::hip_status(hipMemset(c->d_off, 0, 4), "offsets", __LINE__) != noErr ||
-        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr) {
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr ||
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_plan), lbad::sliding_plan_words(inEntryCapacity) * 4), "hipMalloc plan", __LINE__) != noErr) {
         LBAudioDetectiveCorpusDispose(c);
         return NULL;
     }
@@ -261,6 +291,17 @@ OSStatus LBAudioDetectiveCorpusAppendRaggedPackedDevice(LBAudioDetectiveCorpusRe
         st = lbad::hip_status(lbad::launch_pack_records(static_cast<const uint32_t*>(inPacked), total, c->d_off + at,
                                                         inNumberOfEntries, (uint32_t)c->count, c->d_recs, stream),
                               "pack records", __LINE__);
+    if (st == noErr) {
+        try {
+            for (UInt64 e = 0; e < inNumberOfEntries; ++e) ++c->len_hist[inCounts[e]];
+        } catch (const std::bad_alloc&) {
+            // the entries up to e are counted: rebuild the histogram from the offsets that stay
+            c->h_off.resize(at + 1);
+            c->len_hist.clear();
+            for (size_t k = 0; k + 1 < c->h_off.size(); ++k) ++c->len_hist[c->h_off[k + 1] - c->h_off[k]];
+            return kLBAudioDetectiveMemFull;
+        }
+    }
     if (st != noErr) {
         c->h_off.resize(at + 1);
         return st;
@@ -274,6 +315,9 @@ OSStatus LBAudioDetectiveCorpusAppendRaggedPackedDevice(LBAudioDetectiveCorpusRe
 
 void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (!c) return;
+    if (c->plan_used) { (void)hipEventSynchronize(c->plan_used); (void)hipEventDestroy(c->plan_used); }
+    if (c->plan_built) { (void)hipEventSynchronize(c->plan_built); (void)hipEventDestroy(c->plan_built); }
+    if (c->d_plan) (void)hipFree(c->d_plan);
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_planes) (void)hipFree(c->d_planes);
@@ -382,6 +426,9 @@ OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef c,
     const uint32_t range = inRange ? inRange : c->subfp_len;
     const uint32_t kw = lbad::plane_query_words();
     const size_t words = (size_t)inCount * kw;
+    // the staging pair is shared with the single-query generic scan, which may still be running on ANOTHER stream:
+    // its event (slot 0) orders every reuse, this path's too (round-3 advice)
+    if (c->query_ev[0]) LBAD_HIP(hipEventSynchronize(c->query_ev[0]));
     if (c->query_cap < words) {
         if (c->d_query) (void)hipFree(c->d_query);
         if (c->h_query) (void)hipHostFree(c->h_query);
@@ -404,6 +451,8 @@ OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef c,
     LBAD_HIP(hipMemsetAsync(keys, 0, (size_t)inCount * sizeof(unsigned long long), stream));
     LBAD_HIP(lbad::launch_compare_planes_batch(c->d_planes, c->capacity, c->count, c->n_sub, c->d_query, inCount,
                                                inIndexBase, keys, stream));
+    if (!c->query_ev[0]) LBAD_HIP(hipEventCreateWithFlags(&c->query_ev[0], hipEventDisableTiming));
+    LBAD_HIP(hipEventRecord(c->query_ev[0], stream));
     return noErr;
     LBAD_GUARD_END
 }
@@ -439,14 +488,14 @@ struct CorpusFileHeader {
 // ragged corpus file: header, the entries' sub-fingerprint counts, the records
 namespace {
 struct RaggedFileHeader {
-    char magic[8];            // "LBADCRP2"
+    char magic[8];            // "LBADCRP3" (round-4 record layout, k_sliding.hip); "LBADCRP2" files (round 3) still load
     uint32_t subfp_len, reserved;
     uint64_t count, n_pos;
 };
 
 OSStatus save_ragged(LBAudioDetectiveCorpus* c, FILE* f) {
     RaggedFileHeader h;
-    std::memcpy(h.magic, "LBADCRP2", 8);
+    std::memcpy(h.magic, "LBADCRP3", 8);
     h.subfp_len = c->subfp_len; h.reserved = 0; h.count = c->count; h.n_pos = c->n_pos;
     if (std::fwrite(&h, sizeof(h), 1, f) != 1) return kLBAudioDetectiveDeviceError;
     std::vector<uint32_t> counts(c->count);
@@ -467,6 +516,7 @@ OSStatus save_ragged(LBAudioDetectiveCorpus* c, FILE* f) {
 LBAudioDetectiveCorpusRef load_ragged(FILE* f, long file_size, uint64_t capacity) {
     RaggedFileHeader h;
     if (file_size < (long)sizeof(h) || std::fread(&h, sizeof(h), 1, f) != 1) return NULL;
+    const bool old_layout = std::memcmp(h.magic, "LBADCRP2", 8) == 0;
     // untrusted header: the file must really hold what it announces before anything is allocated from it
     if (!lbad::sliding_supported(h.subfp_len) || h.count > 0xFFFFFFFFull || h.n_pos > 0xFFFFFFFFull || h.n_pos < h.count)
         return NULL;
@@ -505,13 +555,25 @@ LBAudioDetectiveCorpusRef load_ragged(FILE* f, long file_size, uint64_t capacity
     }
     if (ok) {
         c->h_off[0] = 0;
-        for (uint64_t e = 0; e < h.count; ++e) {
-            c->h_off[e + 1] = c->h_off[e] + counts[e];
-            if (counts[e] > c->ne_max) c->ne_max = counts[e];
-        }
+        try {
+            for (uint64_t e = 0; e < h.count; ++e) {
+                c->h_off[e + 1] = c->h_off[e] + counts[e];
+                if (counts[e] > c->ne_max) c->ne_max = counts[e];
+                ++c->len_hist[counts[e]];
+            }
+        } catch (const std::bad_alloc&) { ok = false; }
+    }
+    if (ok)
         ok = lbad::hip_status(hipMemcpy(c->d_off, c->h_off.data(), (h.count + 1) * 4, hipMemcpyHostToDevice),
                               "corpus offsets H2D", __LINE__) == noErr;
-    }
+    // The records of a file are data, not structure: every place a record has inside its entry comes from the counts
+    // validated above (the scan reads d_off, nothing else), and what a record carries besides its 200 Booleans -- the
+    // table row of its `possible`, reserved bits, pairs beyond the length -- is recomputed / cleared here, so a crafted
+    // file cannot steer the scan (round-3 advice: the old records carried their own index fields)
+    if (ok)
+        ok = lbad::hip_status(lbad::launch_restamp_records(c->d_recs, c->d_off, h.count, h.n_pos, h.subfp_len, old_layout, nullptr),
+                              "restamp records", __LINE__) == noErr &&
+             lbad::hip_status(hipStreamSynchronize(nullptr), "restamp records", __LINE__) == noErr;
     if (!ok) {
         LBAudioDetectiveCorpusDispose(c);
         return NULL;
@@ -564,7 +626,8 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 
     const long file_size = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
     char magic[8] = {0};
-    if (file_size >= 8 && std::fread(magic, 8, 1, f) == 1 && std::memcmp(magic, "LBADCRP2", 8) == 0) {
+    if (file_size >= 8 && std::fread(magic, 8, 1, f) == 1 &&
+        (std::memcmp(magic, "LBADCRP3", 8) == 0 || std::memcmp(magic, "LBADCRP2", 8) == 0)) {
         std::fseek(f, 0, SEEK_SET);
         c = load_ragged(f, file_size, inCapacity);
         std::fclose(f);

@@ -727,6 +727,9 @@ OSStatus LBAudioDetectiveProcessAudioURL(LBAudioDetectiveRef d, const char* inFi
                                          LBAudioDetectiveFingerprintRef* outFingerprint) {  // :208-308
     LBAD_GUARD_BEGIN
     if (!d || !inFileURL || !outFingerprint) return kLBAudioDetectiveArgumentInvalid;  // :211-214
+    // the pinned block, the converter buffers, the io stream and the stride are ONE set per detective: this call is
+    // serialised like every other entry point (round-3 advice: the batch and pair calls were, this one was not)
+    LBAD_LOCK(d);
     // ExtAudioFile decodes and converts to the client format (:229); here both happen on the device and the
     // converted samples stay there for the window loop (api_files.cpp: a batch of one file)
     return lbad::process_audio_files(d, &inFileURL, 1, outFingerprint, nullptr);

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -83,7 +84,11 @@ public:
         }();
         return *pool;
     }
-    // fn(0) .. fn(n_tasks - 1), each exactly once, on the pool's threads and the caller's; returns when all are done
+    // fn(0) .. fn(n_tasks - 1), each exactly once, on the pool's threads and the caller's; returns when all are done.
+    // A task that throws (std::bad_alloc from a vector inside the caller's lambda) does not take the process down and
+    // does not leave workers running on a dead frame: the first exception is kept, every remaining task is skipped,
+    // ALL threads are awaited, and the exception is rethrown here, on the calling thread (whose LBAD_GUARD turns it
+    // into a status).
     void run(size_t n_tasks, const std::function<void(size_t, bool)>& fn) {
         if (forked().load()) {
             for (size_t i = 0; i < n_tasks; ++i) fn(i, false);
@@ -96,13 +101,21 @@ public:
             n_ = n_tasks;
             next_.store(0);
             pending_ = threads_.size();
+            failed_.store(false);
+            error_ = nullptr;
             ++generation_;
         }
         start_.notify_all();
-        for (size_t i; (i = next_.fetch_add(1)) < n_tasks;) fn(i, false);
+        for (size_t i; (i = next_.fetch_add(1)) < n_tasks;) run_one(fn, i, false);
         std::unique_lock<std::mutex> g(m_);
         done_.wait(g, [&] { return pending_ == 0; });
         fn_ = nullptr;
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            g.unlock();
+            std::rethrow_exception(e);
+        }
     }
     size_t threads() const { return threads_.size() + 1; }
 
@@ -132,7 +145,7 @@ private:
                 fn = fn_;
                 n = n_;
             }
-            for (size_t i; (i = next_.fetch_add(1)) < n;) (*fn)(i, true);
+            for (size_t i; (i = next_.fetch_add(1)) < n;) run_one(*fn, i, true);
             {
                 std::lock_guard<std::mutex> g(m_);
                 --pending_;
@@ -140,6 +153,18 @@ private:
             done_.notify_one();
         }
     }
+    void run_one(const std::function<void(size_t, bool)>& fn, size_t i, bool on_worker) {
+        if (failed_.load(std::memory_order_relaxed)) return;       // a task failed: the rest of the batch is void anyway
+        try {
+            fn(i, on_worker);
+        } catch (...) {
+            std::lock_guard<std::mutex> g(m_);
+            if (!error_) error_ = std::current_exception();
+            failed_.store(true);
+        }
+    }
+    std::atomic<bool> failed_{false};
+    std::exception_ptr error_;
     std::vector<std::thread> threads_;
     std::mutex m_, batch_;
     std::condition_variable start_, done_;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <new>
 #include <stdexcept>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -214,15 +215,34 @@ bool sliding_supported(uint32_t subfp_len);
 uint32_t sliding_query_words(uint32_t n_query);
 void build_sliding_query(const Boolean* bools, uint32_t n_query, uint32_t subfp_len, uint32_t range,
                          std::vector<uint32_t>& out);
-// d_off_new: ABSOLUTE record positions of the n_new new entries (n_new + 1 values, the first one = first_pos)
+// d_off_new: ABSOLUTE record positions of the n_new new entries (n_new + 1 values, the first one = slot 0's position)
 hipError_t launch_pack_records(const uint32_t* d_slots, uint64_t n_new_pos, const uint32_t* d_off_new, uint64_t n_new,
                                uint32_t first_entry, uint4* d_recs, hipStream_t stream);
+// records read from a file: derived fields (table row, place inside the entry) recomputed from d_off, reserved bits and
+// pairs beyond the length cleared (old_layout: the round-3 "LBADCRP2" record)
+hipError_t launch_restamp_records(uint4* d_recs, const uint32_t* d_off, uint64_t n_entries, uint64_t n, uint32_t subfp_len,
+                                  bool old_layout, hipStream_t stream);
 hipError_t launch_synth_ragged(uint32_t seed, uint64_t first_entry, uint64_t n_entries, const uint32_t* d_off,
                                uint64_t n_pos, uint32_t subfp_len, uint32_t* d_out, hipStream_t stream);
-hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries,
-                                  uint32_t ne_max, uint32_t subfp_len, const uint32_t* d_qblk, uint32_t n_query,
-                                  uint32_t range, uint64_t index_base, unsigned int* d_score_bits,
-                                  unsigned long long* d_key, hipStream_t stream);
+// shape of a scan: workgroups (one per CU) and the tasks of either kind each of them owns
+struct SlideShape {
+    uint32_t grid = 0, chunk_a = 0, chunk_b = 0;
+};
+constexpr uint32_t kSlideMaxGrid = 1024;
+SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b);
+size_t sliding_plan_words(uint64_t capacity);
+// the plan of a query length (where every workgroup's run of entries starts) into d_plan
+hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, const SlideShape& sh, uint32_t* d_plan,
+                               hipStream_t stream);
+// tasks_a / tasks_b: groups of four sliding offsets over the entries longer / not longer than the query; d_query: the
+// block build_sliding_query made; zero_rec: index of an all-zero record
+bool sliding_short(uint32_t n_query, uint32_t ne_max);    // the systolic scan of short queries applies (no plan needed)
+hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries, uint32_t ne_max,
+                                  uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
+                                  uint32_t subfp_len, const uint32_t* d_query, uint32_t n_query, uint32_t range,
+                                  uint64_t index_base, unsigned int* d_score_bits, unsigned long long* d_key,
+                                  hipStream_t stream);
+constexpr uint32_t kRecordSlack = 8;   // records allocated behind a ragged corpus' capacity (zero: over-read + the zero record)
 
 // measurement: ticks of the shader clock and of the constant 100 MHz clock over ~usec microseconds (2 words)
 hipError_t launch_clock_probe(uint32_t usec, unsigned long long* d_out, hipStream_t stream);
@@ -353,6 +373,14 @@ struct LBAudioDetectiveCorpus {
     uint32_t* d_off = nullptr;                   // capacity + 1 record positions (entry e = [off[e], off[e + 1]))
     std::vector<uint32_t> h_off;                 // count + 1
     uint32_t ne_max = 0;                         // longest entry
+    std::map<uint32_t, uint64_t> len_hist;       // entries per length: the scan's task totals for any query length
+    // the scan's plan for ONE query length (k_sliding.hip): rebuilt when the length, the entries or the grid change
+    uint32_t* d_plan = nullptr;
+    uint32_t plan_nq = 0, plan_grid = 0;
+    uint64_t plan_count = 0;
+    hipEvent_t plan_built = nullptr;             // behind the plan's kernels, on plan_stream
+    hipEvent_t plan_used = nullptr;              // behind the latest scan that read the plan
+    hipStream_t plan_stream = nullptr;
     // ring of query slots in h_query / d_query (ragged scan): slot size in words, one event per slot, queries so far
     size_t query_slot_words = 0;
     hipEvent_t query_ev[8] = {};

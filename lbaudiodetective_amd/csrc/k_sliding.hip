@@ -4,33 +4,51 @@
 // LBAudioDetectiveTests/LBAudioDetectiveTests.m:57-91 (one original against sequences of other lengths) as ONE
 // launch.
 //
-// The corpus is a stream of sub-fingerprint RECORDS, 32 bytes each, entries back to back:
-//   bits   0.. 99  P   first Boolean of pair p at bit p        (pairs = ceil(length / 2) <= 100)
-//   bits 100..199  N   second Boolean of pair p at bit 100 + p
-//   bits 200..211  i   index of the sub-fingerprint inside its entry, saturated at 4095
-//   bits 212..223  r   sub-fingerprints that follow it inside its entry, saturated at 4095
-//   bits 224..255  e   index of the entry
-// so a lane that loads one record knows everything about its place, no side table is read by the scan and the
-// loads are two aligned, fully coalesced dwordx4 per lane.  25 of the 32 bytes are the reference's information
-// (25 B per sub-fingerprint).
+// The corpus is a stream of sub-fingerprint RECORDS, 32 bytes each, entries back to back, plus one record offset per
+// entry (d_off).  A record (round 4 layout, eight words):
+//   w0..w2  P   first Boolean of pairs 0..95  (pairs = ceil(length / 2) <= 100), pair p at bit p & 31 of word p >> 5
+//   w3      bits 0..3: P of pairs 96..99;  bits 4..16: the row of the quotient table for this record's `possible`
+//           over the FULL range, possible (possible + 1) / 2;  bits 17..20: entry index, bits 28..31;
+//           bits 21..24: index of the sub-fingerprint inside its entry, saturated at 15;  bits 25..28: sub-fingerprints
+//           that follow it inside its entry, saturated at 15
+//   w4..w6  N   second Boolean of pairs 0..95
+//   w7      bits 0..3: N of pairs 96..99;  bits 4..31: entry index, bits 0..27
+// 25 of the 32 bytes are the reference's information (25 B per sub-fingerprint).  Everything else is
+// DERIVED (the table row from the Booleans, the place fields from the entries' counts) and is written by this
+// library only: the loader recomputes it from the counts it has validated (restamp_records_kernel), so a corpus file
+// cannot plant it.  The bits above the pairs never score: a hit needs both Booleans of a pair equal on both sides,
+// and the query's words are zero there.  The place fields serve the scan of SHORT queries only (compare_short_kernel).
 //
 // Per pair of sub-fingerprints (A = the longer fingerprint's, B = the other's; Fp.m:151-176):
 //   NZ = (PA | NA) & RANGE,  possible = popc(NZ),  hits = popc(NZ & ~((PA ^ PB) | (NA ^ NB)))
 //   ratio = hits / possible (0 when possible == 0) -- taken from a triangular table of the 5151 correctly rounded
 //   quotients in LDS instead of an IEEE division per pair.
 //
-// Systolic evaluation.  Lane l of a wave holds record base + l in registers; the query's sub-fingerprints a = 0, 1,
-// ... are wave-uniform (scalar loads).  In step a every lane computes ratio(a, l) and adds it to an accumulator
-// that moves one lane to the right per step (`v_add_f32 ... wave_shr:1`), so an accumulator follows one diagonal
-// l - a = const: exactly the terms of one sliding offset, added in the reference's order (Fp.m:139-142).
-//   entry longer than the query ("A" lanes): a diagonal starts in step 0 in every lane and is complete after the
-//     last step; it is an offset of the entry iff it stayed inside the entry (i >= n_query - 1).
-//   entry not longer than the query ("B" lanes): a diagonal starts whenever it enters the entry's first lane
-//     (i == 0) and is complete when it leaves the last one (r == 0); that lane keeps the maximum over the steps.
-// Diagonals that did not start properly carry -inf.  max over offsets commutes with the division by n2 (a correctly
-// rounded division by a positive constant is monotonic), so there is ONE division per lane and chunk
-// (Fp.m:144).  Consecutive chunks of 64 records overlap by min(n_query, longest entry) - 1 records; a window
-// inside the overlap is evaluated twice with the same result.
+// Round 4: only the sliding offsets that EXIST are evaluated.  (Round 3 let an accumulator per diagonal travel
+// across the lanes of a 256-record chunk: every (query sub-fingerprint, record) pair was computed although 45 % of
+// them at a query of 21 -- 76 % at a query of 48 -- lie on diagonals that leave their entry, and chunks overlapped.)
+//
+//   task  = four consecutive sliding offsets o0 .. o0 + 3 of ONE entry; a lane owns a task and keeps its four
+//           float32 sums in place.  The query's sub-fingerprints i = 0, 1, ... are wave-uniform (scalar loads): in
+//           step i the lane adds ratio(i, offset) to each of its sums -- the reference's order (Fp.m:139-142).
+//   "A"   entry LONGER than the query (Fp.m:123-131 swaps: it becomes fingerprint1): offset o pairs query i with record
+//           o + i.  The lane's window of records slides one record per step; the record it needs next is the one
+//           its RIGHT neighbour (offsets o0 + 4 ..) used four steps earlier, so records travel leftwards through the
+//           lanes of an entry (8 `v_mov_b32 wave_shl:1` per step for 4 pairs) and only the entry's last task reads
+//           memory (its fresh record lands five steps before it is needed, directly in the window's ring of 8
+//           register slots -- no staging copy).
+//   "B"   entry not longer than the query (no swap: the query is fingerprint1): offset o pairs query j with record
+//           j - o; records travel rightwards, the entry's FIRST task reads memory, and positions outside the entry
+//           are fed from an all-zero record, whose pairs score hits = 0 -> +0.0 -- adding them leaves the float32
+//           sum as it is, so the step loop is the same n_query steps for every lane.
+//   A wave turns entries into tasks itself: it claims runs of entries from a counter, keeps (first task, records,
+//   length) of the entries that still have tasks in a small LDS queue and runs a PASS -- 64 tasks, n_query steps --
+//   whenever the queue holds 64 of them; what is left over waits for the next claim, so every pass but a wave's
+//   last is full.  All A passes of the scan first, then the B passes (skipped when the host's length histogram
+//   says there are none).  No chunk overlap, no diagonal leaves its entry, no side table besides d_off.
+//
+// max over offsets commutes with the division by n2 (a correctly rounded division by a positive constant is
+// monotonic), so there is ONE division per task, and only where the sum can still reach the wave's best (Fp.m:144).
 #include "internal.hpp"
 
 #include <cmath>
@@ -40,11 +58,693 @@
 namespace lbad {
 namespace {
 
-constexpr int kSlThreads = 256;
+constexpr int kSlThreads = 256;       // pack / plan kernels
+#ifndef LBAD_SCAN_THREADS
+#define LBAD_SCAN_THREADS 1024
+#define LBAD_SCAN_PER_CU 1
+#endif
+constexpr int kScanThreads = LBAD_SCAN_THREADS;    // the scan: ONE workgroup fills a CU (16 waves, four per SIMD)
+constexpr int kScanPerCu = LBAD_SCAN_PER_CU;
+constexpr int kScanWaves = kScanThreads / 64;
 constexpr uint32_t kTriPairs = 100;
 constexpr uint32_t kTriSize = (kTriPairs + 1) * (kTriPairs + 2) / 2;   // 5151 quotients
-constexpr uint32_t kQWords = 16;   // per query sub-fingerprint: P[4] N[4] NZ[4] tri-base possible - -
+constexpr uint32_t kQWords = 16;      // per query sub-fingerprint: P[4] N[4] NZ[4] tri-base possible - -
+constexpr uint32_t kQHeader = 16;     // words in front of the query (reserved, zero)
+constexpr uint32_t kSlots = 128;      // queue slots per wave (at most 63 left over + 64 new)
 
+__device__ __forceinline__ unsigned long long sl_key(float score, uint64_t global_index) {
+    return ((unsigned long long)__float_as_uint(score) << 32) |
+           (unsigned long long)(0xFFFFFFFFu - (uint32_t)global_index);
+}
+
+// value of lane l + 1 / lane l - 1 (the wave's last / first lane keeps `old`); full EXEC wherever these are used:
+// a DPP read of a lane that is switched off does not deliver its register
+__device__ __forceinline__ uint32_t from_right_lane(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t from_left_lane(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+
+struct SlideArgs {                // the scalars of a scan (the pointers are kernel arguments of their own: `restrict`)
+    uint64_t index_base;
+    uint64_t n_entries;
+    uint32_t nq;
+    uint32_t zero_rec;            // index of an all-zero record
+    uint32_t rm[4];               // RANGE over pair bits
+    uint32_t dense_a, dense_b;    // entries that hold about 128 tasks of a kind (two passes): the least a wave claims
+};
+
+struct SlidePtrs {
+    const uint4* __restrict__ recs;
+    const uint32_t* __restrict__ off;      // n_entries + 1 record positions
+    const uint32_t* __restrict__ q;        // the query, kQWords per sub-fingerprint
+    unsigned int* score_bits;              // optional, per entry
+};
+
+#ifdef LBAD_SLIDE_PROF
+// bring-up aid: shader-clock ticks per phase, summed over the waves (tools/exp/sliding_prof.py reads them)
+__device__ unsigned long long g_slide_prof[16];
+#define LBAD_PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+__shared__ unsigned long long s_slide_prof[kScanWaves][16];     // per wave, flushed once when the kernel ends
+#define LBAD_PROF_ADD(slot, a, b) do { if ((threadIdx.x & 63u) == 0) s_slide_prof[threadIdx.x >> 6][slot] += (b) - (a); } while (0)
+#else
+#define LBAD_PROF_T(x)
+#define LBAD_PROF_ADD(slot, a, b)
+#endif
+
+struct Task {                     // one lane's share of a pass
+    bool active, feeder;
+    uint32_t rec0;                // A: record index of offset o0, step 0;  B: first record of the entry
+    uint32_t ne, o0, n_off, ent;
+};
+
+template <bool FULL>
+__device__ __forceinline__ uint32_t record_row(const uint32_t (&r)[8], const uint32_t (&rm)[4]) {
+    if (FULL) return (r[3] >> 4) & 0x1FFFu;
+    uint32_t p = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) p += __popc((r[w] | r[4 + w]) & rm[w]);   // w3's row bits lie outside rm
+    return p * (p + 1u) / 2u;
+}
+
+// hits of the window record against the step's query sub-fingerprint, accumulated onto the table row:
+//   A: u = (P | N) & ~(P ^ qP)  (0xA4 over P, N, qP; the row bits of w3 meet N = 0, qP = 0 and vanish),
+//      v = u & ~(N ^ qN)        (0x90)
+//   B: u = nzq & ~(P ^ qP), v = u & ~(N ^ qN): the mask is the query's (it is the longer side), the row bits meet
+//      nzq = 0
+template <bool MODE_B, bool FULL>
+__device__ __forceinline__ uint32_t pair_index(const uint32_t (&r)[8], const uint32_t (&qv)[8], const uint32_t (&nzq)[4],
+                                               uint32_t row, const uint32_t (&rm)[4]) {
+    uint32_t h = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t u;
+        if (MODE_B) u = __builtin_amdgcn_bitop3_b32(nzq[w], r[w], qv[w], 0x90);
+        else u = __builtin_amdgcn_bitop3_b32(r[w], r[4 + w], qv[w], 0xA4);
+        uint32_t v = __builtin_amdgcn_bitop3_b32(u, r[4 + w], qv[4 + w], 0x90);
+        if (!MODE_B && !FULL) v &= rm[w];
+        // h += popc(v) as ONE accumulating v_bcnt, starting at the table row
+        if (w == 0) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(v), "v"(row));
+        else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(v));
+    }
+    return h;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// A record slot of a lane's window: words 0..3 and 4..7 as two register quads (the loads' destinations)
+struct Slot {
+    u32x4 lo, hi;
+};
+
+__device__ __forceinline__ void slot_words(const Slot& s, uint32_t (&r)[8]) {
+    r[0] = s.lo.x; r[1] = s.lo.y; r[2] = s.lo.z; r[3] = s.lo.w; r[4] = s.hi.x; r[5] = s.hi.y; r[6] = s.hi.z; r[7] = s.hi.w;
+}
+
+__device__ __forceinline__ void slot_load(const uint4* __restrict__ recs, uint32_t idx, Slot& s) {
+    const uint4* p = recs + 2 * (uint64_t)idx;
+    const uint4 a = p[0], b = p[1];
+    s.lo = u32x4{a.x, a.y, a.z, a.w};
+    s.hi = u32x4{b.x, b.y, b.z, b.w};
+}
+
+// The step loop's loads: the lanes of `mask` fetch their next record straight into the slot, the other lanes keep what
+// the slot holds.  Written as assembly because the count of loads in flight must not depend on the path taken: the
+// compiler skips an exec-masked load when no lane wants it, can then no longer tell how many loads follow a given
+// one, and drains the queue (vmcnt(0)) at every loop head -- the five steps a record is fetched ahead would be lost.
+// Exactly two loads per step are issued here, whatever the mask, and slot_wait() below counts on that.
+__device__ __forceinline__ void slot_load_masked(const uint4* __restrict__ recs, uint32_t idx, unsigned long long mask, Slot& s) {
+    const uint4* p = recs + 2 * (uint64_t)idx;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %2, exec\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "s_mov_b64 exec, %2"
+                 : "+v"(s.lo), "+v"(s.hi), "=&s"(saved)
+                 : "v"(p), "s"(mask)
+                 : "memory");
+}
+
+__device__ __forceinline__ void slot_from_right(Slot& d, const Slot& s) {
+    d.lo.x = from_right_lane(s.lo.x); d.lo.y = from_right_lane(s.lo.y); d.lo.z = from_right_lane(s.lo.z); d.lo.w = from_right_lane(s.lo.w);
+    d.hi.x = from_right_lane(s.hi.x); d.hi.y = from_right_lane(s.hi.y); d.hi.z = from_right_lane(s.hi.z); d.hi.w = from_right_lane(s.hi.w);
+}
+__device__ __forceinline__ void slot_from_left(Slot& d, const Slot& s) {
+    d.lo.x = from_left_lane(s.lo.x); d.lo.y = from_left_lane(s.lo.y); d.lo.z = from_left_lane(s.lo.z); d.lo.w = from_left_lane(s.lo.w);
+    d.hi.x = from_left_lane(s.hi.x); d.hi.y = from_left_lane(s.hi.y); d.hi.z = from_left_lane(s.hi.z); d.hi.w = from_left_lane(s.hi.w);
+}
+
+// the loads of the steps after the awaited one may still be in flight (2 per step, IN_FLIGHT of them), everything
+// older has landed: memory reads return in order
+template <int IN_FLIGHT>
+__device__ __forceinline__ void slot_wait_n(Slot& s) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.lo), "+v"(s.hi) : "n"(IN_FLIGHT));
+}
+
+#ifndef LBAD_SLIDE_RING
+#define LBAD_SLIDE_RING 6
+#endif
+constexpr int kRing = LBAD_SLIDE_RING;        // record slots per lane: the 4 of the window + kRing - 4 fetched ahead
+
+// One pass: 64 tasks, nq steps.  R is the lane's ring of S = kRing record slots.
+//   A: slot n % S holds the record of relative index n (records o0 + n of the entry); step i uses n = i + k for the
+//      offsets k = 0..3; after the step, record i + S replaces record i: from the right neighbour's record i + S - 4
+//      (all lanes, full EXEC), then, in feeder lanes, from memory.
+//   B: slot n % S holds e[n - o0]; step j uses n = j - k; after the step record j + S - 3 replaces record j - 3: from
+//      the left neighbour's record j + S - 7, then, in feeder lanes, from memory (the zero record outside the entry).
+// A record fetched behind step i is first needed S - 4 steps later (A: the left neighbour copies it, one step before
+// the lane itself uses it as offset 3; B likewise), and that is where its wait stands.
+// Every step fetches, needed or not (an A feeder reads up to S records past its entry: the corpus is allocated
+// with that slack), so that the number of loads in flight is the same on every path.
+// The step's query sub-fingerprint comes from LDS (QLDS: two ds_read_b128 per step, the same address in every lane)
+// rather than from scalar registers: a vector instruction with a scalar operand issues at the slow rate on this chip
+// (v_bitop3_b32 1.85 ns against 1.13 ns per SIMD, tools/ubench/slide_rates.hip), and the step has 32 of them.
+template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
+__device__ __forceinline__ void run_pass(const SlideArgs& a, const uint4* __restrict__ recs, const uint32_t* __restrict__ q,
+                                         const uint32_t* s_q, const Task& t, const float* s_tri, float (&acc)[4]) {
+    constexpr int S = kRing;
+    constexpr int D = S - 4;
+    static_assert(S >= 5 && S <= 8, "ring of 5..8 slots");
+    Slot R[S];
+    uint32_t row[S];                            // A: table row of the record in slot s (extracted when it becomes offset 3's)
+#pragma unroll
+    for (int n = 0; n < S; ++n) row[n] = 0;
+    const uint32_t nq = a.nq;
+    const uint32_t rm[4] = {a.rm[0], a.rm[1], a.rm[2], a.rm[3]};
+    const unsigned long long feeders = __ballot(t.feeder);
+    // index of relative record n for this lane (B: the zero record outside the entry, and in idle lanes)
+    auto rec_index = [&](int32_t n) -> uint32_t {
+        if (!MODE_B) return t.rec0 + (uint32_t)n;
+        const int32_t p = n - (int32_t)t.o0;
+        return (t.active && p >= 0 && (uint32_t)p < t.ne) ? t.rec0 + (uint32_t)p : a.zero_rec;
+    };
+    auto mod = [](int n) { return ((n % S) + S) % S; };
+    LBAD_PROF_T(q0);
+    // The ring at step 0, ONE exposed round trip to memory: every lane fetches the four records of its window; the D
+    // records behind it come from the neighbour's window once that has landed, and in feeder lanes from memory -- as
+    // masked loads of the step loop's kind, issued in slot order right here, so that the loop's own waits (everything
+    // but the last 2 (D - 1) loads has landed) cover them: they are still in flight when step 0 starts.
+    if (!MODE_B) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            asm volatile("" : "=v"(R[n].lo), "=v"(R[n].hi));       // idle lanes: whatever the registers hold (never used)
+            if (t.active) slot_load(recs, rec_index(n), R[n]);
+        }
+#pragma unroll
+        for (int n = 4; n < S; ++n) {
+            if (ALL_FEED) asm volatile("" : "=v"(R[n].lo), "=v"(R[n].hi));
+            else slot_from_right(R[n], R[n - 4]);
+        }
+#pragma unroll
+        for (int n = 4; n < S; ++n) slot_load_masked(recs, rec_index(n), feeders, R[n]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint32_t w[8];
+            slot_words(R[k], w);
+            row[k] = record_row<FULL>(w, rm);
+        }
+    } else {
+        // records -3..0: the zero record unless the entry starts here; 1..D from the left neighbour's -3.. / memory
+#pragma unroll
+        for (int n = -3; n <= 0; ++n) slot_load(recs, rec_index(n), R[mod(n)]);
+#pragma unroll
+        for (int n = 1; n <= D; ++n) {
+            if (ALL_FEED) asm volatile("" : "=v"(R[mod(n)].lo), "=v"(R[mod(n)].hi));
+            else slot_from_left(R[mod(n)], R[mod(n - 4)]);
+        }
+#pragma unroll
+        for (int n = 1; n <= D; ++n) slot_load_masked(recs, rec_index(n), feeders, R[mod(n)]);
+    }
+    float pend[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // the previous step's quotients: added one step late, their LDS latency hidden
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = 0.0f;
+    // every slot is "used" here, in front of the loop: the compiler places the waits for the loads above HERE and not
+    // at their first use inside the loop (where a wait would drain the step loop's own loads every S steps)
+#pragma unroll
+    for (int n = 0; n < S; ++n) asm volatile("" : "+v"(R[n].lo), "+v"(R[n].hi));
+    static_assert(D >= 1, "the masked loads of the fill need a slot behind the window");
+
+    // the query sub-fingerprint of a step: P[4] N[4] (and, B: the query's mask and table row) -- fetched one step ahead
+    struct QStep {
+        uint32_t v[8], nz[4], row;
+    };
+    auto fetch_q = [&](uint32_t i, QStep& o) {
+        if (QLDS) {
+            const uint4* ql = reinterpret_cast<const uint4*>(s_q + (size_t)i * kQWords);
+            const uint4 q0 = ql[0], q1 = ql[1];
+            o.v[0] = q0.x; o.v[1] = q0.y; o.v[2] = q0.z; o.v[3] = q0.w; o.v[4] = q1.x; o.v[5] = q1.y; o.v[6] = q1.z; o.v[7] = q1.w;
+            if (MODE_B) {
+                const uint4 q2 = ql[2];
+                o.nz[0] = q2.x; o.nz[1] = q2.y; o.nz[2] = q2.z; o.nz[3] = q2.w;
+                o.row = s_q[(size_t)i * kQWords + 12];
+            }
+        } else {
+            const uint32_t* __restrict__ qa = q + (size_t)i * kQWords;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) o.v[w] = qa[w];
+            if (MODE_B) {
+                // the query's mask and table row in vector registers, once per step for the four offsets (a VALU
+                // instruction reads one scalar operand only)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) asm("v_mov_b32 %0, %1" : "=v"(o.nz[w]) : "s"(qa[8 + w]));
+                asm("v_mov_b32 %0, %1" : "=v"(o.row) : "s"(qa[12]));
+            }
+        }
+    };
+    QStep qn;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) qn.nz[w] = 0;
+    qn.row = 0;
+    fetch_q(0, qn);
+    // one step; u = i % S is a compile-time constant (the ring's slots are registers)
+    auto step = [&](const int u, const uint32_t i) {
+        const QStep qc = qn;
+        fetch_q(i + 1u, qn);                                    // (one sub-fingerprint of slack behind the query)
+        if (!MODE_B) {
+            uint32_t w[8];
+            slot_words(R[(u + 3) % S], w);
+            row[(u + 3) % S] = record_row<FULL>(w, rm);
+        }
+        uint32_t h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t w[8];
+            slot_words(R[MODE_B ? mod(u - k) : (u + k) % S], w);
+            h[k] = pair_index<MODE_B, FULL>(w, qc.v, qc.nz, MODE_B ? qc.row : row[(u + k) % S], rm);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[k] = __fadd_rn(acc[k], pend[k]);                // step i - 1's term (0.0 in front of the first)
+            pend[k] = s_tri[h[k]];
+        }
+        // the window moves on: the record fetched D steps ago has landed by now
+#ifdef LBAD_SLIDE_PROF_STEP
+        LBAD_PROF_T(w0);
+#endif
+        if (!MODE_B) {
+            slot_wait_n<2 * (D - 1)>(R[(u + 4) % S]);
+#ifdef LBAD_SLIDE_PROF_STEP
+            LBAD_PROF_T(w1);
+            LBAD_PROF_ADD(13, w0, w1);
+            LBAD_PROF_ADD(14, 0ull, 1ull);
+#endif
+            if (!ALL_FEED) slot_from_right(R[u], R[(u + D) % S]);
+            slot_load_masked(recs, rec_index((int32_t)i + S), feeders, R[u]);
+        } else {
+            slot_wait_n<2 * (D - 1)>(R[mod(u + 1)]);
+            if (!ALL_FEED) slot_from_left(R[mod(u - 3)], R[mod(u + S - 7)]);
+            slot_load_masked(recs, rec_index((int32_t)i + S - 3), feeders, R[mod(u - 3)]);
+        }
+    };
+    // whole rounds of the ring without a branch inside (one block for the scheduler: the next step's query words and
+    // this step's table look-ups are in flight across the steps), then the last nq % S steps one by one
+    uint32_t i0 = 0;
+    for (; i0 + (uint32_t)S <= nq; i0 += (uint32_t)S) {
+#pragma unroll
+        for (int u = 0; u < S; ++u) step(u, i0 + (uint32_t)u);
+    }
+#pragma unroll
+    for (int u = 0; u < S - 1; ++u)
+        if (i0 + (uint32_t)u < nq) step(u, i0 + (uint32_t)u);   // uniform
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = __fadd_rn(acc[k], pend[k]);
+    // Nothing of this pass may still be in flight when the ring's registers are reused.  The wait NAMES every slot:
+    // the compiler does not know that loads are on their way into them, sees the ring dead after the last step and
+    // would otherwise hand its registers to the code that follows (scheduled in front of a wait without operands) --
+    // the late records then land in the task's results.
+#pragma unroll
+    for (int n = 0; n < S; ++n) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[n].lo), "+v"(R[n].hi) : : "memory");
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// One wave's part of the A (or B) tasks of its workgroup; returns the best key it met.
+//
+// Who does what.  A workgroup is a whole CU (16 waves) and owns a run of entries that holds 1 / grid of the scan's tasks
+// (the plan below: made once per query length).  Inside the workgroup the waves CLAIM pieces of that run from a cursor
+// in LDS -- 64 entries while the run is long, down to 8 near its end -- so all sixteen stay busy until the run is
+// empty.  Two other arrangements were measured on the 1 M-entry corpus first: claims from ONE counter in global memory
+// (16 k same-address atomics per scan: a fifth of a wave's time went into waiting for them, plus the tail of whoever
+// claimed last) and fully static shares per wave (no atomics at all, but waves that share a SIMD do not run at one
+// speed: the slowest needed 1.37 x the average and the rest of its SIMD idled meanwhile).
+template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
+__device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, const SlidePtrs& p, const float* s_tri, const uint32_t* s_q,
+                                                        uint32_t* s_cursor, uint32_t* s_start, uint32_t* s_off, uint32_t* s_ne,
+                                                        uint32_t* s_ent, unsigned long long best) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nq = a.nq;
+    const uint32_t run_end = s_cursor[1];
+    uint32_t n_slots = 0, done = 0, total = 0;       // queue: slots, tasks handed out, tasks queued (this wave's numbering)
+    uint32_t cur = 0, cur_end = 0;                   // claimed entries not yet turned into slots
+    bool more = true;
+    if (lane == 0) s_start[0] = 0;
+    for (;;) {
+        LBAD_PROF_T(p0);
+        // ---- refill: until 64 tasks wait or the workgroup's run is exhausted -----------------------------------
+        while (more && total - done < 64u) {
+            if (cur >= cur_end) {
+                uint32_t c0 = 0, size = 0;
+                if (lane == 0) {
+                    // a 32nd of what is left, but never less than two passes' worth of entries (where the tasks of a
+                    // kind are rare -- the few entries not longer than a short query -- sixteen waves with a handful of
+                    // tasks each would run sixteen nearly empty passes) nor fewer than 8, and at most 4096 entries
+                    const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(s_cursor);
+                    const uint32_t left = seen < run_end ? run_end - seen : 0u;
+                    const uint32_t least = MODE_B ? a.dense_b : a.dense_a;
+                    size = left / (2u * kScanWaves);
+                    size = size < least ? least : size;
+                    size = size < 8u ? 8u : (size > 4096u ? 4096u : size);
+                    c0 = atomicAdd(s_cursor, size);
+                }
+                c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+                size = (uint32_t)__builtin_amdgcn_readfirstlane((int)size);
+                if (c0 >= run_end) { more = false; break; }
+                cur = c0;
+                cur_end = run_end - c0 < size ? run_end : c0 + size;
+            }
+            // drop the slots whose tasks have all been handed out (a prefix: the starts are increasing)
+            {
+                const bool live0 = lane < n_slots && s_start[lane + 1] > done;
+                const bool live1 = lane + 64u < n_slots && s_start[lane + 65u] > done;
+                const uint32_t n_live = (uint32_t)__popcll(__ballot(live0)) + (uint32_t)__popcll(__ballot(live1));
+                const uint32_t first = n_slots - n_live;
+                if (first) {
+                    uint32_t v[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t src = first + lane + 64u * h;
+                        const bool ok = src < n_slots;
+                        v[h][0] = ok ? s_start[src] : 0u; v[h][1] = ok ? s_off[src] : 0u;
+                        v[h][2] = ok ? s_ne[src] : 0u; v[h][3] = ok ? s_ent[src] : 0u;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t dst = lane + 64u * h;
+                        if (first + dst < n_slots) {
+                            s_start[dst] = v[h][0]; s_off[dst] = v[h][1]; s_ne[dst] = v[h][2]; s_ent[dst] = v[h][3];
+                        }
+                    }
+                    n_slots = n_live;
+                    if (lane == 0) s_start[n_slots] = total;
+                }
+            }
+            // the next (at most 64) claimed entries
+            const uint32_t e = cur + lane;
+            const uint32_t part_end = cur_end - cur > 64u ? cur + 64u : cur_end;
+            uint32_t o = 0, ne = 0, tasks = 0;
+            if (e < part_end) {
+                o = p.off[e];
+                ne = p.off[(uint64_t)e + 1] - o;
+                // Fp.m:123-131 swaps only when the query is SHORTER: an entry of the query's length is a "B" entry
+                if (MODE_B) tasks = ne <= nq ? (nq - ne + 4u) >> 2 : 0u;         // ceil((nq - ne + 1) / 4)
+                else tasks = ne > nq ? (ne - nq + 4u) >> 2 : 0u;
+            }
+            cur = part_end;
+            const unsigned long long with = __ballot(tasks != 0u);
+            const uint32_t incl = wave_inclusive_add(tasks, lane);
+            if (tasks) {
+                const uint32_t slot = n_slots + (uint32_t)__popcll(with & ((1ull << lane) - 1ull));
+                s_start[slot] = total + incl - tasks;
+                s_off[slot] = o; s_ne[slot] = ne; s_ent[slot] = e;
+            }
+            n_slots += (uint32_t)__popcll(with);
+            total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (lane == 0) s_start[n_slots] = total;
+        }
+        if (total == done) break;
+        LBAD_PROF_T(p1);
+        LBAD_PROF_ADD(0, p0, p1);
+        // ---- one pass over the next 64 tasks ------------------------------------------------------------------
+        Task t;
+        const uint32_t tid = done + lane;
+        t.active = tid < total;
+        const uint32_t key_t = t.active ? tid : total - 1u;
+        uint32_t lo = 0, hi = n_slots;                       // s_start[lo] <= key_t < s_start[hi]
+#pragma unroll
+        for (int it = 0; it < 7; ++it) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const bool right = s_start[mid] <= key_t;
+            lo = right ? mid : lo;
+            hi = right ? hi : mid;
+        }
+        const uint32_t tl = key_t - s_start[lo];             // task inside the entry
+        t.ne = s_ne[lo];
+        t.ent = s_ent[lo];
+        t.o0 = 4u * tl;
+        t.n_off = MODE_B ? nq - t.ne + 1u : t.ne - nq + 1u;
+        const uint32_t e_first = s_off[lo];
+        t.rec0 = MODE_B ? e_first : e_first + t.o0;
+        // who reads memory: the lane whose neighbour cannot hand it the next record -- the entry's last (A) / first (B)
+        // task and the wave's edge lanes (an entry whose tasks lie in two passes)
+        if (ALL_FEED) t.feeder = t.active;
+        else if (MODE_B) t.feeder = t.active && (tl == 0u || lane == 0u);
+        else t.feeder = t.active && (t.o0 + 4u >= t.n_off || lane == 63u);
+        float acc[4];
+        LBAD_PROF_T(p2);
+        LBAD_PROF_ADD(1, p1, p2);
+        run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc);
+        LBAD_PROF_T(p3);
+        LBAD_PROF_ADD(2, p2, p3);
+        LBAD_PROF_ADD(5, 0ull, 1ull);
+        done = done + 64u < total ? done + 64u : total;
+#ifdef LBAD_SLIDE_DEBUG
+        if (t.active)
+            printf("wg %u wave %u mode %d lane %u ent %u ne %u o0 %u n_off %u rec0 %u feeder %d acc %g %g %g %g total %u n_slots %u\n",
+                   blockIdx.x, threadIdx.x >> 6, (int)MODE_B, lane, t.ent, t.ne, t.o0, t.n_off, t.rec0, (int)t.feeder, acc[0], acc[1],
+                   acc[2], acc[3], total, n_slots);
+#endif
+
+        // max over the task's offsets first, ONE exact division where the sum can still matter (Fp.m:144)
+        int m = -1;                                          // sums are >= 0: as integers their bits order like the floats
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t.active && t.o0 + (uint32_t)k < t.n_off) m = max(m, __float_as_int(acc[k]));
+        const float n2f = (float)(MODE_B ? t.ne : nq);
+        const float thr = __uint_as_float((uint32_t)(best >> 32)) * 0.99999f;
+        const bool need = m >= 0 && (p.score_bits != nullptr || __int_as_float(m) >= thr * n2f);
+        if (need) {
+            const float cand = __fdiv_rn(__int_as_float(m), n2f);
+            const float match = (0.0f < cand) ? cand : 0.0f;                 // MAX(match, cand) from match = 0
+            if (p.score_bits) atomicMax(&p.score_bits[t.ent], __float_as_uint(match));
+            const unsigned long long key = sl_key(match, a.index_base + t.ent);
+            best = key > best ? key : best;
+        }
+        LBAD_PROF_T(p4);
+        LBAD_PROF_ADD(3, p3, p4);
+    }
+    return best;
+}
+
+// the query in LDS (dynamic, 64 bytes per sub-fingerprint): up to kQueryLds sub-fingerprints; longer queries are read
+// through the scalar cache
+constexpr uint32_t kQueryLds = 512;
+
+// starts_a / starts_b: grid + 1 entry indices: workgroup g owns the entries [starts[g], starts[g + 1])
+template <bool FULL, bool ALL_FEED, bool QLDS>
+__global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kernel(
+    const uint4* __restrict__ recs, const uint32_t* __restrict__ off, const uint32_t* __restrict__ q,
+    const uint32_t* __restrict__ starts_a, const uint32_t* __restrict__ starts_b, const float* __restrict__ tri_tbl,
+    unsigned int* score_bits, unsigned long long* key_out, const SlideArgs a) {
+    __shared__ float s_tri[kTriSize];
+    __shared__ uint32_t s_queue[kScanWaves][4 * kSlots + 4];
+    __shared__ unsigned long long s_k[kScanWaves];
+    __shared__ uint32_t s_cursor[2][2];                                    // per mode: next entry to claim, end of the run
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_qbuf[];      // QLDS: nq * kQWords words
+    for (uint32_t i = threadIdx.x; i < kTriSize; i += kScanThreads) s_tri[i] = tri_tbl[i];
+    if (QLDS)
+        for (uint32_t i = threadIdx.x; i < (a.nq + 1u) * kQWords; i += kScanThreads) s_qbuf[i] = q[i];
+    if (threadIdx.x == 0) {
+        s_cursor[0][0] = starts_a[blockIdx.x]; s_cursor[0][1] = starts_a[blockIdx.x + 1];
+        s_cursor[1][0] = starts_b[blockIdx.x]; s_cursor[1][1] = starts_b[blockIdx.x + 1];
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t* s_start = s_queue[wave];            // kSlots + 1 task starts
+    uint32_t* s_off = s_start + kSlots + 4;
+    uint32_t* s_ne = s_off + kSlots;
+    uint32_t* s_ent = s_ne + kSlots;
+    SlidePtrs p;
+    p.recs = recs; p.off = off; p.q = q; p.score_bits = score_bits;
+    const uint32_t* s_q = QLDS ? s_qbuf : nullptr;
+    unsigned long long best = 0ull;
+#ifdef LBAD_SLIDE_PROF
+    if (lane < 16) s_slide_prof[wave][lane] = 0ull;
+#endif
+    LBAD_PROF_T(k0);
+#ifdef LBAD_SLIDE_PROF
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Two of the sixteen waves take the B entries first, the others the A entries; whoever runs out moves on to the
+    // other kind.  Where B entries are rare (a short query: the few entries not longer than it) finding them is a walk
+    // over the whole run's offsets -- latency, not arithmetic -- and hides behind the others' A passes this way.
+    const bool b_first = wave >= kScanWaves - 2;
+    if (b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, best);
+    best = scan_mode<false, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[0], s_start, s_off, s_ne, s_ent, best);
+    LBAD_PROF_T(k1);
+    if (!b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, best);
+    LBAD_PROF_T(k2);
+    LBAD_PROF_ADD(6, k0, k1);
+    LBAD_PROF_ADD(7, k1, k2);
+    LBAD_PROF_ADD(8, 0ull, 1ull);
+#ifdef LBAD_SLIDE_PROF
+    LBAD_PROF_ADD(9, rt0, __builtin_amdgcn_s_memrealtime());      // 100 MHz ticks of the wave's whole scan
+    if (lane == 0) {
+        const unsigned long long busy = __builtin_amdgcn_s_memrealtime() - rt0;
+        atomicMax(&g_slide_prof[10], busy);
+        atomicMin(&g_slide_prof[11], busy);
+    }
+    if (lane < 10 || lane == 13 || lane == 14) atomicAdd(&g_slide_prof[lane], s_slide_prof[wave][lane]);
+#endif
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off2, 64);
+        best = o > best ? o : best;
+    }
+    if (lane == 0) s_k[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = s_k[0];
+        for (int i = 1; i < kScanWaves; ++i) m = s_k[i] > m ? s_k[i] : m;
+        if (m) atomicMax(key_out, m);
+    }
+}
+
+// ---- the plan of a query length: where every workgroup's run of entries starts ---------------------------------------
+// tasks of an entry of ne sub-fingerprints against a query of nq: groups of four of its |ne - nq| + 1 sliding offsets;
+// Fp.m:123-131 swaps only when the query is SHORTER, so an entry of the query's length slides along the query ("B")
+__device__ __forceinline__ void entry_tasks(uint32_t ne, uint32_t nq, uint32_t& ta, uint32_t& tb) {
+    ta = ne > nq ? (ne - nq + 4u) >> 2 : 0u;
+    tb = ne <= nq ? (nq - ne + 4u) >> 2 : 0u;
+}
+constexpr uint32_t kPlanPerThread = 4, kPlanPerBlock = kSlThreads * kPlanPerThread;
+
+// sums of a block of 1024 entries -> block_sums[2 b], [2 b + 1]
+__global__ __launch_bounds__(kSlThreads) void slide_plan_sums_kernel(const uint32_t* __restrict__ off, uint64_t n_entries, uint32_t nq,
+                                                                    uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_a[kSlThreads / 64], s_b[kSlThreads / 64];
+    const uint64_t e0 = (uint64_t)blockIdx.x * kPlanPerBlock + (uint64_t)threadIdx.x * kPlanPerThread;
+    uint32_t sa = 0, sb = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPlanPerThread; ++k) {
+        const uint64_t e = e0 + k;
+        if (e < n_entries) {
+            uint32_t ta, tb;
+            entry_tasks(off[e + 1] - off[e], nq, ta, tb);
+            sa += ta; sb += tb;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sa += __shfl_xor((int)sa, d, 64); sb += __shfl_xor((int)sb, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = sa; s_b[threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ta = 0, tb = 0;
+        for (int i = 0; i < kSlThreads / 64; ++i) { ta += s_a[i]; tb += s_b[i]; }
+        block_sums[2 * blockIdx.x] = ta;
+        block_sums[2 * blockIdx.x + 1] = tb;
+    }
+}
+
+// exclusive scan of the block sums in place (one workgroup); presets the run starts: starts[0] = 0, the others =
+// n_entries (a workgroup whose share begins behind the last task owns nothing)
+__global__ __launch_bounds__(1024) void slide_plan_scan_kernel(uint32_t* __restrict__ block_sums, uint32_t n_blocks, uint32_t n_entries,
+                                                                uint32_t grid, uint32_t chunk_a, uint32_t chunk_b,
+                                                                uint32_t* __restrict__ starts_a, uint32_t* __restrict__ starts_b) {
+    __shared__ uint32_t s_wa[16], s_wb[16];
+    __shared__ uint32_t s_carry[2];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t g = threadIdx.x; g <= grid; g += 1024u) {
+        starts_a[g] = (g && chunk_a) ? n_entries : 0u;      // no tasks of a kind: every run of that kind is empty
+        starts_b[g] = (g && chunk_b) ? n_entries : 0u;
+    }
+    if (threadIdx.x == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t va = i < n_blocks ? block_sums[2 * i] : 0u, vb = i < n_blocks ? block_sums[2 * i + 1] : 0u;
+        uint32_t ia = va, ib = vb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ta = (uint32_t)__shfl_up((int)ia, d, 64), tb = (uint32_t)__shfl_up((int)ib, d, 64);
+            if (lane >= (uint32_t)d) { ia += ta; ib += tb; }
+        }
+        if (lane == 63) { s_wa[wv] = ia; s_wb[wv] = ib; }
+        __syncthreads();
+        uint32_t oa = s_carry[0], ob = s_carry[1];
+        for (uint32_t k = 0; k < wv; ++k) { oa += s_wa[k]; ob += s_wb[k]; }
+        if (i < n_blocks) {
+            block_sums[2 * i] = oa + ia - va;
+            block_sums[2 * i + 1] = ob + ib - vb;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { s_carry[0] = oa + ia; s_carry[1] = ob + ib; }
+        __syncthreads();
+    }
+}
+
+// starts[g] = the first entry whose tasks begin at or behind task g * chunk (tasks in front of it >= g * chunk): a
+// workgroup owns WHOLE entries, its share differs from chunk by less than one entry's tasks
+__global__ __launch_bounds__(kSlThreads) void slide_plan_final_kernel(const uint32_t* __restrict__ off, uint64_t n_entries, uint32_t nq,
+                                                                     const uint32_t* __restrict__ block_sums, uint32_t chunk_a,
+                                                                     uint32_t chunk_b, uint32_t* __restrict__ starts_a,
+                                                                     uint32_t* __restrict__ starts_b) {
+    __shared__ uint32_t s_a[kSlThreads / 64], s_b[kSlThreads / 64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t e0 = (uint64_t)blockIdx.x * kPlanPerBlock + (uint64_t)threadIdx.x * kPlanPerThread;
+    uint32_t ta[kPlanPerThread], tb[kPlanPerThread], sa = 0, sb = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPlanPerThread; ++k) {
+        ta[k] = tb[k] = 0;
+        if (e0 + k < n_entries) entry_tasks(off[e0 + k + 1] - off[e0 + k], nq, ta[k], tb[k]);
+        sa += ta[k]; sb += tb[k];
+    }
+    uint32_t ia = sa, ib = sb;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t xa = (uint32_t)__shfl_up((int)ia, d, 64), xb = (uint32_t)__shfl_up((int)ib, d, 64);
+        if (lane >= (uint32_t)d) { ia += xa; ib += xb; }
+    }
+    if (lane == 63) { s_a[wv] = ia; s_b[wv] = ib; }
+    __syncthreads();
+    uint64_t pa = (uint64_t)block_sums[2 * blockIdx.x] + ia - sa, pb = (uint64_t)block_sums[2 * blockIdx.x + 1] + ib - sb;
+    for (uint32_t k = 0; k < wv; ++k) { pa += s_a[k]; pb += s_b[k]; }
+#pragma unroll
+    for (uint32_t k = 0; k < kPlanPerThread; ++k) {
+        const uint64_t e = e0 + k;
+        if (e < n_entries) {
+            // entry e + 1 is the first with >= g chunk tasks in front of it for every g with pa < g chunk <= pa + ta
+            if (ta[k] && chunk_a)
+                for (uint64_t g = pa / chunk_a + 1u; g * chunk_a <= pa + ta[k]; ++g) starts_a[g] = (uint32_t)(e + 1u);
+            if (tb[k] && chunk_b)
+                for (uint64_t g = pb / chunk_b + 1u; g * chunk_b <= pb + tb[k]; ++g) starts_b[g] = (uint32_t)(e + 1u);
+            pa += ta[k]; pb += tb[k];
+        }
+    }
+}
+
+// ---- short queries (up to 7 sub-fingerprints): the round-3 systolic scan --------------------------------------------
+// A lane holds ONE record (two aligned, fully coalesced dwordx4 per lane: every record is read once, 16 cache lines per
+// wave instruction -- the task kernel above reads a lane's four-record window from 64 different lines and is bound by
+// the texture path when the steps are few), the query's sub-fingerprints a = 0, 1, ... are wave-uniform, and an
+// accumulator per sliding offset travels one lane to the right per step (`v_add_f32 ... wave_shr:1`).  Every (query,
+// record) pair is evaluated, also on the diagonals that leave their entry -- with a query of q against entries of n
+// that is (q - 1) / n of the work, a tenth at q = 5 -- and the scan is HBM-bound.  Chunks of 64 records overlap by
+// min(n_query, longest entry) - 1.  The place of a record inside its entry comes from the record (w3 / w7, see the top of
+// the file): no side table, no search.
+//   entry longer than the query ("A" lanes): a diagonal starts in step 0 in every lane and is complete after the last
+//     step; it is an offset of the entry iff it stayed inside the entry (i >= n_query - 1).
+//   entry not longer than the query ("B" lanes): a diagonal starts whenever it enters the entry's first lane (i == 0) and
+//     is complete when it leaves the last one (r == 0); that lane keeps the maximum over the steps.
+// Diagonals that did not start properly carry -inf.
 struct Rec {
     uint32_t P[4], N[4];
     uint32_t isat, rem, idx;
@@ -53,25 +753,11 @@ struct Rec {
 __device__ __forceinline__ Rec unpack_rec(const uint4 a, const uint4 b) {
     Rec r;
     r.P[0] = a.x; r.P[1] = a.y; r.P[2] = a.z; r.P[3] = a.w & 0xFu;
-    r.N[0] = __funnelshift_r(a.w, b.x, 4);
-    r.N[1] = __funnelshift_r(b.x, b.y, 4);
-    r.N[2] = __funnelshift_r(b.y, b.z, 4);
-    r.N[3] = (b.z >> 4) & 0xFu;
-    r.isat = (b.z >> 8) & 0xFFFu;
-    r.rem = b.z >> 20;
-    r.idx = b.w;
+    r.N[0] = b.x; r.N[1] = b.y; r.N[2] = b.z; r.N[3] = b.w & 0xFu;
+    r.isat = (a.w >> 21) & 0xFu;
+    r.rem = (a.w >> 25) & 0xFu;
+    r.idx = (b.w >> 4) | ((a.w >> 17) & 0xFu) << 28;
     return r;
-}
-
-__device__ __forceinline__ unsigned long long sl_key(float score, uint64_t global_index) {
-    return ((unsigned long long)__float_as_uint(score) << 32) |
-           (unsigned long long)(0xFFFFFFFFu - (uint32_t)global_index);
-}
-
-// value of lane l - 1 (lane 0 receives 0; whatever enters a chunk from the left belongs to a window that is not
-// wholly inside the chunk and is never used)
-__device__ __forceinline__ float from_left_lane(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
 }
 
 constexpr int kNegInf = (int)0xFF800000u;   // -inf; as a signed integer it sorts below the bits of every sum >= 0
@@ -80,7 +766,7 @@ constexpr int kNegInf = (int)0xFF800000u;   // -inf; as a signed integer it sort
 // set k - 1 to set k inside the lane and crosses to the next lane only from set K - 1 to set 0.
 // MODE 0: every entry in the chunk is longer than the query; 1: none is; 2: mixed.
 template <int K, int MODE>
-__device__ __forceinline__ void run_steps(const uint32_t (&P)[K][4], const uint32_t (&N)[K][4], const uint32_t (&nz)[K][4],
+__device__ __forceinline__ void short_steps(const uint32_t (&P)[K][4], const uint32_t (&N)[K][4], const uint32_t (&nz)[K][4],
                                           const uint32_t (&tri)[K], const bool (&case_a)[K], const bool (&start_b)[K],
                                           const uint32_t* __restrict__ q, uint32_t nq, const float* s_tri,
                                           float (&acc)[K], int (&smax)[K]) {
@@ -123,7 +809,7 @@ __device__ __forceinline__ void run_steps(const uint32_t (&P)[K][4], const uint3
             }
             ratio[k] = s_tri[h];
         }
-        const float in0 = from_left_lane(acc[K - 1]);
+        const float in0 = __uint_as_float(from_left_lane(__float_as_uint(acc[K - 1])));
 #pragma unroll
         for (int k = K - 1; k >= 0; --k) {
             float sh = k ? acc[k - 1] : in0;
@@ -136,7 +822,7 @@ __device__ __forceinline__ void run_steps(const uint32_t (&P)[K][4], const uint3
 }
 
 template <int K>
-__global__ __launch_bounds__(kSlThreads) void compare_sliding_kernel(
+__global__ __launch_bounds__(kSlThreads) void compare_short_kernel(
     const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
     uint64_t n_chunks, uint4 range_mask, const float* __restrict__ tri_tbl, uint64_t index_base,
     unsigned int* __restrict__ score_bits, unsigned long long* __restrict__ key_out) {
@@ -186,9 +872,9 @@ __global__ __launch_bounds__(kSlThreads) void compare_sliding_kernel(
 
         float acc[K];
         int smax[K];
-        if (!any_b) run_steps<K, 0>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
-        else if (!any_a) run_steps<K, 1>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
-        else run_steps<K, 2>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
+        if (!any_b) short_steps<K, 0>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
+        else if (!any_a) short_steps<K, 1>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
+        else short_steps<K, 2>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
 
         // a record closes a window iff the window lies inside its entry AND inside this chunk.  The exact
         // division (Fp.m:144) runs only where the sum can reach the lane's best so far.
@@ -225,60 +911,6 @@ __global__ __launch_bounds__(kSlThreads) void compare_sliding_kernel(
     }
 }
 
-// Fallback for a long query against long entries (overlap of 64 records or more): one workgroup per entry,
-// one thread per sliding offset, true divisions.
-__global__ __launch_bounds__(kSlThreads) void compare_ragged_long_kernel(
-    const uint4* __restrict__ recs, const uint32_t* __restrict__ off, uint64_t n_entries, const uint32_t* __restrict__ q,
-    uint32_t nq, uint4 range_mask, uint64_t index_base, unsigned int* __restrict__ score_bits,
-    unsigned long long* __restrict__ key_out) {
-    __shared__ unsigned int s_best[kSlThreads / 64];
-    const uint32_t rm[4] = {range_mask.x, range_mask.y, range_mask.z, range_mask.w};
-    unsigned long long best_key = 0ull;
-    for (uint64_t e = blockIdx.x; e < n_entries; e += gridDim.x) {
-        const uint32_t p0 = off[e];
-        const uint32_t ne = off[e + 1] - p0;
-        const bool case_a = ne > nq;
-        const uint32_t n1 = case_a ? ne : nq, n2 = case_a ? nq : ne;
-        unsigned int best = 0u;
-        for (uint32_t o = threadIdx.x; o + n2 <= n1; o += kSlThreads) {
-            float sum = 0.0f;
-            for (uint32_t i = 0; i < n2; ++i) {
-                const uint32_t es = case_a ? i + o : i;     // entry sub-fingerprint
-                const uint32_t qs = case_a ? i : i + o;     // query sub-fingerprint
-                const Rec r = unpack_rec(recs[2 * (uint64_t)(p0 + es)], recs[2 * (uint64_t)(p0 + es) + 1]);
-                const uint32_t* qa = q + (size_t)qs * kQWords;
-                uint32_t hits = 0, possible = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const uint32_t t = (r.P[w] ^ qa[w]) | (r.N[w] ^ qa[4 + w]);
-                    const uint32_t nz = case_a ? (r.P[w] | r.N[w]) & rm[w] : qa[8 + w];
-                    possible += __popc(nz);
-                    hits += __popc(nz & ~t);
-                }
-                sum = __fadd_rn(sum, possible ? __fdiv_rn((float)hits, (float)possible) : 0.0f);
-            }
-            const unsigned int bits = __float_as_uint(__fdiv_rn(sum, (float)n2));
-            best = bits > best ? bits : best;
-        }
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) {
-            const unsigned int v = __shfl_xor(best, sh, 64);
-            best = v > best ? v : best;
-        }
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int m = s_best[0];
-            for (int i = 1; i < kSlThreads / 64; ++i) m = s_best[i] > m ? s_best[i] : m;
-            if (score_bits) score_bits[e] = m;
-            const unsigned long long k = ((unsigned long long)m << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)(index_base + e));
-            best_key = k > best_key ? k : best_key;
-        }
-    }
-    if (threadIdx.x == 0 && best_key) atomicMax(key_out, best_key);
-}
-
 // even-position bits of a 32-bit word, compacted into 16
 __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
     x &= 0x55555555u;
@@ -289,22 +921,37 @@ __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
     return x;
 }
 
+// the record of the eight words P[0..3], N[0..3] (pairs beyond 99 cleared) with its derived fields: the full-range table
+// row and its place (entry `ent`, sub-fingerprint i of it, r more behind it)
+__device__ __forceinline__ void store_record(uint4* __restrict__ recs, uint64_t p, const uint32_t (&P)[4], const uint32_t (&N)[4],
+                                             uint32_t ent, uint32_t i, uint32_t r) {
+    const uint32_t p3 = P[3] & 0xFu, n3 = N[3] & 0xFu;
+    const uint32_t possible = __popc(P[0] | N[0]) + __popc(P[1] | N[1]) + __popc(P[2] | N[2]) + __popc(p3 | n3);
+    const uint32_t row = possible * (possible + 1u) / 2u;
+    const uint32_t isat = i < 15u ? i : 15u, rsat = r < 15u ? r : 15u;
+    recs[2 * p] = make_uint4(P[0], P[1], P[2], p3 | (row << 4) | ((ent >> 28) << 17) | (isat << 21) | (rsat << 25));
+    recs[2 * p + 1] = make_uint4(N[0], N[1], N[2], n3 | (ent << 4));
+}
+
+// entry e with off[e] <= p < off[e + 1] among n entries (off: n + 1 increasing record positions)
+__device__ __forceinline__ uint64_t entry_of(const uint32_t* __restrict__ off, uint64_t n, uint64_t p) {
+    uint64_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 // packed sub-fingerprints (8-word slots, Boolean b at bit b) of whole entries -> records.  off: ABSOLUTE record
-// positions of the new entries (n_new + 1 values); slot t becomes record off[0] + t.
+// positions of the new entries (n_new + 1 values); slot t becomes record off[0] + t
 __global__ __launch_bounds__(kSlThreads) void pack_records_kernel(const uint32_t* __restrict__ slots, uint64_t n_new_pos,
                                                                   const uint32_t* __restrict__ off, uint64_t n_new,
                                                                   uint32_t first_entry, uint4* __restrict__ recs) {
     const uint64_t t = (uint64_t)blockIdx.x * kSlThreads + threadIdx.x;
     if (t >= n_new_pos) return;
     const uint64_t p = (uint64_t)off[0] + t;
-    // entry with off[e] <= p < off[e + 1]
-    uint64_t lo = 0, hi = n_new;
-    while (hi - lo > 1) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (off[mid] <= p) lo = mid; else hi = mid;
-    }
-    const uint32_t i = (uint32_t)p - off[lo];
-    const uint32_t rem = off[lo + 1] - 1u - (uint32_t)p;
+    const uint64_t e = entry_of(off, n_new, p);
     const uint4* s = reinterpret_cast<const uint4*>(slots + t * kPackedWords);
     const uint4 a = s[0], b = s[1];
     const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -316,18 +963,34 @@ __global__ __launch_bounds__(kSlThreads) void pack_records_kernel(const uint32_t
         P[k] = even_bits(w0) | (even_bits(w1) << 16);
         N[k] = even_bits(w0 >> 1) | (even_bits(w1 >> 1) << 16);
     }
-    P[3] &= 0xFu;
-    N[3] &= 0xFu;
-    const uint32_t isat = i < 4095u ? i : 4095u, rsat = rem < 4095u ? rem : 4095u;
-    uint4 ra, rb;
-    ra.x = P[0]; ra.y = P[1]; ra.z = P[2];
-    ra.w = P[3] | (N[0] << 4);
-    rb.x = (N[0] >> 28) | (N[1] << 4);
-    rb.y = (N[1] >> 28) | (N[2] << 4);
-    rb.z = (N[2] >> 28) | (N[3] << 4) | (isat << 8) | (rsat << 20);
-    rb.w = first_entry + (uint32_t)lo;
-    recs[2 * p] = ra;
-    recs[2 * p + 1] = rb;
+    store_record(recs, p, P, N, first_entry + (uint32_t)e, (uint32_t)p - off[e], off[e + 1] - 1u - (uint32_t)p);
+}
+
+// Records that come from a FILE: keep the 200 Booleans, recompute everything derived (table row; place fields from the
+// offsets the loader built out of the validated counts), clear everything reserved.
+// old_layout: the round-3 file ("LBADCRP2": P at bits 0..99, N at bits 100..199, place fields above).
+__global__ __launch_bounds__(kSlThreads) void restamp_records_kernel(uint4* __restrict__ recs, const uint32_t* __restrict__ off,
+                                                                     uint64_t n_entries, uint64_t n, uint32_t old_layout,
+                                                                     uint4 pair_mask) {
+    const uint64_t t = (uint64_t)blockIdx.x * kSlThreads + threadIdx.x;
+    if (t >= n) return;
+    const uint4 a = recs[2 * t], b = recs[2 * t + 1];
+    uint32_t P[4], N[4];
+    if (old_layout) {
+        P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w & 0xFu;
+        N[0] = __funnelshift_r(a.w, b.x, 4);
+        N[1] = __funnelshift_r(b.x, b.y, 4);
+        N[2] = __funnelshift_r(b.y, b.z, 4);
+        N[3] = (b.z >> 4) & 0xFu;
+    } else {
+        P[0] = a.x; P[1] = a.y; P[2] = a.z; P[3] = a.w & 0xFu;
+        N[0] = b.x; N[1] = b.y; N[2] = b.z; N[3] = b.w & 0xFu;
+    }
+    const uint32_t pm[4] = {pair_mask.x, pair_mask.y, pair_mask.z, pair_mask.w};   // pairs the length has
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { P[k] &= pm[k]; N[k] &= pm[k]; }
+    const uint64_t e = entry_of(off, n_entries, t);
+    store_record(recs, t, P, N, (uint32_t)e, (uint32_t)t - off[e], off[e + 1] - 1u - (uint32_t)t);
 }
 
 // synthetic ragged corpus: sub-fingerprint s of entry e is lbo_synth_entry's (oracle/lbad_oracle.c), entry e has
@@ -379,9 +1042,9 @@ struct TriTable {
 };
 TriTable g_tri;
 
-uint4 sliding_range_mask(uint32_t subfp_len, uint32_t range) {
-    const uint32_t lim = range < subfp_len ? range : subfp_len;      // Fp.m:155
-    const uint32_t pairs = (lim + 1u) / 2u;
+// pair bits 0 .. ceil(limit / 2) - 1
+uint4 pair_mask(uint32_t limit) {
+    const uint32_t pairs = (limit + 1u) / 2u;
     uint32_t m[4];
     for (uint32_t w = 0; w < 4; ++w) {
         const uint32_t base = 32u * w;
@@ -390,11 +1053,15 @@ uint4 sliding_range_mask(uint32_t subfp_len, uint32_t range) {
     return make_uint4(m[0], m[1], m[2], m[3]);
 }
 
+uint4 sliding_range_mask(uint32_t subfp_len, uint32_t range) {
+    return pair_mask(range < subfp_len ? range : subfp_len);      // Fp.m:155
+}
+
 }  // namespace
 
 bool sliding_supported(uint32_t subfp_len) { return subfp_len >= 1 && subfp_len <= 2 * kTriPairs; }
 
-uint32_t sliding_query_words(uint32_t n_query) { return n_query * kQWords; }
+uint32_t sliding_query_words(uint32_t n_query) { return kQHeader + n_query * kQWords; }
 
 // the table of correctly rounded quotients hits / possible, row `possible` at possible (possible + 1) / 2
 const float* sliding_tri_table() {
@@ -415,16 +1082,17 @@ const float* sliding_tri_table() {
     return d;
 }
 
-// Host: the query block of the scan from unpacked Booleans (n_query x subfp_len)
+// Host: the query block of the scan from unpacked Booleans (n_query x subfp_len): kQHeader reserved words, then 16
+// words per sub-fingerprint
 void build_sliding_query(const Boolean* bools, uint32_t n_query, uint32_t subfp_len, uint32_t range,
                          std::vector<uint32_t>& out) {
-    out.assign((size_t)n_query * kQWords, 0u);
+    out.assign((size_t)kQHeader + ((size_t)n_query + 1u) * kQWords, 0u);      // one zero sub-fingerprint of slack (fetch-ahead)
     const uint4 rm4 = sliding_range_mask(subfp_len, range);
     const uint32_t rm[4] = {rm4.x, rm4.y, rm4.z, rm4.w};
     const uint32_t pairs = (subfp_len + 1u) / 2u;
     for (uint32_t s = 0; s < n_query; ++s) {
         const Boolean* b = bools + (size_t)s * subfp_len;
-        uint32_t* o = out.data() + (size_t)s * kQWords;
+        uint32_t* o = out.data() + kQHeader + (size_t)s * kQWords;
         for (uint32_t p = 0; p < pairs; ++p) {
             if (b[2 * p]) o[p >> 5] |= 1u << (p & 31);
             if (2 * p + 1 < subfp_len && b[2 * p + 1]) o[4 + (p >> 5)] |= 1u << (p & 31);
@@ -439,13 +1107,24 @@ void build_sliding_query(const Boolean* bools, uint32_t n_query, uint32_t subfp_
     }
 }
 
+// d_off_new: ABSOLUTE record positions of the n_new new entries (n_new + 1 values, the first one = the position of slot 0)
 hipError_t launch_pack_records(const uint32_t* d_slots, uint64_t n_new_pos, const uint32_t* d_off_new, uint64_t n_new,
-                               uint32_t first_entry, uint4* d_recs_at_first, hipStream_t stream) {
+                               uint32_t first_entry, uint4* d_recs, hipStream_t stream) {
     if (n_new_pos == 0) return hipSuccess;
     const uint64_t blocks = (n_new_pos + kSlThreads - 1) / kSlThreads;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pack_records_kernel, dim3((uint32_t)blocks), dim3(kSlThreads), 0, stream, d_slots, n_new_pos,
-                       d_off_new, n_new, first_entry, d_recs_at_first);
+    hipLaunchKernelGGL(pack_records_kernel, dim3((uint32_t)blocks), dim3(kSlThreads), 0, stream, d_slots, n_new_pos, d_off_new,
+                       n_new, first_entry, d_recs);
+    return hipGetLastError();
+}
+
+hipError_t launch_restamp_records(uint4* d_recs, const uint32_t* d_off, uint64_t n_entries, uint64_t n, uint32_t subfp_len,
+                                  bool old_layout, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + kSlThreads - 1) / kSlThreads;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(restamp_records_kernel, dim3((uint32_t)blocks), dim3(kSlThreads), 0, stream, d_recs, d_off, n_entries, n,
+                       old_layout ? 1u : 0u, pair_mask(subfp_len));
     return hipGetLastError();
 }
 
@@ -459,40 +1138,140 @@ hipError_t launch_synth_ragged(uint32_t seed, uint64_t first_entry, uint64_t n_e
     return hipGetLastError();
 }
 
-// d_off: n_entries + 1 record positions; ne_max: the longest entry.  d_score_bits (optional, n_entries words)
-// must be zero on entry and receives the float bits of every entry's match; *d_key is max-ed.
-hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries,
-                                  uint32_t ne_max, uint32_t subfp_len, const uint32_t* d_qblk, uint32_t n_query,
-                                  uint32_t range, uint64_t index_base, unsigned int* d_score_bits,
-                                  unsigned long long* d_key, hipStream_t stream) {
-    if (n_entries == 0 || n_pos == 0 || n_query == 0) return hipSuccess;
+// ---- the plan and the scan ---------------------------------------------------------------------------------------------
+// a query (or a corpus) so short that a sliding window reaches back at most kShortLook records: the systolic scan (the
+// records' place fields saturate at 15, which bounds it at 14; measured cross-over with the task kernel: see DESIGN.md)
+#ifndef LBAD_SHORT_LOOK
+#define LBAD_SHORT_LOOK 14
+#endif
+bool sliding_short(uint32_t n_query, uint32_t ne_max) { return (n_query < ne_max ? n_query : ne_max) <= LBAD_SHORT_LOOK + 1u; }
+
+static void sliding_variant(uint32_t subfp_len, uint32_t n_query, uint32_t range, bool& full, bool& all_feed, bool& qlds, uint32_t& dyn_lds) {
     const uint4 rm = sliding_range_mask(subfp_len, range);
-    const uint32_t look = (n_query < ne_max ? n_query : ne_max) - 1u;   // records a window reaches back
-    const int cus = device_cu_count();
-    if (look >= 64u) {
-        const uint64_t cap = (uint64_t)cus * 8u;
-        const uint32_t grid = (uint32_t)(n_entries < cap ? n_entries : cap);
-        hipLaunchKernelGGL(compare_ragged_long_kernel, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, d_off, n_entries,
-                           d_qblk, n_query, rm, index_base, d_score_bits, d_key);
-        return hipGetLastError();
-    }
-    const float* tri = sliding_tri_table();
-    if (!tri) return hipErrorOutOfMemory;
-    // 64 K records per wave and chunk; a short overlap relative to the chunk keeps the repeated work small
-    const uint32_t K = look <= 6u ? 1u : 4u;
-    const uint32_t step = 64u * K - look;
-    const uint64_t span = 64ull * K;
-    const uint64_t n_chunks = n_pos <= span ? 1u : (n_pos - span + step - 1u) / step + 1u;
-    const uint64_t want = (n_chunks + (kSlThreads / 64) - 1) / (kSlThreads / 64);
-    const uint64_t cap = (uint64_t)cus * 6u;                             // 21 KB of LDS per workgroup
-    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    if (K == 1)
-        hipLaunchKernelGGL(compare_sliding_kernel<1>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_qblk,
-                           n_query, step, n_chunks, rm, tri, index_base, d_score_bits, d_key);
-    else
-        hipLaunchKernelGGL(compare_sliding_kernel<4>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_qblk,
-                           n_query, step, n_chunks, rm, tri, index_base, d_score_bits, d_key);
+    const uint4 all = pair_mask(subfp_len);
+    full = rm.x == all.x && rm.y == all.y && rm.z == all.z && rm.w == all.w;
+    all_feed = n_query <= 6u;     // short queries: every lane reads its own records, nothing travels
+    qlds = n_query <= kQueryLds;
+    dyn_lds = qlds ? (n_query + 1u) * kQWords * 4u : 0u;
+}
+
+// Shape of a scan: one workgroup per CU, each with 1 / grid of the tasks of either kind (whole entries).
+SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b) {
+    SlideShape sh;
+    const uint64_t passes = (tasks_a + 63) / 64 + (tasks_b + 63) / 64;
+    const uint64_t want = (passes + kScanWaves - 1) / kScanWaves;
+    uint64_t cap = (uint64_t)device_cu_count() * kScanPerCu;
+    if (cap > kSlideMaxGrid) cap = kSlideMaxGrid;
+    sh.grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
+    auto chunk = [&](uint64_t tasks) -> uint32_t {
+        if (tasks == 0) return 0u;
+        const uint64_t per = (tasks + sh.grid - 1) / sh.grid;
+        return (uint32_t)(per ? per : 1);
+    };
+    sh.chunk_a = chunk(tasks_a);
+    sh.chunk_b = chunk(tasks_b);
+    return sh;
+}
+
+// words of a plan buffer for a corpus of `capacity` entries: starts_a, starts_b (kSlideMaxGrid + 1 each), block sums
+// (2 per 1024 entries)
+size_t sliding_plan_words(uint64_t capacity) {
+    return 2 * (size_t)(kSlideMaxGrid + 1) + 2 * (size_t)((capacity + kPlanPerBlock - 1) / kPlanPerBlock) + 8;
+}
+
+// Where every workgroup's run of entries starts, for queries of n_query sub-fingerprints: three small launches (block
+// sums of the entries' task counts, their scan, the boundaries), about 15 us for 1 M entries; the corpus keeps the plan
+// until the query length or the entries change.
+hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, const SlideShape& sh, uint32_t* d_plan,
+                               hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    uint32_t* starts_a = d_plan;
+    uint32_t* starts_b = starts_a + (kSlideMaxGrid + 1);
+    uint32_t* sums = starts_b + (kSlideMaxGrid + 1);
+    const uint64_t nb = (n_entries + kPlanPerBlock - 1) / kPlanPerBlock;
+    if (nb > 0x7fffffffull || n_entries > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(slide_plan_sums_kernel, dim3((uint32_t)nb), dim3(kSlThreads), 0, stream, d_off, n_entries, n_query, sums);
+    hipLaunchKernelGGL(slide_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nb, (uint32_t)n_entries, sh.grid,
+                       sh.chunk_a, sh.chunk_b, starts_a, starts_b);
+    hipLaunchKernelGGL(slide_plan_final_kernel, dim3((uint32_t)nb), dim3(kSlThreads), 0, stream, d_off, n_entries, n_query, sums,
+                       sh.chunk_a, sh.chunk_b, starts_a, starts_b);
     return hipGetLastError();
 }
+
+// tasks_a / tasks_b: groups of four sliding offsets over the entries longer than / not longer than the query (from the
+// host's histogram of entry lengths).  d_query: what build_sliding_query made.  zero_rec: index of an all-zero record
+// behind the stored ones.  d_score_bits (optional, n_entries words) must be zero on entry and receives the float bits of
+// every entry's match; *d_key is max-ed.
+hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries, uint32_t ne_max,
+                                  uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
+                                  uint32_t subfp_len, const uint32_t* d_query, uint32_t n_query, uint32_t range,
+                                  uint64_t index_base, unsigned int* d_score_bits, unsigned long long* d_key,
+                                  hipStream_t stream) {
+    if (n_entries == 0 || n_query == 0 || tasks_a + tasks_b == 0) return hipSuccess;
+    if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return hipErrorInvalidValue;    // the plan counts in 32 bits
+    const float* tri = sliding_tri_table();
+    if (!tri) return hipErrorOutOfMemory;
+    if (sliding_short(n_query, ne_max)) {
+        // the systolic scan: 64 K records per wave and chunk (K = 4 records per lane once a window reaches back more than six
+        // records: the overlap of consecutive chunks stays a small part of a chunk)
+        const uint32_t look = (n_query < ne_max ? n_query : ne_max) - 1u;
+        const uint32_t K = look <= 6u ? 1u : 4u;
+        const uint32_t step = 64u * K - look;
+        const uint64_t span = 64ull * K;
+        const uint64_t n_chunks = n_pos <= span ? 1u : (n_pos - span + step - 1u) / step + 1u;
+        const uint64_t want = (n_chunks + (kSlThreads / 64) - 1) / (kSlThreads / 64);
+        const uint64_t cap = (uint64_t)device_cu_count() * 6u;                   // 21 KB of LDS per workgroup
+        const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+        const uint4 rm4 = sliding_range_mask(subfp_len, range);
+        if (K == 1)
+            hipLaunchKernelGGL(compare_short_kernel<1>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_query + kQHeader,
+                               n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, d_key);
+        else
+            hipLaunchKernelGGL(compare_short_kernel<4>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_query + kQHeader,
+                               n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, d_key);
+        return hipGetLastError();
+    }
+    SlideArgs a;
+    a.index_base = index_base; a.n_entries = n_entries; a.nq = n_query; a.zero_rec = zero_rec;
+    const uint4 rm = sliding_range_mask(subfp_len, range);
+    a.rm[0] = rm.x; a.rm[1] = rm.y; a.rm[2] = rm.z; a.rm[3] = rm.w;
+    auto dense = [&](uint64_t tasks) -> uint32_t {
+        if (tasks == 0) return 8u;
+        const uint64_t e = (128ull * n_entries + tasks - 1) / tasks;
+        return (uint32_t)(e < 8ull ? 8ull : (e > 4096ull ? 4096ull : e));
+    };
+    a.dense_a = dense(tasks_a);
+    a.dense_b = dense(tasks_b);
+    bool full, all_feed, qlds;
+    uint32_t dyn_lds;
+    sliding_variant(subfp_len, n_query, range, full, all_feed, qlds, dyn_lds);
+    const uint32_t* starts_a = d_plan;
+    const uint32_t* starts_b = starts_a + (kSlideMaxGrid + 1);
+    const uint32_t* q = d_query + kQHeader;
+#define LBAD_SLIDE(FULL, FEED, QL)                                                                                         \
+    hipLaunchKernelGGL((compare_sliding_kernel<FULL, FEED, QL>), dim3(sh.grid), dim3(kScanThreads), dyn_lds, stream, d_recs, \
+                       d_off, q, starts_a, starts_b, tri, d_score_bits, d_key, a)
+    if (full) {
+        if (all_feed) { if (qlds) LBAD_SLIDE(true, true, true); else LBAD_SLIDE(true, true, false); }
+        else { if (qlds) LBAD_SLIDE(true, false, true); else LBAD_SLIDE(true, false, false); }
+    } else {
+        if (all_feed) { if (qlds) LBAD_SLIDE(false, true, true); else LBAD_SLIDE(false, true, false); }
+        else { if (qlds) LBAD_SLIDE(false, false, true); else LBAD_SLIDE(false, false, false); }
+    }
+#undef LBAD_SLIDE
+    return hipGetLastError();
+}
+
+#ifdef LBAD_SLIDE_PROF
+extern "C" int LBAudioDetectiveDebugSlideProfile(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_slide_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        z[11] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_slide_prof), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 }  // namespace lbad

@@ -126,6 +126,62 @@ def test_ragged_save_load(lb, gpu, oracle, tmp_path):
     assert d.query(lb.Fingerprint.from_bools(q)) == (50, 1.0)
 
 
+def _record_words(row, L, old_layout):
+    """One sub-fingerprint of L Booleans as the eight words of a corpus-file record (k_sliding.hip): round-4 layout
+    or the round-3 one ("LBADCRP2": P at bits 0..99, N at bits 100..199, place fields above)."""
+    pairs = (L + 1) // 2
+    P = sum(int(row[2 * p]) << p for p in range(pairs))
+    N = sum(int(row[2 * p + 1]) << p for p in range(pairs) if 2 * p + 1 < L)
+    if old_layout:
+        v = P | (N << 100) | (0xABC << 200) | (0xDEF << 212) | (0x12345678 << 224)     # place fields: garbage on purpose
+        return [(v >> (32 * w)) & 0xFFFFFFFF for w in range(8)]
+    w = [(P >> (32 * k)) & 0xFFFFFFFF for k in range(4)] + [(N >> (32 * k)) & 0xFFFFFFFF for k in range(4)]
+    return w
+
+
+def test_corpus_file_records_are_not_trusted(lb, gpu, oracle, tmp_path):
+    """Round-3 advice: a corpus file's records carried index fields the scan wrote through.  Now nothing a record
+    carries besides its Booleans survives the loader: a file with garbage in every reserved / derived bit and in the
+    pairs beyond the length, and a round-3 file with nonsense place fields, load to corpora whose every score equals
+    the oracle's; a file whose counts do not add up is refused."""
+    import struct
+    rng = np.random.default_rng(31)
+    for L in (200, 33):
+        lens = rng.integers(1, 40, 30)
+        entries = [_rand_fp(rng, int(n), L, p_zero=0.05, p_both=0.02) for n in lens]
+        flat = np.concatenate(entries, axis=0)
+        for old_layout, magic in ((False, b"LBADCRP3"), (True, b"LBADCRP2")):
+            recs = np.array([_record_words(r, L, old_layout) for r in flat], np.uint32)
+            if not old_layout:
+                pairs = (L + 1) // 2
+                junk = rng.integers(0, 2**32, recs.shape, dtype=np.uint32)
+                keep = np.zeros(8, np.uint32)                            # bits that hold pairs < pairs
+                for k in range(4):
+                    nbits = min(32, max(0, pairs - 32 * k)) if k < 3 else min(4, max(0, pairs - 96))
+                    keep[k] = keep[4 + k] = (1 << nbits) - 1 if nbits < 32 else 0xFFFFFFFF
+                recs = (recs & keep) | (junk & ~keep)                     # row field, reserved bits, pairs beyond L: junk
+            p = str(tmp_path / f"crafted_{L}_{int(old_layout)}.lbad")
+            with open(p, "wb") as f:
+                f.write(magic + struct.pack("<IIQQ", L, 0, len(entries), flat.shape[0]))
+                f.write(np.asarray(lens, np.uint32).tobytes())
+                f.write(recs.tobytes())
+            c = lb.Corpus.load(p, L, 0, 0)
+            assert len(c) == len(entries) and c.subfingerprint_total == flat.shape[0]
+            for nq in (1, 7, 21, 45):
+                q = _rand_fp(rng, nq, L, p_zero=0.05, p_both=0.02)
+                k = min(nq, entries[3].shape[0])
+                q[:k] = entries[3][:k]
+                for rg in (0, max(1, L // 2)):
+                    _check_query(lb, oracle, c, entries, q, rg)
+        bad = str(tmp_path / "bad_counts.lbad")
+        with open(bad, "wb") as f:
+            wrong = np.asarray(lens, np.uint32).copy()
+            wrong[0] += 1
+            f.write(b"LBADCRP3" + struct.pack("<IIQQ", L, 0, len(entries), flat.shape[0]) + wrong.tobytes() + recs.tobytes())
+        with pytest.raises(Exception):
+            lb.Corpus.load(bad, L, 0, 0)
+
+
 def test_birds_ten_archives_in_one_corpus(lb, gpu, oracle):
     """Upstream's best-match loop as corpus queries on its own fixtures (LBAudioDetectiveTests.m:57-91).  The ten
     archive recordings (48 .. 115 sub-fingerprints each) live in ONE corpus and each of the 50 sequences is one

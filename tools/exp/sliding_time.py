@@ -5,6 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import torch
 import lbaudiodetective_amd as lb
+from lbaudiodetective_amd import _native as _N
+if os.environ.get("LBAD_LIB"):
+    _N.LIB_PATH = os.path.abspath(os.environ["LBAD_LIB"])
 from oracle import oracle as O
 
 ap = argparse.ArgumentParser()
