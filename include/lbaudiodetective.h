@@ -406,7 +406,8 @@ void LBAudioDetectiveCorpusDecodeKey(UInt64 inKey, SInt64* outIndex, Float32* ou
  * process is reused).  ArgumentInvalid when inIndexBase + the shard's entry count exceeds 2^32 (the key carries
  * a 32-bit global index).  The call is COLLECTIVE: a rank whose own scan cannot run (that error, a NULL corpus, a
  * failed launch) still takes part in the exchange with empty keys, so the other ranks return their result, and
- * reports its own status afterwards; only a NULL communicator or a count of zero returns without the exchange. */
+ * reports its own status afterwards; only a NULL communicator or a count of zero returns without the exchange
+ * (nothing is allocated by the call: the key block belongs to the corpus). */
 OSStatus LBAudioDetectiveCorpusQuerySharded(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,
                                             UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
                                             SInt64* outIndex, Float32* outScore);
@@ -414,6 +415,25 @@ OSStatus LBAudioDetectiveCorpusQueryBatchSharded(LBAudioDetectiveCorpusRef inCor
                                                  const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
                                                  UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
                                                  SInt64* outIndices, Float32* outScores);
+/* The same with the exchange step handed in: inAllReduce(inContext, keys, count, stream) must leave in `keys` (a
+ * DEVICE array of `count` unsigned 64-bit words, in place) the element-wise MAXIMUM over all ranks, ordered on `stream`
+ * -- what ncclAllReduce(keys, keys, count, ncclUint64, ncclMax, comm, stream) does; return noErr or an error status.
+ * LBAudioDetectiveCorpusQueryBatchSharded is this function with RCCL's all-reduce.  For hosts that bring their own
+ * collective (MPI, a different RCCL build) and for tests that run several "ranks" inside one process.  Batches of more
+ * than LBAD_SHARD_KEYS queries run as several exchanges, cut the same way on every rank.  After the exchange has been
+ * enqueued the call waits for the stream at most LBAudioDetectiveSetExchangeTimeout milliseconds (default 60 000,
+ * 0 = for ever) and returns kLBAudioDetectiveCollectiveError when a peer never joined. */
+#define LBAD_SHARD_KEYS 4096
+typedef OSStatus (*LBAudioDetectiveAllReduceMaxFn)(void* inContext, UInt64* ioDeviceKeys, UInt32 inCount, void* inStream);
+OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef inCorpus,
+                                                     const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
+                                                     UInt32 inRange, UInt64 inIndexBase,
+                                                     LBAudioDetectiveAllReduceMaxFn inAllReduce, void* inContext,
+                                                     void* inStream, SInt64* outIndices, Float32* outScores);
+void LBAudioDetectiveSetExchangeTimeout(UInt32 inMilliseconds);
+/* the corpus' own key block of a sharded query (LBAD_SHARD_KEYS words on the device, and its pinned host twin) */
+unsigned long long* LBAudioDetectiveCorpusShardKeysDevice(LBAudioDetectiveCorpusRef inCorpus);
+unsigned long long* LBAudioDetectiveCorpusShardKeysHost(LBAudioDetectiveCorpusRef inCorpus);
 /* Communicator helpers for hosts without an RCCL binding of their own: rank 0 obtains a 128-byte id
  * (LBAD_COMM_UNIQUE_ID_BYTES) and hands it to the other ranks by whatever means the host has (a file, a socket,
  * MPI, torch.distributed ...); then every rank calls InitRank with the current HIP device set.  Thin wrappers

@@ -3,7 +3,7 @@
 `lbaudiodetective_amd._native.lib()` loads lib/liblbaudiodetective.so (built by
 `_native.build()` / `__graft_entry__.build()`); there is no CPU or PyTorch fallback.
 """
-from ._native import build, lib, constant, LIB_PATH, PACKED_BYTES, PACKED_WORDS, ROWS_PER_FRAME  # noqa: F401
+from ._native import build, lib, constant, LIB_PATH, PACKED_BYTES, PACKED_WORDS, ROWS_PER_FRAME, SHARD_KEYS  # noqa: F401
 from .api import (  # noqa: F401
     Comm, Corpus, Detective, Fingerprint, Frame, Stream, LBAudioDetectiveError, noErr, pack_subfingerprint,
     frames_to_subfingerprints_device, probe_shader_clock, read_audio_url, synth_clips_device, synth_corpus_device, synth_ragged_corpus_device, unpack_packed, unpack_subfingerprint,

@@ -22,6 +22,7 @@ Ref = C.c_void_p
 
 PACKED_WORDS = 8
 PACKED_BYTES = 32
+SHARD_KEYS = 4096          # LBAD_SHARD_KEYS: queries per exchange of a sharded query
 ROWS_PER_FRAME = 128
 
 
@@ -45,6 +46,9 @@ def build(force: bool = False, jobs: int = 8) -> str:
 
 
 _P = C.POINTER
+# LBAudioDetectiveAllReduceMaxFn: OSStatus (*)(void* context, UInt64* deviceKeys, UInt32 count, void* stream)
+AllReduceMaxFn = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p)
+
 _SIGNATURES = {
     # ---- detective (D.h) ----
     "LBAudioDetectiveNew": (Ref, []),
@@ -134,6 +138,11 @@ _SIGNATURES = {
     "LBAudioDetectiveCorpusQuerySharded": (OSStatus, [Ref, Ref, UInt32, UInt64, C.c_void_p, C.c_void_p, _P(SInt64), _P(Float32)]),
     "LBAudioDetectiveCorpusQueryBatchSharded": (OSStatus, [Ref, _P(Ref), UInt32, UInt32, UInt64, C.c_void_p, C.c_void_p,
                                                            _P(SInt64), _P(Float32)]),
+    "LBAudioDetectiveCorpusQueryBatchShardedWith": (OSStatus, [Ref, _P(Ref), UInt32, UInt32, UInt64, C.c_void_p, C.c_void_p,
+                                                               C.c_void_p, _P(SInt64), _P(Float32)]),
+    "LBAudioDetectiveSetExchangeTimeout": (None, [UInt32]),
+    "LBAudioDetectiveCorpusShardKeysDevice": (C.c_void_p, [Ref]),
+    "LBAudioDetectiveCorpusShardKeysHost": (C.c_void_p, [Ref]),
     "LBAudioDetectiveCommGetUniqueId": (OSStatus, [C.c_void_p]),
     "LBAudioDetectiveCommInitRank": (OSStatus, [_P(C.c_void_p), SInt32, C.c_void_p, SInt32]),
     "LBAudioDetectiveCommDestroy": (OSStatus, [C.c_void_p]),

@@ -570,6 +570,20 @@ class Corpus:
                                                               _stream_ptr(stream), idx, sc), "CorpusQueryBatchSharded")
         return [(int(idx[i]), float(sc[i])) for i in range(n)]
 
+    def query_batch_sharded_with(self, fps, all_reduce, index_base: int = 0, range_: int = 0, stream=None, context=None):
+        """LBAudioDetectiveCorpusQueryBatchShardedWith: the sharded query with the caller's exchange step --
+        all_reduce(context, device_keys_ptr, count, stream_ptr) -> status must leave the element-wise MAX over all
+        ranks in the `count` unsigned 64-bit keys at device_keys_ptr.  `self` may be None-like (pass corpus=None through
+        sharded_query_without_corpus) only from tests of the failing-rank path."""
+        n = len(fps)
+        refs = (N.Ref * n)(*[f._ref for f in fps])
+        idx, sc = (N.SInt64 * n)(), (N.Float32 * n)()
+        cb = all_reduce if isinstance(all_reduce, N.AllReduceMaxFn) else N.AllReduceMaxFn(all_reduce)
+        st = self._L.LBAudioDetectiveCorpusQueryBatchShardedWith(self._ref, refs, n, range_, index_base, cb, context,
+                                                                _stream_ptr(stream), idx, sc)
+        _check(st, "CorpusQueryBatchShardedWith")
+        return [(int(idx[i]), float(sc[i])) for i in range(n)]
+
     def scores_device(self, fp: Fingerprint, range_: int = 0, stream=None):
         import torch
         out = torch.empty(len(self), dtype=torch.float32, device="cuda")

@@ -220,7 +220,9 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLengt
     // the polled query's own stream exists from the start, so that every append can order it behind itself
     if (lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_planes), bytes), "hipMalloc corpus", __LINE__) != noErr ||
         lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr ||
-        lbad::hip_status(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "stream", __LINE__) != noErr) {
+        lbad::hip_status(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "stream", __LINE__) != noErr ||
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_shard_keys), (size_t)LBAD_SHARD_KEYS * 8), "hipMalloc keys", __LINE__) != noErr ||
+        lbad::hip_status(hipHostMalloc(reinterpret_cast<void**>(&c->h_shard_keys), (size_t)LBAD_SHARD_KEYS * 8, hipHostMallocDefault), "keys", __LINE__) != noErr) {
         LBAudioDetectiveCorpusDispose(c);
         return NULL;
     }
@@ -255,7 +257,9 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprin
         lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_off), (size_t)(inEntryCapacity + 1) * 4), "hipMalloc offsets", __LINE__) != noErr ||
         lbad::hip_status(hipMemset(c->d_off, 0, 4), "offsets", __LINE__) != noErr ||
         lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_key), 16), "hipMalloc key", __LINE__) != noErr ||
-        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_plan), lbad::sliding_plan_words(inEntryCapacity) * 4), "hipMalloc plan", __LINE__) != noErr) {
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_plan), lbad::sliding_plan_words(inEntryCapacity) * 4), "hipMalloc plan", __LINE__) != noErr ||
+        lbad::hip_status(hipMalloc(reinterpret_cast<void**>(&c->d_shard_keys), (size_t)LBAD_SHARD_KEYS * 8), "hipMalloc keys", __LINE__) != noErr ||
+        lbad::hip_status(hipHostMalloc(reinterpret_cast<void**>(&c->h_shard_keys), (size_t)LBAD_SHARD_KEYS * 8, hipHostMallocDefault), "keys", __LINE__) != noErr) {
         LBAudioDetectiveCorpusDispose(c);
         return NULL;
     }
@@ -318,6 +322,8 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (c->plan_used) { (void)hipEventSynchronize(c->plan_used); (void)hipEventDestroy(c->plan_used); }
     if (c->plan_built) { (void)hipEventSynchronize(c->plan_built); (void)hipEventDestroy(c->plan_built); }
     if (c->d_plan) (void)hipFree(c->d_plan);
+    if (c->d_shard_keys) (void)hipFree(c->d_shard_keys);
+    if (c->h_shard_keys) (void)hipHostFree(c->h_shard_keys);
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_off) (void)hipFree(c->d_off);
     if (c->d_planes) (void)hipFree(c->d_planes);
@@ -335,6 +341,8 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
 }
 
 UInt64 LBAudioDetectiveCorpusGetCount(LBAudioDetectiveCorpusRef c) { return c ? c->count : 0; }
+unsigned long long* LBAudioDetectiveCorpusShardKeysDevice(LBAudioDetectiveCorpusRef c) { return c ? c->d_shard_keys : NULL; }
+unsigned long long* LBAudioDetectiveCorpusShardKeysHost(LBAudioDetectiveCorpusRef c) { return c ? c->h_shard_keys : NULL; }
 
 UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef c) {
     if (!c) return 0;

@@ -11,8 +11,11 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <thread>
 
 const OSStatus kLBAudioDetectiveCollectiveError = 0x7263636C;   // 'rccl'
 
@@ -64,14 +67,38 @@ OSStatus nccl_status(ncclResult_t e, const char* what) {
     return kLBAudioDetectiveCollectiveError;
 }
 
-// pinned landing area of the reduced keys, one per device, only growing
-struct KeyOut {
-    std::mutex lock;
-    unsigned long long* h = nullptr;
-    unsigned long long* d = nullptr;
-    size_t cap = 0;
-};
-KeyOut g_keys[kMaxDevices];
+// The keys of one exchange: at most kKeysPerExchange queries are reduced at a time (larger batches run as several
+// exchanges, cut the same way on every rank).  The buffer of a call lives in the CORPUS (api_corpus.cpp allocates it
+// with the corpus, so a sharded query never allocates); a rank that has no corpus to offer takes part with this
+// module-level block of zero keys -- "nothing found here" -- whose contents nobody reads afterwards.
+constexpr uint32_t kKeysPerExchange = LBAD_SHARD_KEYS;
+__device__ unsigned long long g_no_keys[kKeysPerExchange];
+
+std::atomic<uint32_t> g_exchange_timeout_ms{60000};
+
+OSStatus rccl_all_reduce_max(void* context, UInt64* keys, UInt32 count, void* stream) {
+    Rccl& r = rccl();
+    if (!r.ok || !context) return kLBAudioDetectiveCollectiveError;
+    return nccl_status(r.AllReduce(keys, keys, count, ncclUint64, ncclMax, static_cast<ncclComm_t>(context),
+                                   static_cast<hipStream_t>(stream)), "ncclAllReduce");
+}
+
+// wait for `stream` without hanging for ever on a peer that never joined the exchange
+OSStatus wait_with_deadline(hipStream_t stream) {
+    const uint32_t limit = g_exchange_timeout_ms.load();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return noErr;
+        if (e != hipErrorNotReady) return hip_status(e, "sharded query", __LINE__);
+        if (limit && (spins & 0x3FF) == 0 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit)) {
+            fprintf(stderr, "lbaudiodetective: the exchange of a sharded query did not finish within %u ms (a rank missing?)\n", limit);
+            return kLBAudioDetectiveCollectiveError;
+        }
+        if (spins > 2000) std::this_thread::yield();
+    }
+}
 
 }  // namespace
 }  // namespace lbad
@@ -109,53 +136,57 @@ OSStatus LBAudioDetectiveCommDestroy(void* inComm) {
     return lbad::nccl_status(r.CommDestroy(static_cast<ncclComm_t>(inComm)), "ncclCommDestroy");
 }
 
+void LBAudioDetectiveSetExchangeTimeout(UInt32 inMilliseconds) { lbad::g_exchange_timeout_ms.store(inMilliseconds); }
+
+// The sharded query, exchange step as a parameter.  Nothing between "the other ranks may already be waiting" and the
+// exchange can return: the key buffer exists since the corpus was made, every local failure -- bad arguments, a shard
+// whose indices do not fit the key's 32 bits, a failed launch, even a failed memset -- turns this rank's keys into zeros
+// ("nothing found here") or leaves them as they are, the exchange runs, and the status comes back afterwards.
+OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef inCorpus,
+                                                     const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
+                                                     UInt32 inRange, UInt64 inIndexBase,
+                                                     LBAudioDetectiveAllReduceMaxFn inAllReduce, void* inContext,
+                                                     void* inStream, SInt64* outIndices, Float32* outScores) {
+    if (inCount == 0 || !inAllReduce) return kLBAudioDetectiveArgumentInvalid;      // (the same on every rank, or a caller's bug)
+    hipStream_t stream = static_cast<hipStream_t>(inStream);
+    OSStatus first_error = noErr;
+    for (UInt32 done = 0; done < inCount; done += lbad::kKeysPerExchange) {
+        const UInt32 n = inCount - done < lbad::kKeysPerExchange ? inCount - done : lbad::kKeysPerExchange;
+        unsigned long long* keys = inCorpus ? LBAudioDetectiveCorpusShardKeysDevice(inCorpus) : nullptr;
+        unsigned long long* host = inCorpus ? LBAudioDetectiveCorpusShardKeysHost(inCorpus) : nullptr;
+        OSStatus local = noErr;
+        if (!inCorpus || !inQueries || !keys || !host) local = kLBAudioDetectiveArgumentInvalid;
+        else if (inIndexBase + LBAudioDetectiveCorpusGetCount(inCorpus) > 0x100000000ull) local = kLBAudioDetectiveArgumentInvalid;
+        else
+            local = n == 1 ? LBAudioDetectiveCorpusQueryKeyDevice(inCorpus, inQueries[done], inRange, inIndexBase, keys, stream)
+                           : LBAudioDetectiveCorpusQueryBatchKeysDevice(inCorpus, inQueries + done, n, inRange, inIndexBase, keys, stream);
+        if (!keys) {
+            void* p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(lbad::g_no_keys)) == hipSuccess) keys = static_cast<unsigned long long*>(p);
+        }
+        if (local != noErr && keys) (void)hipMemsetAsync(keys, 0, (size_t)n * 8, stream);      // best effort: the exchange runs either way
+        // the one exchange step: MAX over ranks of the unsigned 64-bit keys, in place, on the caller's stream
+        OSStatus st = keys ? inAllReduce(inContext, reinterpret_cast<UInt64*>(keys), n, stream) : kLBAudioDetectiveDeviceError;
+        if (st == noErr && local == noErr)
+            st = lbad::hip_status(hipMemcpyAsync(host, keys, (size_t)n * 8, hipMemcpyDeviceToHost, stream), "keys D2H", __LINE__);
+        if (st == noErr) st = lbad::wait_with_deadline(stream);
+        if (st == noErr && local == noErr)
+            for (UInt32 i = 0; i < n; ++i)
+                LBAudioDetectiveCorpusDecodeKey(host[i], outIndices ? outIndices + done + i : NULL, outScores ? outScores + done + i : NULL);
+        if (first_error == noErr) first_error = local != noErr ? local : st;
+        if (st != noErr) break;            // the exchange itself failed: the communicator is not usable any more
+    }
+    return first_error;
+}
+
 OSStatus LBAudioDetectiveCorpusQueryBatchSharded(LBAudioDetectiveCorpusRef inCorpus,
                                                  const LBAudioDetectiveFingerprintRef* inQueries, UInt32 inCount,
                                                  UInt32 inRange, UInt64 inIndexBase, void* inComm, void* inStream,
                                                  SInt64* outIndices, Float32* outScores) {
     if (inCount == 0 || !inComm) return kLBAudioDetectiveArgumentInvalid;
-    lbad::Rccl& r = lbad::rccl();
-    if (!r.ok) return kLBAudioDetectiveCollectiveError;
-    const int dev = lbad::current_device();
-    if (dev < 0 || dev >= lbad::kMaxDevices) return kLBAudioDetectiveDeviceUnavailable;
-    lbad::KeyOut& k = lbad::g_keys[dev];
-    std::lock_guard<std::mutex> guard(k.lock);
-    if (k.cap < inCount) {
-        unsigned long long *nd = nullptr, *nh = nullptr;
-        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&nd), (size_t)inCount * 8));
-        if (hipHostMalloc(reinterpret_cast<void**>(&nh), (size_t)inCount * 8, hipHostMallocDefault) != hipSuccess) {
-            (void)hipFree(nd);
-            return kLBAudioDetectiveDeviceError;
-        }
-        if (k.d) (void)hipFree(k.d);
-        if (k.h) (void)hipHostFree(k.h);
-        k.d = nd; k.h = nh; k.cap = inCount;
-    }
-    hipStream_t stream = static_cast<hipStream_t>(inStream);
-    // From here on the other ranks are (or will be) waiting in the exchange: a rank whose OWN scan cannot run -- bad
-    // arguments, a shard whose indices do not fit the key's 32 bits, a failed launch -- still takes part, with keys of
-    // zero ("nothing found here"), and reports its error afterwards.  Returning early would hang the other ranks.
-    OSStatus local = noErr;
-    if (!inCorpus || !inQueries) local = kLBAudioDetectiveArgumentInvalid;
-    else if (inIndexBase + LBAudioDetectiveCorpusGetCount(inCorpus) > 0x100000000ull) local = kLBAudioDetectiveArgumentInvalid;
-    else
-        local = inCount == 1
-            ? LBAudioDetectiveCorpusQueryKeyDevice(inCorpus, inQueries[0], inRange, inIndexBase, k.d, stream)
-            : LBAudioDetectiveCorpusQueryBatchKeysDevice(inCorpus, inQueries, inCount, inRange, inIndexBase, k.d, stream);
-    if (local != noErr) LBAD_HIP(hipMemsetAsync(k.d, 0, (size_t)inCount * 8, stream));
-    // the one exchange step: MAX over ranks of the unsigned 64-bit keys, in place, on the caller's stream
-    OSStatus st = lbad::nccl_status(r.AllReduce(k.d, k.d, inCount, ncclUint64, ncclMax, static_cast<ncclComm_t>(inComm), stream),
-                                    "ncclAllReduce");
-    if (st != noErr) return st;
-    if (local != noErr) {
-        (void)hipStreamSynchronize(stream);
-        return local;
-    }
-    LBAD_HIP(hipMemcpyAsync(k.h, k.d, (size_t)inCount * 8, hipMemcpyDeviceToHost, stream));
-    LBAD_HIP(hipStreamSynchronize(stream));
-    for (UInt32 i = 0; i < inCount; ++i)
-        LBAudioDetectiveCorpusDecodeKey(k.h[i], outIndices ? outIndices + i : NULL, outScores ? outScores + i : NULL);
-    return noErr;
+    if (!lbad::rccl().ok) return kLBAudioDetectiveCollectiveError;
+    return LBAudioDetectiveCorpusQueryBatchShardedWith(inCorpus, inQueries, inCount, inRange, inIndexBase, lbad::rccl_all_reduce_max,
+                                                       inComm, inStream, outIndices, outScores);
 }
 
 OSStatus LBAudioDetectiveCorpusQuerySharded(LBAudioDetectiveCorpusRef inCorpus, LBAudioDetectiveFingerprintRef inQuery,

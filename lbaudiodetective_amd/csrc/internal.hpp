@@ -381,6 +381,9 @@ struct LBAudioDetectiveCorpus {
     hipEvent_t plan_built = nullptr;             // behind the plan's kernels, on plan_stream
     hipEvent_t plan_used = nullptr;              // behind the latest scan that read the plan
     hipStream_t plan_stream = nullptr;
+    // key block of the sharded query (api_rccl.cpp), made with the corpus so that the collective call never allocates
+    unsigned long long* d_shard_keys = nullptr;
+    unsigned long long* h_shard_keys = nullptr;
     // ring of query slots in h_query / d_query (ragged scan): slot size in words, one event per slot, queries so far
     size_t query_slot_words = 0;
     hipEvent_t query_ev[8] = {};

@@ -316,3 +316,90 @@ def test_sharded_c_host_one_rank(lb, gpu, tmp_path):
     out = subprocess.run([exe, "0", "1", str(tmp_path / "rccl.id"), "3000000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "best match index 1777777 " in out.stdout and "score 0.919" in out.stdout, out.stdout
+
+
+def test_sharded_entry_point_with_two_ranks_in_one_process(lb, gpu, oracle):
+    """LBAudioDetectiveCorpusQueryBatchShardedWith -- the C entry point of the sharded query with the exchange step
+    handed in -- driven by TWO "ranks" inside this process: two threads, each with its own shard of the corpus on the
+    one GPU and its own stream, and a collective written here (copy the keys to the host, meet at a barrier, MAX, copy
+    back) where a multi-GPU run has ncclAllReduce(ncclUint64, ncclMax).  RCCL refuses two ranks on one device, the
+    reduction rule does not care where the ranks live.  Asserted: every rank receives the global best match; an entry
+    present in BOTH shards resolves to the LOWER global index (LBAudioDetectiveTests.m:80-83 across ranks); a rank
+    whose own scan cannot run (no corpus; indices beyond 2^32) still joins the exchange, the other rank gets its own
+    result and does not hang; a batch larger than one exchange's key block is cut the same way on both ranks."""
+    import ctypes as C
+    import threading
+    from lbaudiodetective_amd import _native as N
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(41)
+    n0, n1 = 300, 260
+    ent = [_rand_fp(rng, int(n), 200) for n in rng.integers(3, 40, n0 + n1)]
+    twin = _rand_fp(rng, 25, 200)
+    ent[123] = twin.copy()                       # global index 123 (rank 0)
+    ent[n0 + 17] = twin.copy()                   # global index 317 (rank 1): same score, must lose the tie
+    shards = [_ragged_corpus(lb, gpu, ent[:n0], 200)[0], _ragged_corpus(lb, gpu, ent[n0:], 200)[0]]
+    bases = [0, n0]
+    queries = [twin[2:23], ent[n0 + 100][:3] if ent[n0 + 100].shape[0] >= 3 else ent[n0 + 100], _rand_fp(rng, 9, 200), ent[5][:1]]
+    want = [oracle.corpus_best_ragged(q, ent, 200) for q in queries]
+    assert want[0] == (123, 1.0) and want[1][0] >= n0
+
+    barrier = threading.Barrier(2)
+    slots = [None, None]
+    calls = [0, 0]
+
+    def make_collective(rank):
+        def all_reduce(context, keys, count, stream):
+            hip.hipStreamSynchronize(stream)
+            host = (C.c_uint64 * count)()
+            hip.hipMemcpy(host, keys, 8 * count, 2)                      # device to host
+            slots[rank] = list(host)
+            barrier.wait(timeout=60)
+            best = [max(a, b) for a, b in zip(slots[0], slots[1])]
+            barrier.wait(timeout=60)
+            out = (C.c_uint64 * count)(*best)
+            hip.hipMemcpy(keys, out, 8 * count, 1)                      # host to device
+            calls[rank] += 1
+            return 0
+        return N.AllReduceMaxFn(all_reduce)
+
+    def run(rank, corpus_of_rank, base_of_rank, fps, out):
+        gpu.cuda.set_device(0)
+        stream = gpu.cuda.Stream()
+        try:
+            out[rank] = ("ok", corpus_of_rank.query_batch_sharded_with(fps, make_collective(rank), index_base=base_of_rank, stream=stream))
+        except lb.LBAudioDetectiveError as e:
+            out[rank] = ("error", e.status)
+
+    def both(corpora, base_list, fps):
+        out = [None, None]
+        th = [threading.Thread(target=run, args=(r, corpora[r], base_list[r], fps, out)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not any(t.is_alive() for t in th), "a rank hangs in the exchange"
+        return out
+
+    fps = [lb.Fingerprint.from_bools(q) for q in queries]
+    out = both(shards, bases, fps)
+    assert out[0] == out[1] == ("ok", want), (out, want)
+    # a rank whose indices do not fit the key (index base + count > 2^32) joins with empty keys and reports its error;
+    # the other rank's result is the best match of ITS shard alone
+    out = both(shards, [2**32 - 10, n0], fps[:2])
+    alone = [oracle.corpus_best_ragged(q, ent[n0:], 200) for q in queries[:2]]
+    assert out[0] == ("error", 1) and out[1] == ("ok", [(i + n0 if i >= 0 else -1, s) for i, s in alone]), out
+    # a rank without a corpus at all (the C entry point takes NULL): same thing
+    class NoCorpus:
+        _L = shards[0]._L
+        _ref = None
+        query_batch_sharded_with = lb.Corpus.query_batch_sharded_with
+    out = both([shards[0], NoCorpus()], bases, fps[:1])
+    assert out[1] == ("error", 1) and out[0] == ("ok", [oracle.corpus_best_ragged(queries[0], ent[:n0], 200)]), out
+    # more queries than one exchange carries: two exchanges on both ranks, the same results
+    before = list(calls)
+    many = [fps[i % len(fps)] for i in range(lb.SHARD_KEYS + 5)]
+    out = both(shards, bases, many)
+    assert out[0] == out[1] and out[0][0] == "ok" and out[0][1] == [want[i % len(fps)] for i in range(len(many))]
+    assert [c - b for c, b in zip(calls, before)] == [2, 2]
