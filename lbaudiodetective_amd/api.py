@@ -407,13 +407,33 @@ class Detective:
         return out, raw, haar
 
 
-def frames_to_subfingerprints_device(det: "Detective", frames, want_haar: bool = False, stream=None):
-    """Stage 2 alone on torch frames [n, 128, bands] float32 (cuda) -> packed uint8 [n, 32] (and the Haar frames)."""
+def compact_layout(det: "Detective"):
+    """(live band among bands 0..15 or 32, columns of the row transform that can be non-zero) of the configuration's compact
+    inter-stage frames, or None when it has none (LBAudioDetectiveGetCompactLayout)."""
+    left, cols = N.UInt32(0), N.UInt32(0)
+    st = N.lib().LBAudioDetectiveGetCompactLayout(det._ref, C.byref(left), C.byref(cols))
+    return (int(left.value), int(cols.value)) if st == 0 else None
+
+
+def frames_to_subfingerprints_device(det: "Detective", frames, want_haar: bool = False, stream=None, compact: bool = False):
+    """Stage 2 alone on torch frames [n, 128, bands] float32 (cuda) -> packed uint8 [n, 32] (and the Haar frames).
+    compact: through the SPARSE form -- the frames (whose structurally empty bands must be zero) are packed into the
+    compact layout first (128 rows of bands 16..31, then the live left band's 128 means)."""
     import torch
     assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous()
     n = frames.shape[0]
     out = torch.empty((n, N.PACKED_BYTES), dtype=torch.uint8, device=frames.device)
     haar = torch.empty_like(frames) if want_haar else None
+    if compact:
+        lay = compact_layout(det)
+        if lay is None:
+            raise LBAudioDetectiveError(1, "this configuration has no compact frame layout")
+        left = frames[:, :, lay[0]] if lay[0] < 32 else torch.zeros((n, 128), dtype=torch.float32, device=frames.device)
+        cf = torch.cat([frames[:, :, 16:32].reshape(n, 128 * 16), left.reshape(n, 128)], dim=1).contiguous()
+        _check(N.lib().LBAudioDetectiveCompactFramesToSubfingerprintsDevice(det._ref, cf.data_ptr(), n, out.data_ptr(),
+                                                                            haar.data_ptr() if want_haar else None, _stream_ptr(stream)),
+               "CompactFramesToSubfingerprintsDevice")
+        return (out, haar) if want_haar else out
     _check(N.lib().LBAudioDetectiveFramesToSubfingerprintsDevice(det._ref, frames.data_ptr(), n, out.data_ptr(),
                                                                  haar.data_ptr() if want_haar else None, _stream_ptr(stream)),
            "FramesToSubfingerprintsDevice")

@@ -81,12 +81,25 @@ OSStatus ensure_plan(LBAudioDetective* d) {
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_tw), 2 * half * sizeof(float)));
     LBAD_HIP(hipMemcpy(p.d_tw, re.data(), half * sizeof(float), hipMemcpyHostToDevice));
     LBAD_HIP(hipMemcpy(p.d_tw + half, im.data(), half * sizeof(float), hipMemcpyHostToDevice));
-    std::vector<uint32_t> tbl(3 * (size_t)p.bands);
+    plan_sparse(p);
+    // [bands] lo, [bands] hi, [bands] divisor as float bits; then where the band's mean of row w goes inside a frame, as
+    // multiplier and offset (w * mult + off): for rows of `bands` floats, and for the compact frame of plan.sparse
+    // (off 0xFFFFFFFF: not stored)
+    std::vector<uint32_t> tbl(7 * (size_t)p.bands);
     for (uint32_t b = 0; b < p.bands; ++b) {
         tbl[b] = p.table.lo[b];
         tbl[p.bands + b] = p.table.hi[b];
         const float div = (float)(p.table.indices[b + 1] - p.table.indices[b]);  // :404
         std::memcpy(&tbl[2 * p.bands + b], &div, 4);
+        tbl[3 * p.bands + b] = p.bands;
+        tbl[4 * p.bands + b] = b;
+        uint32_t mult = 0, off = 0xFFFFFFFFu;
+        if (p.sparse.ok) {
+            if (b >= 16) { mult = 16; off = b - 16; }
+            else if (b == p.sparse.left) { mult = 1; off = 128 * 16; }
+        }
+        tbl[5 * p.bands + b] = mult;
+        tbl[6 * p.bands + b] = off;
     }
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bands), tbl.size() * sizeof(uint32_t)));
     LBAD_HIP(hipMemcpy(p.d_bands, tbl.data(), tbl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -173,17 +186,25 @@ OSStatus fingerprint_clips_device(LBAudioDetective* d, const void* d_pcm_raw, ui
     if (d->variant >= 2 && !special) return kLBAudioDetectiveArgumentInvalid;
     StreamOrder order{d, stream};
     LBAD_HIP(order.begin());
+    const bool special2 = d->variant != 1 && haar_select32_supported(p);   // (variants 2 and 3 use it as well)
+    // rows of 16 floats between the stages where more than half of the bands are structurally empty (plan.sparse): the
+    // pruned stage 1 with the sparse stage 2, no file tails (they rewrite whole rows), no tap of the raw frames; variant 4
+    // keeps full rows (measurement)
+    const bool compact = special && p.pruned_ok && special2 && p.sparse.ok && !tail && !d_raw && d->variant != 4;
     auto stage1 = [&](const void* pcm_in, uint64_t nc, float* frames_out) -> hipError_t {
         if (special && p.pruned_ok)
-            return launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
+            return launch_rows_pruned(p, p.d_bin_const, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream, compact);
         if (special && stream2_ok) return launch_rows_stream2(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         if (special && full_ok) return launch_rows_full(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         if (special) return launch_rows_stream(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
         return launch_fft_bands(p, pcm_in, fmt, nc, spc, (uint32_t)per, frames_out, stream);
     };
-    const bool special2 = d->variant != 1 && haar_select32_supported(p);   // (variants 2 and 3 use it as well)
     auto stage2 = [&](float* frames_in, uint64_t nf, uint32_t* packed_out, float* haar_out) -> hipError_t {
-        return special2 ? launch_haar_select32(p, frames_in, nf, packed_out, haar_out, stream)
+        if (compact && haar_out) {      // the sparse form writes the columns that can be non-zero; the others are +0.0
+            hipError_t e = hipMemsetAsync(haar_out, 0, nf * kRowsPerFrame * p.bands * sizeof(float), stream);
+            if (e != hipSuccess) return e;
+        }
+        return special2 ? launch_haar_select32(p, frames_in, nf, packed_out, haar_out, stream, compact)
                         : launch_haar_select(p, frames_in, nf, packed_out, haar_out, stream);
     };
     const uint64_t frame_floats = (uint64_t)kRowsPerFrame * p.bands;
@@ -453,7 +474,7 @@ OSStatus LBAudioDetectiveSetAnalysisStride(LBAudioDetectiveRef d, UInt32 inAnaly
 
 OSStatus LBAudioDetectiveSetKernelVariant(LBAudioDetectiveRef d, UInt32 inVariant) {
     LBAD_LOCK(d);
-    if (inVariant > 3) return kLBAudioDetectiveArgumentInvalid;
+    if (inVariant > 4) return kLBAudioDetectiveArgumentInvalid;   // 4: variant 2 with full rows between the stages (measurement)
     d->variant = inVariant;
     return noErr;
 }
@@ -528,6 +549,35 @@ OSStatus LBAudioDetectiveFramesToSubfingerprintsDevice(LBAudioDetectiveRef d, co
         if (d->variant == 2) return kLBAudioDetectiveArgumentInvalid;
         LBAD_HIP(lbad::launch_haar_select(p, frames, inNumberOfFrames, static_cast<uint32_t*>(outPacked), outFramesHaar, stream));
     }
+    return noErr;
+}
+
+// The sparse form of stage 2 alone, on compact frames (what the pruned stage 1 writes when more than half of the bands are
+// structurally empty): LBAD_COMPACT_FRAME_FLOATS floats per frame -- 128 rows of bands 16..31, then the 128 means of the one
+// live band among bands 0..15 (*outLeftBand of LBAudioDetectiveGetCompactLayout; 32: none).  ArgumentInvalid when the
+// configuration has no such layout.  For tests and fuzzers: the batch entry points choose the layout themselves.
+OSStatus LBAudioDetectiveGetCompactLayout(LBAudioDetectiveRef d, UInt32* outLeftBand, UInt32* outLiveColumns) {
+    LBAD_LOCK(d);
+    if (!d) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    if (!d->plan.sparse.ok || !lbad::haar_select32_supported(d->plan)) return kLBAudioDetectiveArgumentInvalid;
+    if (outLeftBand) *outLeftBand = d->plan.sparse.left;
+    if (outLiveColumns) *outLiveColumns = d->plan.sparse.n_cols;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveCompactFramesToSubfingerprintsDevice(LBAudioDetectiveRef d, const Float32* inFrames, UInt64 inNumberOfFrames,
+                                                              void* outPacked, Float32* outFramesHaar, void* inStream) {
+    LBAD_LOCK(d);
+    if (!d || (!inFrames && inNumberOfFrames) || (!outPacked && inNumberOfFrames)) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    const lbad::Plan& p = d->plan;
+    if (!p.sparse.ok || !lbad::haar_select32_supported(p)) return kLBAudioDetectiveArgumentInvalid;
+    hipStream_t stream = static_cast<hipStream_t>(inStream);
+    if (outFramesHaar) LBAD_HIP(hipMemsetAsync(outFramesHaar, 0, inNumberOfFrames * lbad::kRowsPerFrame * p.bands * sizeof(float), stream));
+    LBAD_HIP(lbad::launch_haar_select32(p, inFrames, inNumberOfFrames, static_cast<uint32_t*>(outPacked), outFramesHaar, stream, true));
     return noErr;
 }
 

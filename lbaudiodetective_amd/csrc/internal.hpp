@@ -18,6 +18,7 @@ namespace lbad {
 constexpr uint32_t kRowsPerFrame = 128;  // LBAudioDetective.m:25
 constexpr uint32_t kPackedWords = LBAD_PACKED_WORDS;
 constexpr uint32_t kMaxBands = 64;
+constexpr uint32_t kSparseFrameDw = 128 * 16 + 128;   // a compact frame (Plan::Sparse): 128 rows of 16 floats, then 128 floats
 constexpr uint32_t kMinWindow = 16;
 constexpr uint32_t kMaxWindow = 8192;
 
@@ -85,6 +86,17 @@ struct Plan {
     bool stream_ok = false;       // k_rows_stream.hip applies (also uses d_claim)
     bool stream2_ok = false;      // k_rows_stream2.hip applies (preferred over k_rows_full.hip when the clip length is even)
     uint32_t* d_claim = nullptr;  // its per-XCD claim counters (8 words)
+    // Structurally empty bands (round 4): a band whose bin range is empty is +0.0 in every window (17 of the 32
+    // bands at 44.1 kHz / 1024).  `sparse.ok`: 32 bands and at most ONE live band among the left sixteen -- stage 1 then
+    // writes compact frames (kSparseFrameDw floats: 128 rows of the right sixteen bands, then the left band's 128 means)
+    // and stage 2 runs its sparse form (k_haar_select32.hip): one thread per row, and only the columns of the row
+    // transform that can be non-zero go through the column transform and the select.
+    struct Sparse {
+        bool ok = false;
+        uint32_t left = 32;            // the live band of the left half (32: none)
+        uint32_t n_cols = 0;           // columns of the row transform's output that can be non-zero ...
+        uint8_t cols[32] = {};         // ... in ascending ordered position
+    } sparse;
     // measurement knobs of the generic stage-1 kernel (LBAudioDetectiveSetKernelTuning): waves per workgroup
     // (0 = automatic) and whether the per-lane twiddle cache is used
     uint32_t tune_waves = 0;
@@ -121,9 +133,10 @@ hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_fram
 // specialised stage 1 (k_rows_pruned.hip): 1024-sample windows whose bands read only bins 0..21
 bool rows_pruned_supported(const Plan& plan);
 void rows_pruned_constants(std::vector<float>& out);
+// compact: rows of 16 floats (plan.sparse), else rows of 32
 hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint32_t fmt,
                               uint64_t n_clips, uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
-                              hipStream_t stream);
+                              hipStream_t stream, bool compact = false);
 
 // specialised stage 1 without pruning (k_rows_full.hip): 1024- and 2048-sample windows, any band table
 bool rows_full_supported(const Plan& plan);
@@ -144,8 +157,10 @@ hipError_t launch_rows_stream2(const Plan& plan, const void* d_pcm, uint32_t fmt
 
 // specialised stage 2 (k_haar_select32.hip): 128 x 32 frames, keep <= 128
 bool haar_select32_supported(const Plan& plan);
+// compact: d_frames holds plan.sparse's rows of 16 floats (the sparse form; d_haar_out must be zeroed by the caller)
 hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_t n_frames, uint32_t* d_packed,
-                                float* d_haar_out, hipStream_t stream);
+                                float* d_haar_out, hipStream_t stream, bool compact = false);
+void plan_sparse(Plan& plan);    // fills plan.sparse from plan.table
 
 // end-of-file chain of upstream's file loop, tail mode "stale" (k_file_tail.hip); d_tbl: per window
 // [n_read, lo[bands], hi[bands]]

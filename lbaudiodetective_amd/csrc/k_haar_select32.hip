@@ -18,6 +18,8 @@
 // butterflies, correctly rounded divisions.
 #include "internal.hpp"
 
+#include <type_traits>
+
 namespace lbad {
 namespace {
 
@@ -380,10 +382,29 @@ __device__ __forceinline__ float cross_levels(float cur, int h, float root2, boo
 
 // 32 columns: 72 VGPRs -> seven workgroups per CU, which is also what the 22 KB of LDS allow (90 VGPRs and five
 // workgroups without the bound: 4.33 -> 3.81 ms per 500 k frames; the second bound is waves per SIMD).
-template <int COLS>
+// The sparse form (SPARSE, 32 bands): bands whose bin range is empty are +0.0 in every window (LBAudioDetective.m:386-404
+// with an empty loop), and where only ONE of the left sixteen bands is live (44.1 kHz / 1024: band 13; bands 16, 18,
+// 20..31 on the right) most of the row transform is structure, not arithmetic:
+//   * row pass: ONE thread per row (two waves instead of four).  The right half is an ordinary 16-value line; the left
+//     half is the single value walking up the levels -- at each level the pair (a, 0) or (0, a) gives the sum a / sqrt 2 and
+//     the detail +-a / sqrt 2, every other detail of the half is (0 +- 0) / sqrt 2 = +0.0;
+//   * the columns of the row transform's output that can be non-zero (21 of 32 there; the plan lists them) are the only
+//     ones that go through the column transform, the search and the gather: the others' 128 coefficients are all +0.0,
+//     and a zero never sets a Boolean (its sign code is 0) nor changes the rank of a non-zero coefficient (every non-zero
+//     key is larger), whether it would have been selected or not -- frames with fewer than `keep` non-zero coefficients
+//     included (tests/test_gpu_parity.py::test_stage2_corner_frames runs them through both forms);
+//   * input: the compact frame stage 1 writes for such a plan (kSparseFrameDw floats), half of the bytes.
+// Every value that is computed is computed by the same operations on the same operands as in the general form.
+struct SparseArgs {
+    uint32_t left, n_cols;
+    uint32_t cols[8];              // 32 ordered positions, one byte each
+};
+
+template <int COLS, bool SPARSE>
 __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
                                                                           uint32_t subfp_len, uint32_t* __restrict__ packed,
-                                                                          float* __restrict__ haar_out) {
+                                                                          float* __restrict__ haar_out, const SparseArgs sp) {
+    static_assert(!SPARSE || COLS == 32, "the sparse form is for 32 bands");
     constexpr int kCols = COLS;
     constexpr int kThreads = COLS * 8;
     constexpr int kWavesPerWg = kThreads / 64;
@@ -422,6 +443,85 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     for (int i = t; i < 2 * (int)kCand; i += kThreads)
         reinterpret_cast<uint32_t*>(s_cand)[i] = 0;   // zero keys pad the list to a multiple of 8 for the ranking loop
 
+    // ---- row pass, sparse form: thread = row (waves 0 and 1) ----------------------------------------------------
+    if constexpr (SPARSE) {
+        if (t < (int)kRowsPerFrame) {
+            const int row = t;
+            const float* fr = frames + frame * kSparseFrameDw;
+            const float4* src = reinterpret_cast<const float4*>(fr + row * 16);
+            float d[15];
+            auto load = [&](float (&a)[16]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = src[q];
+                    a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+                }
+            };
+            const float root = __fsqrt_rn(32.0f);
+            bool fast;
+            const float s4r = haar16(load, d, root, root2, fast);               // bands 16..31: levels 1..4
+            // bands 0..15: the one live band's mean up the four levels.  At level k the pair is (a, 0) when bit k - 1 of
+            // the band's index is clear -- sum (a + 0) / sqrt 2, detail (a - 0) / sqrt 2: the same quotient -- and (0, a)
+            // when it is set: detail (0 - a) / sqrt 2.
+            const float xl = sp.left < 32u ? fr[kRowsPerFrame * 16 + row] : 0.0f;
+            float det[4], s4l = 0.0f;
+            auto chain = [&](auto fast_tag, DivGuard& g) {
+                constexpr bool F = decltype(fast_tag)::value;
+                const float r_root = F ? __fdiv_rn(1.0f, root) : 0.0f, r_root2 = F ? __fdiv_rn(1.0f, root2) : 0.0f;
+                if constexpr (F) { g.inputs(xl, xl); g.dividends(xl, xl); }
+                float a = div_c<F>(xl, root, r_root);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool odd = ((sp.left >> k) & 1u) != 0u;               // (uniform)
+                    const float sum_in = __fadd_rn(odd ? 0.0f : a, odd ? a : 0.0f);
+                    const float dif_in = __fsub_rn(odd ? 0.0f : a, odd ? a : 0.0f);
+                    if constexpr (F) g.dividends(sum_in, dif_in);
+                    const float sum = div_c<F>(sum_in, root2, r_root2);
+                    det[k] = div_c<F>(dif_in, root2, r_root2);
+                    a = sum;
+                }
+                s4l = a;
+            };
+            // level 5 pairs the halves: the left one keeps (l + r) / sqrt 2, the right one leaves with (l - r) / sqrt 2 =
+            // (l + (-r)) / sqrt 2 (cross_level_step's form)
+            float avg = 0.0f, det5 = 0.0f;
+            auto level5 = [&](auto fast_tag, DivGuard& g) {
+                constexpr bool F = decltype(fast_tag)::value;
+                const float r_root2 = F ? __fdiv_rn(1.0f, root2) : 0.0f;
+                const float sp5 = __fadd_rn(s4l, s4r), sm5 = __fadd_rn(s4l, -s4r);
+                if constexpr (F) g.dividends(sp5, sm5);
+                avg = div_c<F>(sp5, root2, r_root2);
+                det5 = div_c<F>(sm5, root2, r_root2);
+            };
+            {
+                DivGuard g;
+                chain(std::true_type{}, g);
+                if (fast) level5(std::true_type{}, g);
+                if (!fast || __any(g.bad())) {       // tiny / huge / NaN somewhere in the wave: true divisions
+                    chain(std::false_type{}, g);
+                    level5(std::false_type{}, g);
+                }
+            }
+            // transposed store: coefficient at ordered position p of this row -> s_t[p][row >> 4][row & 15]; positions
+            // that are structurally zero are neither written nor read
+            float* base = s_t + (row >> 4) * kChunkDw + (row & 15);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) base[(24 + i) * (8 * kChunkDw)] = d[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) base[(12 + i) * (8 * kChunkDw)] = d[8 + i];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) base[(6 + i) * (8 * kChunkDw)] = d[12 + i];
+            base[3 * (8 * kChunkDw)] = d[14];
+            if (sp.left < 32u) {
+                base[(16 + (sp.left >> 1)) * (8 * kChunkDw)] = det[0];
+                base[(8 + (sp.left >> 2)) * (8 * kChunkDw)] = det[1];
+                base[(4 + (sp.left >> 3)) * (8 * kChunkDw)] = det[2];
+                base[2 * (8 * kChunkDw)] = det[3];
+            }
+            base[0] = avg;
+            base[1 * (8 * kChunkDw)] = det5;
+        }
+    } else
     // ---- row pass: thread = (row, sixteenth h of the row) ------------------------------------------------
     {
         const int row = t / H, h = t % H;
@@ -456,9 +556,22 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     STAMP(1);
 
     // ---- column pass: thread = (column, chunk of 16 rows) -----------------------------------------
-    const int col = t >> 3, j = t & 7;
+    // sparse form: the n_cols columns that can be non-zero, packed into the first 8 n_cols threads; the threads behind them
+    // hold sixteen zeros (never selected: every threshold the search tries is > 0) and a wave without a column skips the
+    // arithmetic altogether
+    const bool live_thread = !SPARSE || (uint32_t)(t >> 3) < sp.n_cols;
+    const bool live_wave = !SPARSE || (uint32_t)((t & ~63) >> 3) < sp.n_cols;          // (wave-uniform)
+    int col = t >> 3;
+    if constexpr (SPARSE) {
+        const uint32_t c = live_thread ? (uint32_t)(t >> 3) : 0u;
+        col = (int)((sp.cols[c >> 2] >> (8u * (c & 3u))) & 0xFFu);
+    }
+    const int j = t & 7;
     float v[16];
-    {
+    if (!live_wave) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+    } else {
         float d[15];
         const float4* src = reinterpret_cast<const float4*>(s_t + (col * 8 + j) * kChunkDw);
         auto load = [&](float (&a)[16]) {
@@ -480,6 +593,12 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         v[13] = d[13];
         v[14] = d[14];
         v[15] = fin;
+        if constexpr (SPARSE) {
+            if (!live_thread) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = 0.0f;
+            }
+        }
     }
     // Ordered row position of the thread's i-th coefficient (levels 1..4 of its chunk, then the cross-lane value: chunk ->
     // 0,4,2,5,1,6,3,7).  Only the optional Haar tap and the plateau path need it; `jj` comes through an empty asm there so
@@ -493,7 +612,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         asm volatile("" : "+v"(jj));
         return jj;
     };
-    if (haar_out) {
+    if (haar_out && live_thread) {
         float* dst = haar_out + frame * (kRowsPerFrame * kCols);
         const uint32_t jj = opaque_j();
 #pragma unroll
@@ -517,8 +636,10 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         // one vector compare per key; the per-wave count is a scalar popcount of the lane mask, so the
         // adds and the cross-lane reduction run on the scalar unit instead of the VALU
         uint32_t c = 0;
+        if (live_wave) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) c += (uint32_t)__popcll(__ballot(key[i] >= (mid << 1)));   // mid < 2^31
+            for (int i = 0; i < 16; ++i) c += (uint32_t)__popcll(__ballot(key[i] >= (mid << 1)));   // mid < 2^31
+        }
         {
             uint32_t* slot = s_red + 8 * parity;
             if ((t & 63) == 0) slot[t >> 6] = c;
@@ -534,7 +655,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     // hoist sixteen of them in front of the rare paths that need them)
     const uint32_t lo2 = lo << 1;
     auto above = [&](uint32_t k) { return lo != 0x7FFFFFFFu && k >= lo2 + 2u; };
-    auto tied = [&](uint32_t k) { return k - lo2 < 2u; };
+    auto tied = [&](uint32_t k) { return live_thread && k - lo2 < 2u; };      // (a thread without a column holds no coefficients)
     if (cnt_lo > kCand) {
         // plateau: more than kCand coefficients share the threshold key (e.g. digital silence).  Take
         // every key above it, then the tied ones in ascending flat-index order until `keep` is reached.
@@ -663,18 +784,28 @@ bool haar_select32_supported(const Plan& p) {
 }
 
 hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_t n_frames, uint32_t* d_packed,
-                                float* d_haar_out, hipStream_t stream) {
+                                float* d_haar_out, hipStream_t stream, bool compact) {
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
+    SparseArgs sp = {};
+    if (compact) {
+        if (!plan.sparse.ok || plan.bands != 32) return hipErrorInvalidValue;
+        sp.left = plan.sparse.left;
+        sp.n_cols = plan.sparse.n_cols;
+        for (uint32_t c = 0; c < 32; ++c) sp.cols[c >> 2] |= (uint32_t)plan.sparse.cols[c] << (8u * (c & 3u));
+        hipLaunchKernelGGL((haar_select32_kernel<32, true>), dim3((uint32_t)n_frames), dim3(256), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out, sp);
+        return hipGetLastError();
+    }
     if (plan.bands == 16)
-        hipLaunchKernelGGL(haar_select32_kernel<16>, dim3((uint32_t)n_frames), dim3(128), 0, stream, d_frames, plan.keep,
-                           plan.subfp_len, d_packed, d_haar_out);
+        hipLaunchKernelGGL((haar_select32_kernel<16, false>), dim3((uint32_t)n_frames), dim3(128), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out, sp);
     else if (plan.bands == 64)
-        hipLaunchKernelGGL(haar_select32_kernel<64>, dim3((uint32_t)n_frames), dim3(512), 0, stream, d_frames, plan.keep,
-                           plan.subfp_len, d_packed, d_haar_out);
+        hipLaunchKernelGGL((haar_select32_kernel<64, false>), dim3((uint32_t)n_frames), dim3(512), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out, sp);
     else
-        hipLaunchKernelGGL(haar_select32_kernel<32>, dim3((uint32_t)n_frames), dim3(256), 0, stream, d_frames, plan.keep,
-                           plan.subfp_len, d_packed, d_haar_out);
+        hipLaunchKernelGGL((haar_select32_kernel<32, false>), dim3((uint32_t)n_frames), dim3(256), 0, stream, d_frames, plan.keep,
+                           plan.subfp_len, d_packed, d_haar_out, sp);
     return hipGetLastError();
 }
 

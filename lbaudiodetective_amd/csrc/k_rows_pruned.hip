@@ -186,7 +186,8 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
                                                                          const float* __restrict__ bin_const,
                                                                          const uint32_t* __restrict__ band_tbl,
                                                                          uint32_t* __restrict__ claim_ctr,
-                                                                         float* __restrict__ frames) {
+                                                                         float* __restrict__ frames, uint32_t frame_dw,
+                                                                         uint32_t place_tbl) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* span = smem;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,6 +223,10 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
     const int band = lane & 31;
     const uint32_t b_lo = band_tbl[band], b_hi = band_tbl[kBands + band];
     const float b_div = __uint_as_float(band_tbl[2 * kBands + band]);
+    // where the band's mean of row w goes inside a frame of frame_dw floats: w * b_mult + b_off -- rows of 32 bands, or
+    // the compact frame of plan.sparse (128 rows of the right sixteen bands, then the 128 means of the one live band of
+    // the left half; b_off = 0xFFFFFFFF: a band that is +0.0 in every window and that nobody reads)
+    const uint32_t b_mult = band_tbl[place_tbl * kBands + band], b_off = band_tbl[(place_tbl + 1) * kBands + band];
 
     const int w8 = lane >> 3, r = lane & 7;
     const float inv_norm = 1.0f / (float)(kW / 4);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
 #ifndef LBAD_EXP_TIMELINE
         if (out_ptr) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) out_ptr[q * 2 * kBands] = out[q];
+            for (int q = 0; q < 4; ++q) out_ptr[q * 2 * b_mult] = out[q];
         }
 #endif
         STAMP(2);
@@ -364,7 +369,9 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = __fdiv_rn(p[q], b_div);
         // row = quarter * 32 + 8 * wave + 2 q + (lane >> 5)
-        out_ptr = frames + ((unit >> 2) * 128 + quarter * kUnitWindows + 8 * wave + (lane >> 5)) * kBands + band;
+        out_ptr = b_off != 0xFFFFFFFFu
+                      ? frames + (unit >> 2) * frame_dw + (quarter * kUnitWindows + 8 * wave + (lane >> 5)) * b_mult + b_off
+                      : nullptr;
 #ifdef LBAD_EXP_TIMELINE
         STAMP(6);
         if (lane == 0) {
@@ -380,8 +387,10 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
         unit = next;
     }
 #ifndef LBAD_EXP_TIMELINE
+    if (out_ptr) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out_ptr[q * 2 * kBands] = out[q];
+        for (int q = 0; q < 4; ++q) out_ptr[q * 2 * b_mult] = out[q];
+    }
 #endif
 }
 
@@ -423,7 +432,7 @@ void rows_pruned_constants(std::vector<float>& out) {
 template <int FMT>
 static hipError_t launch_rows_fmt(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint64_t n_frames,
                                   uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, bool compact) {
     static PerDevice attr;
     if (attr.changed(kLdsBytes)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(frame_rows_pruned_kernel<FMT>),
@@ -441,21 +450,22 @@ static hipError_t launch_rows_fmt(const Plan& plan, const float* d_bin_const, co
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frame_rows_pruned_kernel<FMT>, dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), kLdsBytes,
                        stream, d_pcm, samples_per_clip, frames_per_clip, n_units, units_per_xcd, d_bin_const,
-                       plan.d_bands, claim, d_frames);
+                       plan.d_bands, claim, d_frames, compact ? kSparseFrameDw : 128u * kBands, compact ? 5u : 3u);
     return hipGetLastError();
 }
 
 hipError_t launch_rows_pruned(const Plan& plan, const float* d_bin_const, const void* d_pcm, uint32_t fmt,
                               uint64_t n_clips, uint64_t samples_per_clip, uint32_t frames_per_clip, float* d_frames,
-                              hipStream_t stream) {
+                              hipStream_t stream, bool compact) {
+    if (compact && !plan.sparse.ok) return hipErrorInvalidValue;
     const uint64_t n_frames = n_clips * frames_per_clip;
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
     if (n_frames * 4 + 8 > 0x7fffffffull) return hipErrorInvalidValue;
     switch (fmt) {
-        case 0: return launch_rows_fmt<0>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 1: return launch_rows_fmt<1>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
-        case 2: return launch_rows_fmt<2>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        case 0: return launch_rows_fmt<0>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream, compact);
+        case 1: return launch_rows_fmt<1>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream, compact);
+        case 2: return launch_rows_fmt<2>(plan, d_bin_const, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream, compact);
         default: return hipErrorInvalidValue;
     }
 }

@@ -112,4 +112,42 @@ void make_twiddles(uint32_t W, std::vector<float>& re, std::vector<float>& im) {
     }
 }
 
+// Which bands can be non-zero at all, and what that leaves of the row transform (LBAudioDetectiveFrame.m:134-153 on a
+// row of 32): a band whose bin range is empty is 0 / divisor = +0.0 in every window (LBAudioDetective.m:386-404).  The
+// ordered positions of a row's Haar output are [0] the average, [1] the level-5 detail, [2..3] level 4, [4..7] level 3,
+// [8..15] level 2, [16..31] level 1; an output is structurally zero when both its inputs are.
+void plan_sparse(Plan& plan) {
+    Plan::Sparse sp;
+    plan.sparse = sp;
+    if (plan.bands != 32) return;
+    bool live[32];
+    uint32_t n_left = 0;
+    for (uint32_t b = 0; b < 32; ++b) {
+        live[b] = plan.table.lo[b] < plan.table.hi[b];
+        if (b < 16 && live[b]) { ++n_left; sp.left = b; }
+        // an empty band is 0 / divisor (LBAudioDetective.m:404): +0.0 -- unless the divisor is 0 as well (two equal band
+        // edges, e.g. 48 kHz / 1024), which makes it NaN in every window: such a table keeps the general kernels
+        if (!live[b] && plan.table.indices[b + 1] == plan.table.indices[b]) return;
+    }
+    if (n_left > 1) return;
+    // propagate "can be non-zero" through the five levels
+    bool cur[32], out[32] = {};
+    for (int i = 0; i < 32; ++i) cur[i] = live[i];
+    for (int n = 32; n > 1; n >>= 1) {
+        bool next[16];
+        for (int i = 0; i < n / 2; ++i) {
+            const bool any = cur[2 * i] || cur[2 * i + 1];
+            next[i] = any;
+            out[n / 2 + i] = any;          // the level's details sit at [n / 2, n)
+        }
+        for (int i = 0; i < n / 2; ++i) cur[i] = next[i];
+    }
+    out[0] = cur[0];
+    for (uint32_t c = 0; c < 32; ++c)
+        if (out[c]) sp.cols[sp.n_cols++] = (uint8_t)c;
+    if (sp.n_cols == 0) return;            // nothing is ever read: leave such a table to the general kernels
+    sp.ok = true;
+    plan.sparse = sp;
+}
+
 }  // namespace lbad

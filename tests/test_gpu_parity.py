@@ -881,6 +881,71 @@ def test_stage2_corner_frames(lb, gpu, oracle, variant, bands, keep_len):
             assert np.array_equal(got_bits[i], oracle.extract(want_haar, keep_len)[:keep_len]), f"{name}: bits differ ({bands} bands)"
 
 
+@pytest.mark.parametrize("keep_len", [200, 31, 256])
+def test_stage2_sparse_form_on_corner_frames(lb, gpu, oracle, keep_len):
+    """The sparse form of stage 2 (compact frames: bands 16..31 plus the one live band of the left half -- what 44.1 kHz /
+    1024 produces) against the oracle on the corner frames, masked to that structure: division-shortcut tiers,
+    plateaus, inf / NaN, and -- the tie rule the sparse form must keep -- frames with FEWER non-zero coefficients than are
+    kept (digital silence in all but a few rows; a single non-zero value; nothing at all).  Bits and Haar frames equal the
+    oracle's, and the general form's on the same frames."""
+    det = lb.Detective().configure(sample_rate=44100, window=1024, bands=32, subfp_len=keep_len)
+    lay = lb.compact_layout(det)
+    assert lay == (13, 21), lay                              # band 13 alone on the left; 21 of 32 columns can be non-zero
+    live = np.zeros(32, bool)
+    live[[13, 16, 18] + list(range(20, 32))] = True         # SURVEY 8 a-5, configuration B
+    cases = {k: v * live for k, v in _frames_cases(np.random.default_rng(3), 32).items()
+             if not np.isinf(v).any() or k in ("one_inf", "near_overflow")}
+    for k in ("one_inf",):                                   # keep the inf inside a live band
+        f = cases[k].copy(); f[np.isnan(f)] = 0; f[10, 3] = 0; f[10, 21] = np.inf; cases[k] = f
+    nan = cases["typical"].copy(); nan[77, 31] = np.nan; cases["one_nan"] = nan
+    few = np.zeros((128, 32), np.float32); few[3, 13] = 5.0; few[3, 20] = 7.0; few[90, 31] = 1.0
+    cases["three_values"] = few                              # 3 inputs -> a few dozen non-zero coefficients < keep
+    one = np.zeros((128, 32), np.float32); one[64, 13] = 2.0
+    cases["one_value_left_band"] = one
+    rows = np.zeros((128, 32), np.float32); rows[5:7] = cases["typical"][5:7]
+    cases["two_rows"] = rows
+    cases["zeros"] = np.zeros((128, 32), np.float32)
+    with np.errstate(invalid="ignore"):
+        cases = {k: np.where(live, v, np.float32(0)).astype(np.float32) for k, v in cases.items()}
+    frames = np.stack(list(cases.values()))
+    dev = gpu.from_numpy(frames).cuda()
+    packed, haar = lb.frames_to_subfingerprints_device(det, dev, want_haar=True, compact=True)
+    full = lb.frames_to_subfingerprints_device(det, dev)
+    gpu.cuda.synchronize()
+    got_bits = lb.unpack_packed(packed.cpu().numpy(), keep_len)
+    got_haar = haar.cpu().numpy()
+    assert gpu.equal(packed, full), "sparse and general form disagree"
+    for i, name in enumerate(cases):
+        want_haar = oracle.haar_2d(frames[i])
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(got_haar[i], want_haar, equal_nan=True), f"{name}: Haar differs (sparse form)"
+        if not np.isnan(want_haar).any():
+            assert np.array_equal(got_bits[i], oracle.extract(want_haar, keep_len)[:keep_len]), f"{name}: bits differ (sparse form)"
+
+
+def test_compact_frames_between_the_stages_change_nothing(lb, gpu, oracle):
+    """configs[1]'s batch path with the compact inter-stage frames (default) == the same kernels with full rows
+    (variant 4) == the generic kernels (variant 1) == the oracle, float32 and int16 input, ragged clip lengths."""
+    for n_samples in (44100, 1024 + 64 * 128, 1024 + 64 * 128 * 3 + 17):
+        clips = lb.synth_clips_device(SEED, 7, 48, 44100, n_samples)
+        outs = []
+        for variant in (0, 4, 1):
+            det = lb.Detective().configure(sample_rate=44100, window=1024)
+            det.set_kernel_variant(variant)
+            outs.append(det.fingerprint_clips_device(clips).clone())
+        assert gpu.equal(outs[0], outs[1]) and gpu.equal(outs[0], outs[2])
+        per = outs[0].shape[1]
+        want = oracle.fingerprint_batch(clips.cpu().numpy(), oracle.Config(44100, 1024), nthreads=8)
+        assert np.array_equal(lb.unpack_packed(outs[0].cpu().numpy(), 200).reshape(48, per, 200), want)
+    # other sampling rates with 1024-sample windows: whatever the band table, the layout choice must not matter
+    for rate in (44100, 32000, 22050, 48000, 16000, 8000):
+        det = lb.Detective().configure(sample_rate=rate, window=1024)
+        clips = lb.synth_clips_device(SEED, 3, 16, rate, 1024 + 64 * 128 * 2)
+        a = det.fingerprint_clips_device(clips).clone()
+        det.set_kernel_variant(1)
+        assert gpu.equal(a, det.fingerprint_clips_device(clips)), rate
+
+
 def test_corpus_batch_queries(lb, gpu, oracle):
     """Several queries sharing one pass over the corpus == the same queries one at a time."""
     n = 30000
