@@ -393,24 +393,32 @@ __device__ __forceinline__ float cross_levels(float cur, int h, float root2, boo
 //     and a zero never sets a Boolean (its sign code is 0) nor changes the rank of a non-zero coefficient (every non-zero
 //     key is larger), whether it would have been selected or not -- frames with fewer than `keep` non-zero coefficients
 //     included (tests/test_gpu_parity.py::test_stage2_corner_frames runs them through both forms);
-//   * input: the compact frame stage 1 writes for such a plan (kSparseFrameDw floats), half of the bytes.
+//   * input: the compact frame stage 1 writes for such a plan (kSparseFrameDw floats), half of the bytes;
+//   * a workgroup is THREE waves (192 threads: 128 rows, up to 24 column slots of 8 threads) with 15 KB of transposed
+//     coefficients instead of 20: nine workgroups fit a CU where the general form has seven.  That, not the smaller
+//     instruction count, is what the sparse form returns: the kernel is bound by the life time of a workgroup (a chain
+//     of fourteen barriers) times the number of workgroups a CU holds -- the first sparse build (256 threads, a wave
+//     idle in every phase, 14 % fewer vector instructions) took exactly as long as the general form.
 // Every value that is computed is computed by the same operations on the same operands as in the general form.
 struct SparseArgs {
     uint32_t left, n_cols;
-    uint32_t cols[8];              // 32 ordered positions, one byte each
+    uint32_t cols[8];              // 32 ordered positions, one byte each: the columns that can be non-zero, ascending
+    uint32_t rank[8];              // ordered position -> its place in that list (0xFF: structurally zero), one byte each
 };
+constexpr int kSparseCols = 24;    // column slots of the sparse form (192 threads); a plan with more live columns keeps the general form
+__device__ __forceinline__ uint32_t byte_of(const uint32_t (&tbl)[8], uint32_t i) { return (tbl[i >> 2] >> (8u * (i & 3u))) & 0xFFu; }
 
 template <int COLS, bool SPARSE>
-__global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
+__global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
                                                                           uint32_t subfp_len, uint32_t* __restrict__ packed,
                                                                           float* __restrict__ haar_out, const SparseArgs sp) {
     static_assert(!SPARSE || COLS == 32, "the sparse form is for 32 bands");
     constexpr int kCols = COLS;
-    constexpr int kThreads = COLS * 8;
+    constexpr int kThreads = SPARSE ? 192 : COLS * 8;
     constexpr int kWavesPerWg = kThreads / 64;
     constexpr int H = COLS / 16;                     // threads per row in the row pass
     constexpr uint32_t kIdxBits = COLS == 16 ? 11 : COLS == 32 ? 12 : 13;   // flat index of a coefficient
-    __shared__ __attribute__((aligned(16))) float s_t[kCols * 8 * kChunkDw];   // [col][chunk][20]
+    __shared__ __attribute__((aligned(16))) float s_t[(SPARSE ? kSparseCols : kCols) * 8 * kChunkDw];   // [col (sparse: slot)][chunk][20]
     __shared__ __attribute__((aligned(16))) unsigned long long s_cand[kCand];
     __shared__ uint32_t s_rank[kCand];
     __shared__ uint32_t s_red[16];
@@ -505,21 +513,25 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
             // transposed store: coefficient at ordered position p of this row -> s_t[p][row >> 4][row & 15]; positions
             // that are structurally zero are neither written nor read
             float* base = s_t + (row >> 4) * kChunkDw + (row & 15);
+            auto put = [&](uint32_t pos, float value) {                         // (pos and its slot are wave-uniform)
+                const uint32_t slot = byte_of(sp.rank, pos);
+                if (slot != 0xFFu) base[slot * (8 * kChunkDw)] = value;
+            };
 #pragma unroll
-            for (int i = 0; i < 8; ++i) base[(24 + i) * (8 * kChunkDw)] = d[i];
+            for (int i = 0; i < 8; ++i) put(24 + i, d[i]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) base[(12 + i) * (8 * kChunkDw)] = d[8 + i];
+            for (int i = 0; i < 4; ++i) put(12 + i, d[8 + i]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) base[(6 + i) * (8 * kChunkDw)] = d[12 + i];
-            base[3 * (8 * kChunkDw)] = d[14];
+            for (int i = 0; i < 2; ++i) put(6 + i, d[12 + i]);
+            put(3, d[14]);
             if (sp.left < 32u) {
-                base[(16 + (sp.left >> 1)) * (8 * kChunkDw)] = det[0];
-                base[(8 + (sp.left >> 2)) * (8 * kChunkDw)] = det[1];
-                base[(4 + (sp.left >> 3)) * (8 * kChunkDw)] = det[2];
-                base[2 * (8 * kChunkDw)] = det[3];
+                put(16 + (sp.left >> 1), det[0]);
+                put(8 + (sp.left >> 2), det[1]);
+                put(4 + (sp.left >> 3), det[2]);
+                put(2, det[3]);
             }
-            base[0] = avg;
-            base[1 * (8 * kChunkDw)] = det5;
+            put(0, avg);
+            put(1, det5);
         }
     } else
     // ---- row pass: thread = (row, sixteenth h of the row) ------------------------------------------------
@@ -561,11 +573,9 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
     // arithmetic altogether
     const bool live_thread = !SPARSE || (uint32_t)(t >> 3) < sp.n_cols;
     const bool live_wave = !SPARSE || (uint32_t)((t & ~63) >> 3) < sp.n_cols;          // (wave-uniform)
-    int col = t >> 3;
-    if constexpr (SPARSE) {
-        const uint32_t c = live_thread ? (uint32_t)(t >> 3) : 0u;
-        col = (int)((sp.cols[c >> 2] >> (8u * (c & 3u))) & 0xFFu);
-    }
+    const int cslot = SPARSE ? (live_thread ? t >> 3 : 0) : t >> 3;                   // where the column sits in s_t
+    int col = t >> 3;                                                                 // its ordered position in a row
+    if constexpr (SPARSE) col = (int)byte_of(sp.cols, (uint32_t)cslot);
     const int j = t & 7;
     float v[16];
     if (!live_wave) {
@@ -573,7 +583,7 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
         for (int i = 0; i < 16; ++i) v[i] = 0.0f;
     } else {
         float d[15];
-        const float4* src = reinterpret_cast<const float4*>(s_t + (col * 8 + j) * kChunkDw);
+        const float4* src = reinterpret_cast<const float4*>(s_t + (cslot * 8 + j) * kChunkDw);
         auto load = [&](float (&a)[16]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -737,21 +747,26 @@ __global__ __launch_bounds__(COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_ke
 
     // ---- rank: kThreads / 128 threads per candidate, each scans its share of the list --------------------
     {
-        constexpr uint32_t kParts = kThreads / 128;
-        const uint32_t i = t & 127, part = t >> 7;
-        if (i < nc) {
-            const unsigned long long mine = s_cand[i];
-            // blocks of 8 keys (the tail is zero-padded and never counts); each part takes its share of the blocks
-            const uint32_t nblk = (nc + 7) >> 3, pblk = (nblk + kParts - 1) / kParts;
-            const uint32_t b0 = part * pblk < nblk ? part * pblk : nblk, b1 = b0 + pblk < nblk ? b0 + pblk : nblk;
-            uint32_t r = 0;
-            for (uint32_t b = b0; b < b1; ++b) {
-                const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_cand + 8 * b);
-                const ulonglong2 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-                r += (c0.x > mine ? 1u : 0u) + (c0.y > mine ? 1u : 0u) + (c1.x > mine ? 1u : 0u) + (c1.y > mine ? 1u : 0u) +
-                     (c2.x > mine ? 1u : 0u) + (c2.y > mine ? 1u : 0u) + (c3.x > mine ? 1u : 0u) + (c3.y > mine ? 1u : 0u);
+        // 192 threads (sparse form): three parts, a thread ranks candidates i and i + 64 over its third of the list
+        constexpr uint32_t kGroup = kThreads == 192 ? 64 : 128;                 // threads of a part
+        constexpr uint32_t kParts = kThreads / kGroup;
+        const uint32_t part = t / kGroup;
+#pragma unroll
+        for (uint32_t i = t % kGroup; i < kCand; i += kGroup) {
+            if (i < nc) {
+                const unsigned long long mine = s_cand[i];
+                // blocks of 8 keys (the tail is zero-padded and never counts); each part takes its share of the blocks
+                const uint32_t nblk = (nc + 7) >> 3, pblk = (nblk + kParts - 1) / kParts;
+                const uint32_t b0 = part * pblk < nblk ? part * pblk : nblk, b1 = b0 + pblk < nblk ? b0 + pblk : nblk;
+                uint32_t r = 0;
+                for (uint32_t b = b0; b < b1; ++b) {
+                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_cand + 8 * b);
+                    const ulonglong2 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+                    r += (c0.x > mine ? 1u : 0u) + (c0.y > mine ? 1u : 0u) + (c1.x > mine ? 1u : 0u) + (c1.y > mine ? 1u : 0u) +
+                         (c2.x > mine ? 1u : 0u) + (c2.y > mine ? 1u : 0u) + (c3.x > mine ? 1u : 0u) + (c3.y > mine ? 1u : 0u);
+                }
+                if (r) atomicAdd(&s_rank[i], r);
             }
-            if (r) atomicAdd(&s_rank[i], r);
         }
     }
     __syncthreads();
@@ -790,10 +805,16 @@ hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_
     SparseArgs sp = {};
     if (compact) {
         if (!plan.sparse.ok || plan.bands != 32) return hipErrorInvalidValue;
+        if (plan.sparse.n_cols > (uint32_t)kSparseCols) return hipErrorInvalidValue;
         sp.left = plan.sparse.left;
         sp.n_cols = plan.sparse.n_cols;
+        for (uint32_t i = 0; i < 8; ++i) sp.rank[i] = 0xFFFFFFFFu;
         for (uint32_t c = 0; c < 32; ++c) sp.cols[c >> 2] |= (uint32_t)plan.sparse.cols[c] << (8u * (c & 3u));
-        hipLaunchKernelGGL((haar_select32_kernel<32, true>), dim3((uint32_t)n_frames), dim3(256), 0, stream, d_frames, plan.keep,
+        for (uint32_t c = 0; c < plan.sparse.n_cols; ++c) {
+            const uint32_t pos = plan.sparse.cols[c];
+            sp.rank[pos >> 2] = (sp.rank[pos >> 2] & ~(0xFFu << (8u * (pos & 3u)))) | (c << (8u * (pos & 3u)));
+        }
+        hipLaunchKernelGGL((haar_select32_kernel<32, true>), dim3((uint32_t)n_frames), dim3(192), 0, stream, d_frames, plan.keep,
                            plan.subfp_len, d_packed, d_haar_out, sp);
         return hipGetLastError();
     }

@@ -145,7 +145,7 @@ void plan_sparse(Plan& plan) {
     out[0] = cur[0];
     for (uint32_t c = 0; c < 32; ++c)
         if (out[c]) sp.cols[sp.n_cols++] = (uint8_t)c;
-    if (sp.n_cols == 0) return;            // nothing is ever read: leave such a table to the general kernels
+    if (sp.n_cols == 0 || sp.n_cols > 24) return;   // nothing is ever read / more columns than the sparse stage 2 has slots for
     sp.ok = true;
     plan.sparse = sp;
 }

@@ -52,14 +52,37 @@ def make(cols):
         return np.ascontiguousarray(m, np.float32)
 
 
-for cols, keep_len in ((32, 200), (16, 200), (64, 256), (32, 64)):
-    for variant in (0, 1) if cols == 32 and keep_len == 200 else (0,):
+# "sparse": the sparse form of stage 2 (round 4) on frames masked to the band structure of 44.1 kHz / 1024 -- bands 13, 16,
+# 18, 20..31 live -- with rows and whole bands knocked out at random on top, so that frames with fewer
+# non-zero coefficients than are kept come up often
+LIVE = np.zeros(32, bool)
+LIVE[[13, 16, 18] + list(range(20, 32))] = True
+
+
+def make_sparse():
+    with np.errstate(all="ignore"):
+        m = np.where(LIVE, make(32), np.float32(0)).astype(np.float32)
+        r = rng.random()
+        if r < 0.25:
+            m[rng.random(128) < rng.random()] = 0                   # rows of digital silence
+        elif r < 0.4:
+            m[:, rng.random(32) < 0.7] = 0                          # most live bands silent too
+        elif r < 0.5:
+            keep = rng.integers(0, 128, int(rng.integers(1, 4)))
+            z = np.zeros_like(m); z[keep] = m[keep]; m = z          # one to three rows
+        return np.ascontiguousarray(m, np.float32)
+
+
+for cols, keep_len, mode in ((32, 200, "dense"), (16, 200, "dense"), (64, 256, "dense"), (32, 64, "dense"), (32, 200, "sparse"),
+                            (32, 31, "sparse")):
+    for variant in (0, 1) if cols == 32 and keep_len == 200 and mode == "dense" else (0,):
         det = lb.Detective().configure(sample_rate=44100, window=1024, bands=cols, subfp_len=keep_len)
         det.set_kernel_variant(variant)
         todo = n if variant == 0 else max(1, n // 4)
         for b0 in range(0, todo, 256):
-            frames = np.stack([make(cols) for _ in range(min(256, todo - b0))])
-            packed, haar = lb.frames_to_subfingerprints_device(det, torch.from_numpy(frames).cuda(), want_haar=True)
+            frames = np.stack([(make_sparse() if mode == "sparse" else make(cols)) for _ in range(min(256, todo - b0))])
+            packed, haar = lb.frames_to_subfingerprints_device(det, torch.from_numpy(frames).cuda(), want_haar=True,
+                                                               compact=mode == "sparse")
             torch.cuda.synchronize()
             got_bits = lb.unpack_packed(packed.cpu().numpy(), keep_len)
             got_haar = haar.cpu().numpy()
@@ -71,6 +94,6 @@ for cols, keep_len in ((32, 200), (16, 200), (64, 256), (32, 64)):
                     ok = np.array_equal(got_bits[i], O.extract(want, keep_len)[:keep_len])
                 if not ok:
                     bad += 1
-                    print("STAGE-2 MISMATCH", cols, keep_len, variant, b0 + i, flush=True)
+                    print("STAGE-2 MISMATCH", cols, keep_len, variant, mode, b0 + i, flush=True)
 print(f"{n} frames per shape, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
