@@ -386,8 +386,8 @@ def sliding_leg(args, torch, np):
         "best_index": best[0], "best_score": best[1], "planted_index": PLANTED_1GPU, "found_planted": bool(best[0] == PLANTED_1GPU),
         "scan_ms": round(ms, 4), "query_latency_ms": round(lat_ms, 4),
         "subfingerprint_compares_per_s": round(nq * total / (ms * 1e-3), 1),
-        "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel<4> (k_sliding.hip): integer VALU "
-                     "(2 v_bitop3 + 1 v_bcnt per 32 sign pairs), not HBM",
+        "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel (k_sliding.hip, round 4: only the sliding offsets that "
+                     "exist; 2 v_bitop3 + 1 v_bcnt per 32 sign pairs, 8 DPP moves per step of 4 pairs): integer VALU issue, not HBM",
                      "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes": alg, "layout_GBps": round(32 * total / (ms * 1e-3) / 1e9, 1)},

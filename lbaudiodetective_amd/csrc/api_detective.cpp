@@ -321,6 +321,40 @@ static OSStatus fingerprint_clips_host(LBAudioDetective* d, const void* clips, u
     return noErr;
 }
 
+// the device copy of a rational rate pair's phase table (made once per detective) and its pointers in a descriptor
+OSStatus device_phase(LBAudioDetective* d, const PhaseTable* host, hipStream_t stream, FileDesc& f) {
+    f.ph_p = f.ph_q = 0;
+    if (!host || host->m_span == 0) return noErr;
+    const DevPhase* found = nullptr;
+    for (const DevPhase& e : d->d_phases)
+        if (e.host == host) found = &e;
+    if (!found) {
+        DevPhase e;
+        e.host = host;
+        const size_t q = (size_t)host->q;
+        OSStatus st = hip_status(hipMalloc(reinterpret_cast<void**>(&e.first), q * 4), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMalloc(reinterpret_cast<void**>(&e.count), q * 4), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMalloc(reinterpret_cast<void**>(&e.wsum), q * 8), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMalloc(reinterpret_cast<void**>(&e.w), host->w.size() * 8), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMemcpyAsync(e.first, host->first.data(), q * 4, hipMemcpyHostToDevice, stream), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMemcpyAsync(e.count, host->count.data(), q * 4, hipMemcpyHostToDevice, stream), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMemcpyAsync(e.wsum, host->wsum.data(), q * 8, hipMemcpyHostToDevice, stream), "phase table", __LINE__);
+        if (st == noErr) st = hip_status(hipMemcpyAsync(e.w, host->w.data(), host->w.size() * 8, hipMemcpyHostToDevice, stream), "phase table", __LINE__);
+        if (st != noErr) {
+            if (e.first) (void)hipFree(e.first);
+            if (e.count) (void)hipFree(e.count);
+            if (e.wsum) (void)hipFree(e.wsum);
+            if (e.w) (void)hipFree(e.w);
+            return st;
+        }
+        d->d_phases.push_back(e);           // (the host table lives for the life of the process: pageable copies may finish late)
+        found = &d->d_phases.back();
+    }
+    f.ph_p = host->p; f.ph_q = host->q; f.ph_m_min = host->m_min; f.ph_m_span = host->m_span;
+    f.ph_first = found->first; f.ph_count = found->count; f.ph_wsum = found->wsum; f.ph_w = found->w;
+    return noErr;
+}
+
 // The file front end on the device, one file, samples back on the host (LBAudioDetectiveConvertAudioURL, the parity
 // aid): the payload's bytes go up, the SAME table-driven kernels the batch path uses (decode_batch_kernel,
 // resample_batch_kernel, here with one descriptor) decode and convert, the converted samples come back.
@@ -349,6 +383,8 @@ static OSStatus convert_file_on_device(LBAudioDetective* d, const AudioPayload& 
     f.total_frames = a.total_frames; f.first = a.first; f.n_in = a.count;
     f.n_write = rp.n_out; f.mode = rp.mode; f.copy = rp.copy ? 1u : 0u;
     f.ratio = rp.ratio; f.scale = rp.scale; f.half = rp.half;
+    st = device_phase(d, rp.copy ? nullptr : rp.phases, stream, f);
+    if (st != noErr) return st;
     LBAD_HIP(hipMemcpyAsync(d->d_rs_bytes, a.bytes + a.off, a.len, hipMemcpyHostToDevice, stream));
     LBAD_HIP(hipMemcpyAsync(d->d_rs_desc, &f, sizeof(f), hipMemcpyHostToDevice, stream));
     const double* d_table = nullptr;
@@ -415,6 +451,9 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->h_packed) (void)hipHostFree(inDetective->h_packed);
     for (double* t : inDetective->d_rs_table)
         if (t) (void)hipFree(t);
+    for (lbad::DevPhase& e : inDetective->d_phases) {
+        (void)hipFree(e.first); (void)hipFree(e.count); (void)hipFree(e.wsum); (void)hipFree(e.w);
+    }
     if (inDetective->io_stream) (void)hipStreamDestroy(inDetective->io_stream);
     for (hipEvent_t e : inDetective->ev) (void)hipEventDestroy(e);
     if (inDetective->done) (void)hipEventDestroy(inDetective->done);

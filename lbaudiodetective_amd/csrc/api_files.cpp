@@ -254,6 +254,8 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
         f.n_write = j.n_client < slot_len ? j.n_client : slot_len;
         f.mode = j.rp.mode; f.copy = j.rp.copy ? 1u : 0u;
         f.ratio = j.rp.ratio; f.scale = j.rp.scale; f.half = j.rp.half;
+        st = device_phase(d, j.rp.copy ? nullptr : j.rp.phases, stream, f);
+        if (st != noErr) return st;
         f.row_begin = j.frame0 * kRowsPerFrame; f.rows = j.frames * kRowsPerFrame; f.first_short = j.first_short;
         const uint64_t units = j.a.kind == AudioPayload::Ima4 ? j.a.total_frames / 64 : j.a.total_frames;
         if (units > max_units) max_units = units;

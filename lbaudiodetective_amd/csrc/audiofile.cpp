@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -302,6 +304,72 @@ double bessel_i0(double x) {
 }
 }  // namespace
 
+// The weights of every phase of a rational rate pair (audiofile.hpp), built once per (p, q, mode) and kept for the life of
+// the process; nullptr when the pair is not rational in that sense (or the table would be unreasonably large).
+static const PhaseTable* phase_table(double rate_in, double rate_out, const ResamplePlan& plan) {
+    if (rate_in != std::floor(rate_in) || rate_out != std::floor(rate_out) || rate_in > 4294967295.0 || rate_out > 4294967295.0)
+        return nullptr;
+    uint64_t a = (uint64_t)rate_in, b = (uint64_t)rate_out;
+    while (b) { const uint64_t t = a % b; a = b; b = t; }
+    const uint64_t p = (uint64_t)rate_in / a, q = (uint64_t)rate_out / a;
+    if (q > 16384 || p > (1ull << 24)) return nullptr;
+    if ((2.0 * plan.half + 2.0) * (double)q * 8.0 > 64.0 * 1024.0 * 1024.0) return nullptr;
+    struct Key { uint64_t p, q; uint32_t mode; bool operator<(const Key& o) const { return p != o.p ? p < o.p : q != o.q ? q < o.q : mode < o.mode; } };
+    static std::mutex lock;
+    static std::map<Key, std::unique_ptr<PhaseTable>> cache;
+    std::lock_guard<std::mutex> g(lock);
+    std::unique_ptr<PhaseTable>& slot = cache[Key{p, q, plan.mode}];
+    if (slot) return slot.get();
+    std::unique_ptr<PhaseTable> t(new PhaseTable);
+    t->p = p; t->q = q;
+    const std::vector<double>& table = *plan.table;
+    const double coord = (double)plan.table_res / plan.scale, half = plan.half;
+    t->first.resize(q); t->count.resize(q); t->wsum.resize(q);
+    auto weight = [&](long m, double frac, double& w) -> bool {       // false: the table does not cover the tap
+        const double x = std::fabs((double)m - frac) * coord;
+        const size_t i = (size_t)x;
+        if (i + 1 >= table.size()) return false;
+        w = table[i] + (table[i + 1] - table[i]) * (x - (double)i);
+        return true;
+    };
+    long m_min = 0, m_max = 0;
+    bool any = false;
+    for (uint64_t r = 0; r < q; ++r) {
+        const double frac = (double)r / (double)q;
+        const long c0 = (long)std::ceil(frac - half), c1 = (long)std::floor(frac + half);
+        long fm = 0, n = 0;
+        for (long m = c0; m <= c1; ++m) {
+            double w;
+            if (!weight(m, frac, w)) { if (n) break; continue; }     // (covered taps are contiguous)
+            if (!n) fm = m;
+            ++n;
+        }
+        t->first[r] = (int32_t)fm; t->count[r] = (uint32_t)n;
+        if (n) {
+            if (!any || fm < m_min) m_min = fm;
+            if (!any || fm + n - 1 > m_max) m_max = fm + n - 1;
+            any = true;
+        }
+    }
+    t->m_min = (int32_t)m_min;
+    t->m_span = any ? (uint32_t)(m_max - m_min + 1) : 0u;
+    t->w.assign((size_t)t->m_span * q, 0.0);
+    for (uint64_t r = 0; r < q; ++r) {
+        const double frac = (double)r / (double)q;
+        double sum = 0.0;
+        for (uint32_t j = 0; j < t->count[r]; ++j) {
+            const long m = (long)t->first[r] + j;
+            double w = 0.0;
+            (void)weight(m, frac, w);
+            sum += w;
+            t->w[(size_t)(m - m_min) * q + r] = w;
+        }
+        t->wsum[r] = sum;
+    }
+    slot = std::move(t);
+    return slot.get();
+}
+
 bool resample_plan(uint64_t n_in, double rate_in, double rate_out, uint32_t mode, ResamplePlan& plan) {
     plan = ResamplePlan();
     if (mode > 2 || !(rate_in > 0.0) || !(rate_out > 0.0) || !std::isfinite(rate_in) || !std::isfinite(rate_out))
@@ -341,6 +409,7 @@ bool resample_plan(uint64_t n_in, double rate_in, double rate_out, uint32_t mode
     plan.table = &tables[mode];
     plan.table_res = res;
     plan.half = zero_crossings * plan.scale;                 // kernel half-width in input samples
+    plan.phases = phase_table(rate_in, rate_out, plan);
     return true;
 }
 
@@ -370,8 +439,20 @@ bool resample(const std::vector<float>& in, double rate_in, double rate_out, uin
     const double coord = (double)res / scale;                // table points per input sample
     // every output sample is independent: long inputs are split over the host's cores (same arithmetic per
     // sample, so the result does not depend on the split)
+    const PhaseTable* ph = plan.phases;
     auto span = [&](uint64_t n_begin, uint64_t n_end) {
-        for (uint64_t n = n_begin; n < n_end; ++n) {
+        for (uint64_t n = n_begin; ph && n < n_end; ++n) {           // rational position: the phase's weights are ready
+            const uint64_t np = n * ph->p, r = np % ph->q;
+            const long ip = (long)(np / ph->q), m0 = ph->first[r];
+            const double* w = ph->w.data() + (size_t)(m0 - ph->m_min) * ph->q + r;
+            double acc = 0.0;
+            for (uint32_t j = 0; j < ph->count[r]; ++j, w += ph->q) {
+                const long k = ip + m0 + (long)j;
+                if (k >= 0 && (size_t)k < in.size()) acc += *w * (double)in[(size_t)k];
+            }
+            out[n] = (float)(ph->wsum[r] != 0.0 ? acc / ph->wsum[r] : 0.0);
+        }
+        for (uint64_t n = n_begin; !ph && n < n_end; ++n) {
             const double pos = (double)n * ratio;
             const long k0 = (long)std::ceil(pos - half), k1 = (long)std::floor(pos + half);
             double acc = 0.0, wsum = 0.0;

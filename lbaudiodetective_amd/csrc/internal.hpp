@@ -178,7 +178,25 @@ struct FileDesc {
     uint32_t mode, copy;                       // converter model; 1: rates equal, copy
     double ratio, scale, half;                 // ResamplePlan
     uint64_t row_begin, rows, first_short;     // the file's rows in the clip; first window whose read is short
+    // rational position (audiofile.hpp, PhaseTable): q != 0, the phases' weights on the device
+    uint64_t ph_p, ph_q;
+    int32_t ph_m_min;
+    uint32_t ph_m_span;
+    const int32_t* ph_first;
+    const uint32_t* ph_count;
+    const double* ph_wsum;
+    const double* ph_w;
 };
+struct PhaseTable;
+// the device copy of a phase table, made on first use and kept by the detective
+struct DevPhase {
+    const PhaseTable* host = nullptr;
+    int32_t* first = nullptr;
+    uint32_t* count = nullptr;
+    double* wsum = nullptr;
+    double* w = nullptr;
+};
+OSStatus device_phase(struct ::LBAudioDetective* d, const PhaseTable* host, hipStream_t stream, FileDesc& f);
 hipError_t launch_decode_batch(const FileDesc* d_files, uint32_t n_files, uint64_t max_units, const uint8_t* d_bytes,
                                float* d_decoded, hipStream_t stream);
 hipError_t launch_resample_batch(const FileDesc* d_files, uint32_t n_files, uint64_t max_out, const float* d_decoded, int res,
@@ -332,6 +350,7 @@ struct LBAudioDetective {
     void* d_rs_out = nullptr;
     size_t d_rs_out_cap = 0;
     double* d_rs_table[2] = {nullptr, nullptr};
+    std::vector<lbad::DevPhase> d_phases;   // phase tables of the rational rate pairs met so far
     void* d_rs_desc = nullptr;        // per-file descriptors of a file batch
     size_t d_rs_desc_cap = 0;
     void* d_rs_tail = nullptr;        // tail-mode-2 tables of a file batch

@@ -206,6 +206,44 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
     return (float)(wsum != 0.0 ? acc / wsum : 0.0);
 }
 
+// Rational position (audiofile.hpp): output n = the phase's ready-made weights against the inputs around (n p) div q.
+// One thread per output sample; consecutive outputs have consecutive phases (p mod q apart: 1 at 44.1 kHz -> 5512 Hz), so
+// the block reads its weights as contiguous runs of the tap-major table (L2-resident: 4.2 MB) and its input samples --
+// which lanes share eight apart -- from LDS.  Per tap: one 8-byte load, one LDS read, a conversion, a multiplication, an
+// addition; products of taps outside the file are w * (+0.0), which leaves the sum as it is (it is never -0.0).
+__device__ __forceinline__ float rational_sample(const FileDesc& f, const float* __restrict__ in, uint64_t n, bool active,
+                                                 uint64_t n_first, uint64_t n_last, float* s_in) {
+    // the block's input range: from the first output's first possible tap to the last output's last one
+    const long kbase = (long)((n_first * f.ph_p) / f.ph_q) + (long)f.ph_m_min;
+    const long kend = (long)((n_last * f.ph_p) / f.ph_q) + (long)f.ph_m_min + (long)f.ph_m_span - 1;
+    const bool stage_in = kend - kbase + 1 <= (long)kInMax;
+    __syncthreads();                                          // s_in is reused by consecutive blocks
+    if (stage_in) {
+        for (long p = threadIdx.x; p <= kend - kbase; p += kThreads) {
+            const long kk = kbase + p;
+            s_in[p + (p >> 6)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (!active) return 0.0f;
+    const uint64_t np = n * f.ph_p, r = np % f.ph_q;
+    const long ip = (long)(np / f.ph_q), m0 = (long)f.ph_first[r];
+    const uint32_t cnt = f.ph_count[r];
+    const double* w = f.ph_w + (size_t)(m0 - (long)f.ph_m_min) * f.ph_q + r;
+    double acc = 0.0;
+    if (stage_in) {
+        uint32_t q = (uint32_t)(ip + m0 - kbase);
+        for (uint32_t j = 0; j < cnt; ++j, w += f.ph_q, ++q) acc += *w * (double)s_in[q + (q >> 6)];
+    } else {
+        for (uint32_t j = 0; j < cnt; ++j, w += f.ph_q) {
+            const long k = ip + m0 + (long)j;
+            if (k >= 0 && (uint64_t)k < f.n_in) acc += *w * (double)in[(uint64_t)k];
+        }
+    }
+    const double wsum = f.ph_wsum[r];
+    return (float)(wsum != 0.0 ? acc / wsum : 0.0);
+}
+
 // every file of a batch in one launch: blockIdx.y = file, blockIdx.x walks its output samples; a file whose rate is
 // the processing rate is copied
 __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc* __restrict__ files, const float* __restrict__ decoded,
@@ -226,6 +264,9 @@ __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc
             if (active) v = in[n];
         } else if (f.mode == 2) {
             if (active) v = linear_sample(in, f.n_in, f.ratio, n);
+        } else if (f.ph_q) {
+            const uint64_t n_last = n0 + kThreads - 1 < f.n_write ? n0 + kThreads - 1 : f.n_write - 1;
+            v = rational_sample(f, in, n, active, n0, n_last, s_in);
         } else {
             // (a lane past the end works on the file's last sample, so that every lane reads inside the staged runs)
             v = sinc_sample_tiled(in, f.n_in, f.ratio, f.scale, f.half, res, table, table_n, active ? n : f.n_write - 1, active,

@@ -373,6 +373,42 @@ int lbo_resample(const float* in, uint64_t n_in, double rate_in, double rate_out
     const double s = r > 1.0 ? r : 1.0;
     const double reach = (model == 0 ? 24 : 4) * s;
     const double per_sample = (double)SRC_POINTS_PER_UNIT / s;   /* table points per input sample */
+    /* Rational position (the converter's definition since round 4, csrc/audiofile.hpp): with whole-number rates whose
+     * ratio is P / Q in lowest terms and Q <= 16384, output n sits at input position n P / Q exactly -- whole part W,
+     * remainder R -- and everything but the samples depends on R alone.  Restated here sample by sample, without the
+     * product's table of phases: the taps are W + m, m from ceil(R / Q - reach) to floor(R / Q + reach), weighted by the
+     * kernel table at |m - R / Q| * per_sample, summed in ascending m. */
+    uint64_t P = 0, Q = 0;
+    if (rate_in == floor(rate_in) && rate_out == floor(rate_out) && rate_in <= 4294967295.0 && rate_out <= 4294967295.0) {
+        uint64_t a = (uint64_t)rate_in, b = (uint64_t)rate_out;
+        while (b) { const uint64_t t = a % b; a = b; b = t; }
+        P = (uint64_t)rate_in / a; Q = (uint64_t)rate_out / a;
+        if (Q > 16384 || P > (1ull << 24) || (2.0 * reach + 2.0) * (double)Q * 8.0 > 64.0 * 1024.0 * 1024.0) P = Q = 0;
+    }
+    if (Q) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+        for (int64_t n = 0; n < (int64_t)n_out; ++n) {
+            const uint64_t np = (uint64_t)n * P;
+            const long whole = (long)(np / Q);
+            const double part = (double)(np % Q) / (double)Q;
+            const long first = (long)ceil(part - reach), last = (long)floor(part + reach);
+            double num = 0.0, den = 0.0;
+            for (long m = first; m <= last; ++m) {
+                const double t = fabs((double)m - part) * per_sample;
+                const size_t i = (size_t)t;
+                if (i + 1 >= n_tb) continue;
+                const double w = tb[i] + (tb[i + 1] - tb[i]) * (t - (double)i);
+                den += w;
+                const long k = whole + m;
+                if (k >= 0 && (uint64_t)k < n_in) num += w * (double)in[k];
+            }
+            out[n] = (float)(den != 0.0 ? num / den : 0.0);
+        }
+        free(tb);
+        return 0;
+    }
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static)
 #endif
