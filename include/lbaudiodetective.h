@@ -148,6 +148,11 @@ OSStatus LBAudioDetectiveCompareAudioURLs(LBAudioDetectiveRef inDetective, LBAud
  * one / two files. */
 OSStatus LBAudioDetectiveProcessAudioURLs(LBAudioDetectiveRef inDetective, const char* const* inFilePaths, UInt32 inCount,
                                           LBAudioDetectiveFingerprintRef* outFingerprints, OSStatus* outStatuses);
+/* A call of many files runs as a two-slot pipeline (round 4): the files go through in runs (an eighth of the call's bytes,
+ * at least 16 MB, at most 512 MB), the host reads and parses run i + 1 into a second pinned block while the device decodes,
+ * converts and fingerprints run i, and unpacks run i's results while the device works on run i + 1.  Results do not
+ * depend on it.  SetFilePipeline(detective, 0) makes the call take one run at a time again (measurement). */
+OSStatus LBAudioDetectiveSetFilePipeline(LBAudioDetectiveRef inDetective, UInt32 inEnabled);
 /* Parity aid: the file front end alone, on the device -- the mono samples at the processing rate that the window
  * loop of LBAudioDetectiveProcessAudioURL consumes (payload decode + conversion, k_decode.hip / k_resample.hip),
  * copied to a host buffer the caller releases with LBAudioDetectiveFreeSamples; outFileFrames = the file's length

@@ -269,6 +269,11 @@ class Detective:
             self.subfingerprint_length = subfp_len
         return self
 
+    def set_file_pipeline(self, enabled: bool):
+        """Two runs of a file batch in flight (default) or one at a time (LBAudioDetectiveSetFilePipeline)."""
+        _check(self._L.LBAudioDetectiveSetFilePipeline(self._ref, 1 if enabled else 0), "SetFilePipeline")
+        return self
+
     def set_kernel_variant(self, variant: int):
         _check(self._L.LBAudioDetectiveSetKernelVariant(self._ref, variant), "SetKernelVariant")
 

@@ -443,6 +443,12 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->d_io_packed) (void)hipFree(inDetective->d_io_packed);
     if (inDetective->h_io) (void)hipHostFree(inDetective->h_io);
     if (inDetective->d_rs_bytes) (void)hipFree(inDetective->d_rs_bytes);
+    if (inDetective->d_rs_bytes_b) (void)hipFree(inDetective->d_rs_bytes_b);
+    if (inDetective->up_stream) { (void)hipStreamSynchronize(inDetective->up_stream); (void)hipStreamDestroy(inDetective->up_stream); }
+    for (hipEvent_t e : inDetective->up_done) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : inDetective->bytes_free) if (e) (void)hipEventDestroy(e);
+    if (inDetective->h_files_b) (void)hipHostFree(inDetective->h_files_b);
+    if (inDetective->h_packed_b) (void)hipHostFree(inDetective->h_packed_b);
     if (inDetective->d_rs_in) (void)hipFree(inDetective->d_rs_in);
     if (inDetective->d_rs_out) (void)hipFree(inDetective->d_rs_out);
     if (inDetective->d_rs_tail) (void)hipFree(inDetective->d_rs_tail);

@@ -178,9 +178,26 @@ private:
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
-// one clip: jobs[idx[0..n)] share `hop`
-OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vector<size_t>& idx, uint32_t hop,
-                   LBAudioDetectiveFingerprintRef* out) {
+// A group of files on its way through the device: what must stay alive until its results have been unpacked.
+struct Pending {
+    bool active = false;
+    std::vector<size_t> idx;            // the files (indices into jobs)
+    std::vector<uint32_t> tbl;          // tail mode 2 tables (source of an asynchronous copy)
+    std::vector<FileDesc> descs;        // descriptors (likewise)
+    uint32_t* packed = nullptr;         // pinned: where the packed sub-fingerprints land
+    int slot = 0;
+};
+
+OSStatus finish_group(LBAudioDetective* d, std::vector<Job>& jobs, Pending& p, LBAudioDetectiveFingerprintRef* out);
+
+// one clip: jobs[idx[0..n)] share `hop`.  Everything is enqueued on the detective's stream -- decode, conversion, the window
+// loop's two kernels, the copy of the packed results into the slot's pinned block -- and `p` keeps what the copies read;
+// finish_group() waits for the stream and builds the fingerprints.
+OSStatus enqueue_group(LBAudioDetective* d, std::vector<Job>& jobs, std::vector<size_t>&& idx_in, uint32_t hop, int slot, Pending& p) {
+    p = Pending();
+    p.idx = std::move(idx_in);
+    p.slot = slot;
+    const std::vector<size_t>& idx = p.idx;
     const uint32_t W = d->window, bands = d->bands;
     const uint64_t G = (uint64_t)kRowsPerFrame * hop;
     const uint64_t gap = (W + G - 1) / G;
@@ -210,7 +227,9 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     if (st == noErr) st = grow_device(&d->d_rs_out, &d->d_rs_out_cap, T * sizeof(float));
     if (st == noErr) st = grow_device(reinterpret_cast<void**>(&d->d_io_packed), &d->d_io_packed_cap, packed_bytes);
     if (st == noErr && tbl_words) st = grow_device(&d->d_rs_tail, &d->d_rs_tail_cap, tbl_words * sizeof(uint32_t));
-    if (st == noErr) st = grow_pinned(&d->h_packed, &d->h_packed_cap, packed_bytes);
+    void** h_packed = slot ? &d->h_packed_b : &d->h_packed;
+    size_t* h_packed_cap = slot ? &d->h_packed_b_cap : &d->h_packed_cap;
+    if (st == noErr) st = grow_pinned(h_packed, h_packed_cap, packed_bytes);
     if (st != noErr) return st;
     LBAD_T(g0);
     hipStream_t stream = d->io_stream;                             // the payload bytes are on their way on this stream
@@ -218,7 +237,8 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     LBAD_HIP(hipMemsetAsync(pcm, 0, T * sizeof(float), stream));   // the slots' zero padding
 
     // tail mode 2: nRead shrinks monotonically over the short windows (:252,275: in/out argument)
-    std::vector<uint32_t> tbl(tbl_words);
+    std::vector<uint32_t>& tbl = p.tbl;
+    tbl.assign(tbl_words, 0u);
     for (size_t i : idx) {
         const Job& j = jobs[i];
         if (!j.tbl_n) continue;
@@ -237,7 +257,8 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
 
     // one descriptor per file for the table-driven kernels: decode, conversion and (tail mode 1) the short rows of
     // ALL files are one launch each
-    std::vector<FileDesc> descs(idx.size());
+    std::vector<FileDesc>& descs = p.descs;
+    descs.assign(idx.size(), FileDesc());
     std::vector<FileTail> tails;
     uint64_t max_units = 0, max_out = 0, max_short = 0;
     const uint32_t mode = d->resampler;
@@ -294,8 +315,9 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
         }
         d_table = d->d_rs_table[mode];
     }
-    LBAD_HIP(launch_decode_batch(d_files, (uint32_t)descs.size(), max_units, static_cast<const uint8_t*>(d->d_rs_bytes),
-                                 static_cast<float*>(d->d_rs_in), stream));
+    LBAD_HIP(launch_decode_batch(d_files, (uint32_t)descs.size(), max_units,
+                                 static_cast<const uint8_t*>(slot ? d->d_rs_bytes_b : d->d_rs_bytes), static_cast<float*>(d->d_rs_in), stream));
+    if (d->bytes_free[slot]) LBAD_HIP(hipEventRecord(d->bytes_free[slot], stream));   // the slot's payloads may be replaced from here on
     LBAD_HIP(launch_resample_batch(d_files, (uint32_t)descs.size(), max_out, static_cast<const float*>(d->d_rs_in), table_res,
                                    d_table, table_n, pcm, stream));
     if (d->hop_mode == 1 && d->tail_mode == 1 && max_short) {
@@ -316,10 +338,25 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
                                           tails.empty() ? nullptr : tails.data(), tails.size());
     }
     if (st != noErr) return st;
-    uint32_t* packed = static_cast<uint32_t*>(d->h_packed);
-    LBAD_HIP(hipMemcpyAsync(packed, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
+    p.packed = static_cast<uint32_t*>(*h_packed);
+    LBAD_HIP(hipMemcpyAsync(p.packed, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
+    p.active = true;
+#ifdef LBAD_EXP_FILE_TIMES
     LBAD_T(g1);
-    LBAD_HIP(hipStreamSynchronize(stream));
+    fprintf(stderr, "  group of %zu files: tables + launches %ld us\n", idx.size(), LBAD_US(g0, g1));
+#endif
+    return noErr;
+}
+
+// the group's device work is awaited (the stream: everything enqueued after it is awaited too), its packed results
+// become upstream's Boolean rows
+OSStatus finish_group(LBAudioDetective* d, std::vector<Job>& jobs, Pending& p, LBAudioDetectiveFingerprintRef* out) {
+    if (!p.active) return noErr;
+    p.active = false;
+    const std::vector<size_t>& idx = p.idx;
+    const uint32_t* packed = p.packed;
+    LBAD_T(g1);
+    LBAD_HIP(hipStreamSynchronize(d->io_stream));
     LBAD_T(g2);
     // 32 bytes per sub-fingerprint back into upstream's Boolean rows: a few files per task on the reader pool
     auto unpack = [&](size_t k_begin, size_t k_end) {
@@ -344,15 +381,22 @@ OSStatus run_group(LBAudioDetective* d, std::vector<Job>& jobs, const std::vecto
     }
 #ifdef LBAD_EXP_FILE_TIMES
     LBAD_T(g3);
-    fprintf(stderr, "  group of %zu files: tables + launches %ld us, wait for the device %ld us, unpack %ld us\n", idx.size(),
-            LBAD_US(g0, g1), LBAD_US(g1, g2), LBAD_US(g2, g3));
+    fprintf(stderr, "  group of %zu files: wait for the device %ld us, unpack %ld us\n", idx.size(), LBAD_US(g1, g2), LBAD_US(g2, g3));
 #endif
     return noErr;
 }
 
 // the files [run_b, n) of one pinned block, already on their way to the device: framing, then one clip per hop
+void fail_group(std::vector<Job>& jobs, const std::vector<size_t>& idx, OSStatus st, LBAudioDetectiveFingerprintRef* out) {
+    for (size_t k : idx) {
+        jobs[k].st = st;
+        if (out[k]) { LBAudioDetectiveFingerprintDispose(out[k]); out[k] = NULL; }
+    }
+}
+
+// (the run's LAST group is left on the device -- `pending` -- for the caller to finish after it has read the next run)
 void process_run(LBAudioDetective* d, std::vector<Job>& jobs, size_t run_b, size_t n, uint64_t budget, std::vector<bool>& done,
-                 LBAudioDetectiveFingerprintRef* out) {
+                 LBAudioDetectiveFingerprintRef* out, int slot, Pending& pending) {
     // framing per file (:236,250-255), then one clip per hop value, cut where the inter-stage buffer would overflow
     const double rate = d->format.mSampleRate;
     OSStatus st = noErr;
@@ -388,12 +432,17 @@ void process_run(LBAudioDetective* d, std::vector<Job>& jobs, size_t run_b, size
             frames += jobs[k].frames + gap;
             done[k] = true;
         }
-        st = run_group(d, jobs, idx, hop, out);
+        // the groups of a run share the slot's pinned result block: an earlier group is finished before the next is enqueued
+        if (pending.active) {
+            st = finish_group(d, jobs, pending, out);
+            if (st != noErr) fail_group(jobs, pending.idx, st, out);
+        }
+        std::vector<size_t> members = idx;
+        st = enqueue_group(d, jobs, std::move(idx), hop, slot, pending);
         if (st != noErr) {
-            for (size_t k : idx) {
-                jobs[k].st = st;
-                if (out[k]) { LBAudioDetectiveFingerprintDispose(out[k]); out[k] = NULL; }
-            }
+            (void)hipStreamSynchronize(d->io_stream);          // nothing may still read what `pending` owns
+            pending.active = false;
+            fail_group(jobs, members, st, out);
         }
     }
 }
@@ -441,7 +490,26 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     // the files of a call go through in runs of at most 512 MB of file bytes: read straight into ONE pinned block
     // (pooled threads), parsed in place, uploaded part by part
     LBAD_T(t1);
-    const uint64_t kRunBytes = 512ull << 20;
+    // ... and two runs are in flight: while the device works on run i the pool reads run i + 1 into the OTHER pinned block,
+    // and run i's results are unpacked while the device works on run i + 1.  A call of many files is cut into at least
+    // eight runs (of at least 16 MB) for that; upstream's own workload is 200 files per test (LBAudioDetectiveTests.m:57-91).
+    uint64_t all_bytes = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (jobs[i].st == noErr) all_bytes += align_up(jobs[i].file_size);
+    uint64_t kRunBytes = 512ull << 20;
+    if (d->file_pipeline) {
+        const uint64_t eighth = all_bytes / 8;
+        kRunBytes = eighth < (16ull << 20) ? (16ull << 20) : (eighth < kRunBytes ? eighth : kRunBytes);
+    }
+    Pending in_flight;                  // the previous run's last group
+    int slot = 0;
+    struct Drain {                      // however the call ends, nothing enqueued may outlive what it reads
+        LBAudioDetective* d;
+        ~Drain() {
+            if (d->up_stream) (void)hipStreamSynchronize(d->up_stream);
+            if (d->io_stream) (void)hipStreamSynchronize(d->io_stream);
+        }
+    } drain{d};
     std::vector<bool> done(n, false);
     const uint64_t frame_bytes = (uint64_t)kRowsPerFrame * d->bands * sizeof(float);
     const uint64_t budget = d->scratch_limit / frame_bytes ? d->scratch_limit / frame_bytes : 1;
@@ -455,15 +523,30 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
             }
             ++run_e;
         }
-        st = total ? grow_pinned(&d->h_files, &d->h_files_cap, total) : noErr;
-        if (st == noErr && total) st = grow_device(&d->d_rs_bytes, &d->d_rs_bytes_cap, total);
+        void** h_files = slot ? &d->h_files_b : &d->h_files;
+        size_t* h_files_cap = slot ? &d->h_files_b_cap : &d->h_files_cap;
+        st = total ? grow_pinned(h_files, h_files_cap, total) : noErr;
+        void** d_bytes = slot ? &d->d_rs_bytes_b : &d->d_rs_bytes;
+        size_t* d_bytes_cap = slot ? &d->d_rs_bytes_b_cap : &d->d_rs_bytes_cap;
+        if (st == noErr && total) st = grow_device(d_bytes, d_bytes_cap, total);
+        // the run's payloads go up on their own stream, beside the previous run's kernels: they wait for the decode kernel
+        // that read this slot two runs ago, and this run's kernels wait for them
+        if (st == noErr && !d->up_stream) st = hip_status(hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking), "stream", __LINE__);
+        for (int k = 0; k < 2 && st == noErr; ++k) {
+            if (!d->up_done[k]) st = hip_status(hipEventCreateWithFlags(&d->up_done[k], hipEventDisableTiming), "event", __LINE__);
+            if (st == noErr && !d->bytes_free[k]) {
+                st = hip_status(hipEventCreateWithFlags(&d->bytes_free[k], hipEventDisableTiming), "event", __LINE__);
+                if (st == noErr) st = hip_status(hipEventRecord(d->bytes_free[k], d->io_stream), "event", __LINE__);
+            }
+        }
+        if (st == noErr) st = hip_status(hipStreamWaitEvent(d->up_stream, d->bytes_free[slot], 0), "event", __LINE__);
         if (st != noErr) {
             for (size_t i = run_b; i < run_e; ++i)
                 if (jobs[i].st == noErr) jobs[i].st = st;
             run_b = run_e;
             continue;
         }
-        uint8_t* stage = static_cast<uint8_t*>(d->h_files);
+        uint8_t* stage = static_cast<uint8_t*>(*h_files);
         int device = 0;
         (void)hipGetDevice(&device);
         std::atomic<int> upload_error{0};
@@ -493,7 +576,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
                 j.bytes0 = j.file_off + j.a.off;
             }
             if (hi > lo) {
-                const hipError_t err = hipMemcpyAsync(static_cast<uint8_t*>(d->d_rs_bytes) + lo, stage + lo, hi - lo, hipMemcpyHostToDevice, d->io_stream);
+                const hipError_t err = hipMemcpyAsync(static_cast<uint8_t*>(*d_bytes) + lo, stage + lo, hi - lo, hipMemcpyHostToDevice, d->up_stream);
                 if (err != hipSuccess) upload_error.store((int)err);
             }
         };
@@ -510,8 +593,14 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
             });
         }
         LBAD_T(t2);
+        if (upload_error.load() == 0) {
+            hipError_t e = hipEventRecord(d->up_done[slot], d->up_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(d->io_stream, d->up_done[slot], 0);
+            if (e != hipSuccess) upload_error.store((int)e);
+        }
         if (upload_error.load() != 0) {
             st = hip_status((hipError_t)upload_error.load(), "payload upload", __LINE__);
+            (void)hipStreamSynchronize(d->up_stream);
             (void)hipStreamSynchronize(d->io_stream);
             for (size_t i = run_b; i < run_e; ++i)
                 if (jobs[i].st == noErr) jobs[i].st = st;
@@ -519,13 +608,29 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
             continue;
         }
         LBAD_T(t3);
-        process_run(d, jobs, run_b, run_e, budget, done, out);
+        Pending mine;
+        process_run(d, jobs, run_b, run_e, budget, done, out, slot, mine);
+        // the previous run has had the time this one took to read: collect it now, behind this run's launches
+        if (in_flight.active) {
+            const OSStatus fst = finish_group(d, jobs, in_flight, out);
+            if (fst != noErr) fail_group(jobs, in_flight.idx, fst, out);
+        }
+        in_flight = std::move(mine);
+        if (d->file_pipeline) slot ^= 1;
+        else if (in_flight.active) {
+            const OSStatus fst = finish_group(d, jobs, in_flight, out);
+            if (fst != noErr) fail_group(jobs, in_flight.idx, fst, out);
+        }
 #ifdef LBAD_EXP_FILE_TIMES
         LBAD_T(t4);
         fprintf(stderr, "run of %zu files, %llu bytes: sizes + plan %ld us, read + parse %ld us, upload call %ld us, groups %ld us\n",
                 run_e - run_b, (unsigned long long)total, LBAD_US(t0, t1), LBAD_US(t1, t2), LBAD_US(t2, t3), LBAD_US(t3, t4));
 #endif
         run_b = run_e;
+    }
+    if (in_flight.active) {
+        const OSStatus fst = finish_group(d, jobs, in_flight, out);
+        if (fst != noErr) fail_group(jobs, in_flight.idx, fst, out);
     }
     OSStatus first = noErr;
     for (size_t i = 0; i < n; ++i) {
@@ -548,6 +653,13 @@ OSStatus LBAudioDetectiveProcessAudioURLs(LBAudioDetectiveRef inDetective, const
     if (inCount == 0) return noErr;
     return lbad::process_audio_files(inDetective, inFileURLs, inCount, outFingerprints, outStatuses);
     LBAD_GUARD_END
+}
+
+OSStatus LBAudioDetectiveSetFilePipeline(LBAudioDetectiveRef inDetective, UInt32 inEnabled) {
+    LBAD_LOCK(inDetective);
+    if (!inDetective) return kLBAudioDetectiveArgumentInvalid;
+    inDetective->file_pipeline = inEnabled != 0;
+    return noErr;
 }
 
 }  // extern "C"

@@ -343,8 +343,13 @@ struct LBAudioDetective {
     size_t h_io_cap = 0;
     hipStream_t io_stream = nullptr;
     // converter state of the file entry points: input / output samples and the two kernel tables, grown on demand
-    void* d_rs_bytes = nullptr;       // the file's payload as read
+    void* d_rs_bytes = nullptr;       // the file's payload as read (file batches: slot 0)
     size_t d_rs_bytes_cap = 0;
+    void* d_rs_bytes_b = nullptr;     // file batches, slot 1: run i + 1's payloads go up while run i is decoded
+    size_t d_rs_bytes_b_cap = 0;
+    hipStream_t up_stream = nullptr;  // the uploads of a file batch (beside io_stream, which runs the kernels)
+    hipEvent_t up_done[2] = {nullptr, nullptr};      // behind a run's uploads, on up_stream
+    hipEvent_t bytes_free[2] = {nullptr, nullptr};   // behind the decode kernel that read the slot's payloads, on io_stream
     void* d_rs_in = nullptr;          // decoded mono samples at the file's rate
     size_t d_rs_in_cap = 0;
     void* d_rs_out = nullptr;
@@ -355,10 +360,17 @@ struct LBAudioDetective {
     size_t d_rs_desc_cap = 0;
     void* d_rs_tail = nullptr;        // tail-mode-2 tables of a file batch
     size_t d_rs_tail_cap = 0;
-    void* h_files = nullptr;          // pinned block a file batch is read into
+    // a file batch goes through in runs, two in flight (api_files.cpp): while the device works on run i the host reads
+    // run i + 1 into the other pinned block, and run i's results are unpacked while the device works on run i + 1
+    void* h_files = nullptr;          // pinned block a run of files is read into (slot 0)
     size_t h_files_cap = 0;
-    void* h_packed = nullptr;         // pinned landing area of a file batch's packed results
+    void* h_packed = nullptr;         // pinned landing area of a run's packed results (slot 0)
     size_t h_packed_cap = 0;
+    void* h_files_b = nullptr;        // slot 1
+    size_t h_files_b_cap = 0;
+    void* h_packed_b = nullptr;
+    size_t h_packed_b_cap = 0;
+    bool file_pipeline = true;        // LBAudioDetectiveSetFilePipeline(…, 0): one run at a time (measurement)
     // optional per-stage timing (hipEvents on the caller's stream)
     bool timing = false;
     std::vector<hipEvent_t> ev;   // 3 per chunk: start, after stage 1, after stage 2

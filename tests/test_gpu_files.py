@@ -169,3 +169,66 @@ def test_file_batches_from_several_threads(lb, gpu, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_single_file_calls_from_two_threads_on_one_detective(lb, gpu, oracle):
+    """Round-3 advice: LBAudioDetectiveProcessAudioURL -- upstream's main entry point -- did not take the detective's lock
+    while the batch and pair calls did; two threads on ONE detective raced on the pinned block, the converter buffers and
+    the stride.  Two threads now hammer it with different files, a third mixes in CompareAudioURLs; every fingerprint is
+    the oracle's."""
+    import threading
+    paths = _all_birds()[:10]
+    cfg = oracle.Config()
+    want = {p: oracle.fingerprint_file(p, cfg) for p in paths}
+    det = lb.Detective()
+    errors = []
+
+    def worker(mine):
+        try:
+            for _ in range(8):
+                for p in mine:
+                    got = det.process_audio_url(p).to_bools()
+                    assert got.shape == want[p].shape and np.array_equal(got, want[p]), p
+        except BaseException as e:                                    # noqa: BLE001
+            errors.append(e)
+
+    def comparer():
+        try:
+            first = det.compare_audio_urls(paths[0], paths[1])
+            for _ in range(20):
+                assert det.compare_audio_urls(paths[0], paths[1]) == first
+        except BaseException as e:                                    # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(paths[:5],)), threading.Thread(target=worker, args=(paths[5:],)),
+               threading.Thread(target=comparer)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_many_files_in_one_call_run_as_a_pipeline_with_the_same_results(lb, gpu, oracle):
+    """1200 files in one call (the sixty fixtures x 20: 260 MB, eight runs, two in flight -- the host reads run i + 1 while
+    the device works on run i) against the same call one run at a time and against the oracle; a missing file and an
+    unreadable one in the middle keep their statuses and do not disturb their neighbours."""
+    paths = _all_birds()
+    cfg = oracle.Config()
+    want = [oracle.fingerprint_file(p, cfg) for p in paths]
+    batch = paths * 20
+    batch[137] = "/nonexistent/file.caf"
+    batch[701] = os.path.join(os.path.dirname(BIRDS), "essay_figures.json")        # a file that is no audio file
+    det = lb.Detective()
+    outs = []
+    for pipe in (True, False):
+        det.set_file_pipeline(pipe)
+        fps, statuses = det.process_audio_urls(batch, statuses=True)
+        assert statuses[137] == -43 and statuses[701] != 0 and sum(1 for s in statuses if s != 0) == 2
+        outs.append([None if f is None else f.to_bools() for f in fps])
+    for k, (a, b) in enumerate(zip(*outs)):
+        if k in (137, 701):
+            assert a is None and b is None
+            continue
+        w = want[k % len(paths)]
+        assert a.shape == w.shape and np.array_equal(a, w) and np.array_equal(b, w), k

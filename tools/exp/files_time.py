@@ -9,12 +9,21 @@ copies = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 batch = paths * copies
 det = lb.Detective()
-det.process_audio_urls(batch)
-t = time.perf_counter()
-for _ in range(rounds):
-    fps = det.process_audio_urls(batch)
-dt = time.perf_counter() - t
-print(f"{len(batch)} files per call: {len(batch) * rounds / dt:.0f} files/s, {dt * 1e3 / rounds:.2f} ms per call, {dt * 1e6 / rounds / len(batch):.1f} us per file")
+ref = None
+for rep in range(2):                                         # interleaved A/B: pipeline on, off, on, off
+    for pipe in (True, False):
+        det.set_file_pipeline(pipe)
+        fps = det.process_audio_urls(batch)
+        bits = [f.to_bools().tobytes() for f in fps[:60]]
+        ref = ref or bits
+        assert bits == ref, "results depend on the pipeline"
+        t = time.perf_counter()
+        for _ in range(rounds):
+            fps = det.process_audio_urls(batch)
+        dt = time.perf_counter() - t
+        print(f"{len(batch)} files per call, pipeline {'on ' if pipe else 'off'}: {len(batch) * rounds / dt:.0f} files/s, "
+              f"{dt * 1e3 / rounds:.2f} ms per call, {dt * 1e6 / rounds / len(batch):.1f} us per file")
+det.set_file_pipeline(True)
 a, b = os.path.join(birds, "BlackBird.caf"), os.path.join(birds, "BlackBird_eql.caf")
 det.compare_audio_urls(a, b)
 t = time.perf_counter()
