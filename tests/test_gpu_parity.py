@@ -571,22 +571,17 @@ BIRDS = os.path.join(os.path.dirname(__file__), "golden", "birds")
 
 
 def _oracle_file_fingerprint(lb, oracle, path, hop_mode, tail_mode, resampler=0):
-    """The oracle on the PCM the library's own host-side decoder + converter produce for `path`."""
-    cfg = oracle.Config()
-    x, rate = lb.read_audio_url(path)
-    y, _ = lb.read_audio_url(path, cfg.sample_rate, resampler)
-    if hop_mode == 0:
-        return oracle.fingerprint_pcm(y, cfg)
-    hop = max(1, int(round(cfg.stride * cfg.sample_rate / rate)))     # 64 file frames = 64 * 5512 / 44100 ~ 8 samples
-    return oracle.fingerprint_file_loop(y, x.size, hop, cfg, tail_mode)
+    """The INDEPENDENT oracle on the file itself: its own container reader, IMA4 / LPCM decoder and converter
+    (oracle/lbad_file_oracle.c), then upstream's window loop (oracle/lbad_oracle.c).  Nothing of the product runs."""
+    return oracle.fingerprint_file(path, oracle.Config(), hop_mode, tail_mode, resampler)
 
 
 @pytest.mark.parametrize("hop_mode,tail_mode", [(0, 1), (1, 0), (1, 1), (1, 2)])
 def test_bird_fixtures_compare_audio_urls(lb, gpu, oracle, hop_mode, tail_mode):
     """Upstream Test 1 in miniature (LBAudioDetectiveTests.m:95-97): the 4 s crop of the blackbird
     must match its 9 s original far better than another bird does.  Defaults (5512 Hz / 2048 / 64).
-    For every file-loop mode the GPU fingerprints equal the oracle's on the same decoded + converted PCM,
-    including the windows upstream reads past the end of the file."""
+    For every file-loop mode the GPU fingerprints equal the independent oracle's (own decoder, own converter) on the same
+    FILES, including the windows upstream reads past the end of the file."""
     det = lb.Detective()
     det.set_file_hop_mode(hop_mode).set_file_tail_mode(tail_mode)
     orig = os.path.join(BIRDS, "BlackBird.caf")

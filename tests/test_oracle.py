@@ -317,8 +317,8 @@ def test_file_loop_tail_modes(oracle):
 
 
 def test_oracle_reproduces_essay_figures(oracle):
-    """The oracle, fed by the library's host-side decoder and converter, through upstream's file loop on
-    upstream's sixty fixtures, against the fifty numbers of the essay's Fig. 24-28
+    """The oracle -- its OWN container reader, IMA4 / LPCM decoder and converter (oracle/lbad_file_oracle.c; no product
+    code runs), then upstream's file loop -- on upstream's sixty fixtures, against the fifty numbers of the essay's Fig. 24-28
     (tests/golden/essay_figures.json) -- the only end-to-end results the reference publishes.
     Bounds and the two fixtures that cannot be reached: tools/birds_matrix.py."""
     import sys

@@ -119,7 +119,8 @@ def check(ms):
                 bad.append(f"{t}: mean deviation from the essay {np.abs(d - e).mean():.2f} > 2.5 points")
             if (m.argmax(axis=1) == np.arange(10)).sum() > 5:
                 bad.append(f"{t}: more than five birds identified (essay: {ESSAY['tests'][t]['identified']})")
-    for t, mae, mx in (("test3_1", 4.5, 10.0), ("test3_2", 3.5, 9.0)):
+    # observed (default models; profiles/r04_birds_sweep.json row header/0/1): 3.06 / 8.21 and 1.84 / 6.60 -> + 1 point
+    for t, mae, mx in (("test3_1", 4.1, 9.3), ("test3_2", 2.9, 7.7)):
         if t in ms:
             m = ms[t]
             d, e = np.diag(m), np.array(ESSAY["tests"][t]["right"])
@@ -135,9 +136,37 @@ def check(ms):
     return bad
 
 
+def sweep(path):
+    """Every model the essay cannot see directly, through the INDEPENDENT oracle (CPU only): three converters x two IMA4
+    packet-start models x three end-of-file treatments; per combination the deviation from the essay's bars and the
+    birds identified, test by test."""
+    from oracle import oracle as O
+    rows = []
+    for carry in (0, 1):
+        O.lib().lbo_file_set_ima4_carry(carry)
+        for resampler in (0, 1, 2):
+            for tail in (1, 2, 0):
+                ms = matrices("oracle", 1, tail, resampler)
+                sm = summarize(ms)
+                row = {"ima4_start": "carry" if carry else "header", "resampler": resampler, "tail": tail}
+                for t, r in sm.items():
+                    dev = np.array(r["abs_dev"])
+                    skip = [BIRDS.index(b) for b in UNREACHABLE_TEST1] if t == "test1" else []
+                    keep = [i for i in range(10) if i not in skip]
+                    row[t] = {"mean_dev": round(float(dev[keep].mean()), 2), "max_dev": round(float(dev[keep].max()), 2),
+                              "identified": r["identified"], "essay_identified": r["essay_identified"]}
+                rows.append(row)
+                print(json.dumps(row), flush=True)
+    O.lib().lbo_file_set_ima4_carry(0)
+    json.dump({"engine": "oracle (oracle/lbad_file_oracle.c + oracle/lbad_oracle.c)", "hop": 1,
+               "note": "test1: the two fixtures that cannot be reached (Chaffinch, Wren) are left out of the deviations",
+               "rows": rows}, open(path, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--engine", default="gpu", choices=["gpu", "oracle"])
+    ap.add_argument("--sweep", help="write the model sweep (oracle engine, CPU) to this JSON file and exit")
     ap.add_argument("--hop", type=int, default=1)
     ap.add_argument("--tail", type=int, default=1)
     ap.add_argument("--resampler", type=int, default=0)
@@ -145,6 +174,9 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--matrix", action="store_true", help="print the full 10 x 10 matrices")
     args = ap.parse_args()
+    if args.sweep:
+        sweep(args.sweep)
+        return
     ms = matrices(args.engine, args.hop, args.tail, args.resampler)
     rows = summarize(ms)
     for t in TESTS:
