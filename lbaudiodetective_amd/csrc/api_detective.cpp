@@ -447,6 +447,7 @@ OSStatus LBAudioDetectiveDispose(LBAudioDetectiveRef inDetective) {  // :92-111
     if (inDetective->up_stream) { (void)hipStreamSynchronize(inDetective->up_stream); (void)hipStreamDestroy(inDetective->up_stream); }
     for (hipEvent_t e : inDetective->up_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : inDetective->bytes_free) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : inDetective->packed_done) if (e) (void)hipEventDestroy(e);
     if (inDetective->h_files_b) (void)hipHostFree(inDetective->h_files_b);
     if (inDetective->h_packed_b) (void)hipHostFree(inDetective->h_packed_b);
     if (inDetective->d_rs_in) (void)hipFree(inDetective->d_rs_in);

@@ -340,6 +340,8 @@ OSStatus enqueue_group(LBAudioDetective* d, std::vector<Job>& jobs, std::vector<
     if (st != noErr) return st;
     p.packed = static_cast<uint32_t*>(*h_packed);
     LBAD_HIP(hipMemcpyAsync(p.packed, d->d_io_packed, packed_bytes, hipMemcpyDeviceToHost, stream));
+    if (!d->packed_done[slot]) LBAD_HIP(hipEventCreateWithFlags(&d->packed_done[slot], hipEventDisableTiming));
+    LBAD_HIP(hipEventRecord(d->packed_done[slot], stream));
     p.active = true;
 #ifdef LBAD_EXP_FILE_TIMES
     LBAD_T(g1);
@@ -348,15 +350,15 @@ OSStatus enqueue_group(LBAudioDetective* d, std::vector<Job>& jobs, std::vector<
     return noErr;
 }
 
-// the group's device work is awaited (the stream: everything enqueued after it is awaited too), its packed results
-// become upstream's Boolean rows
+// the group's device work is awaited -- ITS event, not the stream: the next run's kernels, enqueued behind it, keep the device
+// busy while this group's packed results become upstream's Boolean rows
 OSStatus finish_group(LBAudioDetective* d, std::vector<Job>& jobs, Pending& p, LBAudioDetectiveFingerprintRef* out) {
     if (!p.active) return noErr;
     p.active = false;
     const std::vector<size_t>& idx = p.idx;
     const uint32_t* packed = p.packed;
     LBAD_T(g1);
-    LBAD_HIP(hipStreamSynchronize(d->io_stream));
+    LBAD_HIP(hipEventSynchronize(d->packed_done[p.slot]));
     LBAD_T(g2);
     // 32 bytes per sub-fingerprint back into upstream's Boolean rows: a few files per task on the reader pool
     auto unpack = [&](size_t k_begin, size_t k_end) {
@@ -461,17 +463,27 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
 
     // sizes first: a missing or unreadable file is reported as such whether or not a device exists (like
     // ExtAudioFileOpenURL); everything after that needs the GPU
-    bool any = false;
-    for (size_t i = 0; i < n; ++i) {
-        Job& j = jobs[i];
-        if (!paths[i]) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }       // :211-214
-        struct stat sb;
-        if (::stat(paths[i], &sb) != 0) { j.st = -43; continue; }                     // fnfErr
-        const long long sz = (long long)sb.st_size;
-        if (sz <= 0) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
-        j.file_size = (uint64_t)sz;
-        any = true;
+    auto sizes = [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            Job& j = jobs[i];
+            if (!paths[i]) { j.st = kLBAudioDetectiveArgumentInvalid; continue; }       // :211-214
+            struct stat sb;
+            if (::stat(paths[i], &sb) != 0) { j.st = -43; continue; }                     // fnfErr
+            const long long sz = (long long)sb.st_size;
+            if (sz <= 0) { j.st = kLBAudioDetectiveUnsupportedFile; continue; }
+            j.file_size = (uint64_t)sz;
+        }
+    };
+    constexpr size_t kStatsPerTask = 128;
+    if (n < 4 * kStatsPerTask) {
+        sizes(0, n);
+    } else {
+        ReadPool::get().run((n + kStatsPerTask - 1) / kStatsPerTask, [&](size_t task, bool) {
+            sizes(task * kStatsPerTask, (task + 1) * kStatsPerTask < n ? (task + 1) * kStatsPerTask : n);
+        });
     }
+    bool any = false;
+    for (size_t i = 0; i < n; ++i) any = any || (jobs[i].st == noErr && jobs[i].file_size);
     if (any) {
         st = ensure_plan(d);
         if (st == noErr && !d->io_stream) st = hip_status(hipStreamCreateWithFlags(&d->io_stream, hipStreamNonBlocking), "stream", __LINE__);

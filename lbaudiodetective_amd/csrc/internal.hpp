@@ -350,6 +350,7 @@ struct LBAudioDetective {
     hipStream_t up_stream = nullptr;  // the uploads of a file batch (beside io_stream, which runs the kernels)
     hipEvent_t up_done[2] = {nullptr, nullptr};      // behind a run's uploads, on up_stream
     hipEvent_t bytes_free[2] = {nullptr, nullptr};   // behind the decode kernel that read the slot's payloads, on io_stream
+    hipEvent_t packed_done[2] = {nullptr, nullptr};  // behind the copy of a group's packed results into the slot's pinned block
     void* d_rs_in = nullptr;          // decoded mono samples at the file's rate
     size_t d_rs_in_cap = 0;
     void* d_rs_out = nullptr;
