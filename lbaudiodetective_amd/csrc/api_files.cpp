@@ -175,6 +175,10 @@ private:
     bool stop_ = false;
 };
 
+#ifndef LBAD_MIN_RUN_MB
+#define LBAD_MIN_RUN_MB 16
+#endif
+constexpr uint64_t kMinRunBytes = (uint64_t)LBAD_MIN_RUN_MB << 20;
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
@@ -511,7 +515,7 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     uint64_t kRunBytes = 512ull << 20;
     if (d->file_pipeline) {
         const uint64_t eighth = all_bytes / 8;
-        kRunBytes = eighth < (16ull << 20) ? (16ull << 20) : (eighth < kRunBytes ? eighth : kRunBytes);
+        kRunBytes = eighth < kMinRunBytes ? kMinRunBytes : (eighth < kRunBytes ? eighth : kRunBytes);
     }
     Pending in_flight;                  // the previous run's last group
     int slot = 0;

@@ -61,6 +61,19 @@ __device__ __forceinline__ float div_c(float x, float d, float r) {
     }
 }
 
+constexpr uint32_t kHistBuckets = 2048;   // |v| bits >> 20
+
+// inclusive prefix sum over the 64 lanes of a wave (full EXEC): four row shifts, two row broadcasts (gfx9 DPP)
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return x;
+}
+
 template <int WAVES>
 __device__ __forceinline__ uint32_t slots_sum(const uint32_t* slot) {
     uint32_t c = 0;
@@ -425,6 +438,8 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_bits[kPackedWords];
     __shared__ uint8_t s_pos[128];   // [i][j]: row position of coefficient i of the thread that owns chunk j (column pass)
+    __shared__ uint32_t s_sel[4];    // the histogram's bracket: lo, hi, keys >= lo
+    static_assert(sizeof(s_t) >= kHistBuckets * sizeof(uint32_t), "the histogram lives in the transposed coefficients' LDS");
 
     const int t = threadIdx.x;
     const uint64_t frame = blockIdx.x;
@@ -641,6 +656,65 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
     uint32_t lo = 0, hi = 0x80000000u, cnt_lo = kRowsPerFrame * kCols;
     uint32_t idx_bound = kRowsPerFrame * kCols;
     int parity = 0;
+#ifndef LBAD_EXP_NO_HISTOGRAM
+    // First by HISTOGRAM (round 4): 2048 counters over the 11 leading bits of |v| (exponent + 3 mantissa bits: an eighth of
+    // a binade each) in the LDS the transposed coefficients have just left; one wave sums them from the top and finds the
+    // bucket b in which the count of keys >= its lower bound first reaches `keep` -- that bound is a threshold with
+    // [keep, keep + population of b) keys above it, in one pass of 16 LDS atomics per thread instead of eleven rounds of 16
+    // compares and a barrier (measured on synthetic and bird frames: 106-109 keys on average, never more than 126).  A
+    // bucket that holds too many (a plateau, a dense cluster) leaves the bracket [b, b + 1) to the bisection below.  Bucket
+    // 0 (zeros, denormals below 2^-126) is never counted: a threshold down there is the initial bracket's lower end.
+    {
+        uint32_t* hist = reinterpret_cast<uint32_t*>(s_t);
+        __syncthreads();                                   // every wave has read (and, on the slow tiers, re-read) its lines
+        for (int i = t; i < (int)(kHistBuckets / 4); i += kThreads) reinterpret_cast<uint4*>(hist)[i] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        if (live_thread) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= key[i];
+            if (any > 1u) {                                // (a thread of zeros -- silence -- would hammer one counter)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) atomicAdd(&hist[key[i] >> 21], 1u);
+            }
+        }
+        __syncthreads();
+        if (t < 64) {
+            // lane l sums buckets 2047 - 32 l down to 2016 - 32 l; a prefix sum over the lanes is a suffix sum over buckets
+            const uint4* src = reinterpret_cast<const uint4*>(hist) + (kHistBuckets / 4 - 8 - 8 * t);
+            uint32_t own = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint4 c = src[q];
+                own += (c.x + c.y) + (c.z + c.w);
+            }
+            if (t == 63) own -= hist[0];
+            const uint32_t incl = wave_prefix_sum(own), excl = incl - own;
+            const unsigned long long m1 = __ballot(excl < keep && keep <= incl);
+            uint32_t out_lo = 0, out_hi = 1u << 20, out_cnt = kRowsPerFrame * kCols;
+            if (m1 != 0ull) {                                                       // (wave-uniform)
+                const int L = __ffsll((long long)m1) - 1;
+                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)excl, L);
+                const uint32_t top = kHistBuckets - 1u - 32u * (uint32_t)L;           // the lane's highest bucket
+                const uint32_t h = t < 32 ? hist[top - (uint32_t)t] : 0u;
+                const uint32_t p = before + wave_prefix_sum(h);
+                const unsigned long long m2 = __ballot(t < 32 && p - h < keep && keep <= p);
+                const int J = __ffsll((long long)m2) - 1;
+                const uint32_t b = top - (uint32_t)J;
+                if (m2 != 0ull && b != 0u) {
+                    out_lo = b << 20;
+                    out_hi = (b + 1u) << 20;
+                    out_cnt = (uint32_t)__builtin_amdgcn_readlane((int)p, J);
+                }
+            }
+            if (t == 0) { s_sel[0] = out_lo; s_sel[1] = out_hi; s_sel[2] = out_cnt; }
+        }
+        __syncthreads();
+        lo = s_sel[0];
+        hi = s_sel[1];
+        cnt_lo = s_sel[2];
+    }
+#endif
     while (cnt_lo > kCand && hi - lo > 1) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         // one vector compare per key; the per-wave count is a scalar popcount of the lane mask, so the

@@ -3,6 +3,9 @@ own events, interleaved A/B on one box."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+from lbaudiodetective_amd import _native as _N
+if os.environ.get("LBAD_LIB"):
+    _N.LIB_PATH = os.path.abspath(os.environ["LBAD_LIB"])
 import lbaudiodetective_amd as lb
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 clips = lb.synth_clips_device(0x4C424144, 0, n, 44100, 44100)

@@ -11,6 +11,10 @@ if [ "$R" != "r02" ]; then
   PROF_DRIVER=tools/prof_sliding.py tools/prof_run.sh ${R}_sliding_q21 1000000 21 20 70 5
   PROF_DRIVER=tools/prof_sliding.py PROF_SETS=short tools/prof_run.sh ${R}_sliding_q5 1000000 5 20 70 5
   PROF_DRIVER=tools/exp/files_time.py PROF_SETS=short tools/prof_run.sh ${R}_files 1 10
+  if [ "$R" != "r03" ]; then      # round 4: the long query and the 6000-file call
+    PROF_DRIVER=tools/prof_sliding.py PROF_SETS=short tools/prof_run.sh ${R}_sliding_q48 1000000 48 20 70 5
+    PROF_DRIVER=tools/exp/files_time.py PROF_SETS=short tools/prof_run.sh ${R}_files6000 100 2
+  fi
   exit 0
 fi
 # LDS-tile sizing sweep of BASELINE configs[4] on the generic kernel: waves per workgroup x twiddle cache
