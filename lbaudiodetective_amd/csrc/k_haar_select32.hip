@@ -455,6 +455,30 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
 #endif
     STAMP(0);
 
+    // the thread's sixteen frame values are asked for before anything else: the LDS set-up below runs while they travel
+    float4 pre[4];
+    float pre_left = 0.0f;
+    {
+        const float4* src;
+        bool mine = true;
+        if constexpr (SPARSE) {
+            const int row = t < (int)kRowsPerFrame ? t : 0;
+            mine = t < (int)kRowsPerFrame;
+            src = reinterpret_cast<const float4*>(frames + frame * kSparseFrameDw + row * 16);
+            if (mine && sp.left < 32u) pre_left = frames[frame * kSparseFrameDw + kRowsPerFrame * 16 + row];
+        } else {
+            src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + (t / H) * kCols + 16 * (t % H));
+        }
+        if (mine) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = src[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    bool first_read = true;
+
     if (t < (int)kPackedWords) s_bits[t] = 0;
     if (t < (int)kCand) s_rank[t] = 0;
     if (t == 0) s_ncand = 0;
@@ -473,12 +497,13 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
             const float* fr = frames + frame * kSparseFrameDw;
             const float4* src = reinterpret_cast<const float4*>(fr + row * 16);
             float d[15];
-            auto load = [&](float (&a)[16]) {
+            auto load = [&](float (&a)[16]) {       // the first call takes what was fetched at the top, a redo reads again
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 v = src[q];
+                    const float4 v = first_read ? pre[q] : src[q];
                     a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
                 }
+                first_read = false;
             };
             const float root = __fsqrt_rn(32.0f);
             bool fast;
@@ -486,7 +511,7 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
             // bands 0..15: the one live band's mean up the four levels.  At level k the pair is (a, 0) when bit k - 1 of
             // the band's index is clear -- sum (a + 0) / sqrt 2, detail (a - 0) / sqrt 2: the same quotient -- and (0, a)
             // when it is set: detail (0 - a) / sqrt 2.
-            const float xl = sp.left < 32u ? fr[kRowsPerFrame * 16 + row] : 0.0f;
+            const float xl = pre_left;
             float det[4], s4l = 0.0f;
             auto chain = [&](auto fast_tag, DivGuard& g) {
                 constexpr bool F = decltype(fast_tag)::value;
@@ -495,12 +520,15 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
                 float a = div_c<F>(xl, root, r_root);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    // the pair is (a, 0) or (0, a): the sum is a + 0 either way, the difference a - 0 = a or 0 - a = -a, and a
+                    // correctly rounded quotient of -x is minus the quotient of x -- ONE division serves both (the results
+                    // differ from the two-division form in the sign of a zero at most, which nothing downstream can see:
+                    // x +- (+-0) = x, and a zero coefficient has sign code 0 whatever its sign bit)
                     const bool odd = ((sp.left >> k) & 1u) != 0u;               // (uniform)
-                    const float sum_in = __fadd_rn(odd ? 0.0f : a, odd ? a : 0.0f);
-                    const float dif_in = __fsub_rn(odd ? 0.0f : a, odd ? a : 0.0f);
-                    if constexpr (F) g.dividends(sum_in, dif_in);
+                    const float sum_in = __fadd_rn(a, 0.0f);
+                    if constexpr (F) g.dividends(sum_in, sum_in);
                     const float sum = div_c<F>(sum_in, root2, r_root2);
-                    det[k] = div_c<F>(dif_in, root2, r_root2);
+                    det[k] = odd ? -sum : sum;
                     a = sum;
                 }
                 s4l = a;
@@ -557,9 +585,10 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
         auto load = [&](float (&a)[16]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 v = src[q];
+                const float4 v = first_read ? pre[q] : src[q];
                 a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
             }
+            first_read = false;
         };
         bool fast;
         const float cur = haar16(load, d, __fsqrt_rn((float)kCols), root2, fast);   // (16, 32, 64: the device root is exact for these)
@@ -771,7 +800,11 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
     //     |v| bits << (idx bits + 2) | (max idx - idx) << 2 | sign code        (sign code: 1 for v > 0, 2 for v < 0).
     {
         const uint32_t origin = ((uint32_t)col << 7) | (uint32_t)j;    // + (i << 3): index into s_pos, column above it
+        typedef __attribute__((address_space(3))) void lds_void_t;
+        uint32_t ncand_at = (uint32_t)(uintptr_t)(lds_void_t*)&s_ncand, one = 1u;
+        asm volatile("" : "+v"(ncand_at), "+v"(one));                   // (held in registers, not rebuilt per block)
         auto gather = [&](auto selected) {
+#ifdef LBAD_EXP_GATHER_BALLOT
             // the lane masks are taken once and kept (scalar registers) -- eight at a time, with one LDS atomic per wave and
             // half: sixteen masks at once push the kernel's arguments out of the scalar registers (v_writelane spills)
 #pragma unroll
@@ -797,6 +830,23 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
                     base += (uint32_t)__popcll(m);
                 }
             }
+#else
+            // every selected coefficient takes its slot with ONE returning LDS atomic (inline asm: the compiler's atomic
+            // optimiser would rebuild the ballot / mbcnt form around it, and it rematerialises the operands in every
+            // block): the order of the list is whatever the hardware made it, the ranks below do not depend on it.  All
+            // sixteen atomics are in flight before the first slot is used (one wait).
+            uint32_t at[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (selected(i)) asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(at[i]) : "v"(ncand_at), "v"(one) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(at[0]), "+v"(at[1]), "+v"(at[2]), "+v"(at[3]), "+v"(at[4]), "+v"(at[5]), "+v"(at[6]), "+v"(at[7]),
+                           "+v"(at[8]), "+v"(at[9]), "+v"(at[10]), "+v"(at[11]), "+v"(at[12]), "+v"(at[13]), "+v"(at[14]), "+v"(at[15])
+                         :: "memory");
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (selected(i)) s_cand[at[i]] = ((unsigned long long)key[i] << 32) | (origin + (uint32_t)(i << 3));
+#endif
         };
         // (workgroup-uniform) without a plateau one compare per key decides; two copies of the loop, so that the masks
         // stay in scalar registers

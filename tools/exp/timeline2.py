@@ -1,5 +1,9 @@
 """Phase timeline of haar_select32_kernel (build with -DLBAD_EXP_TIMELINE): shader-clock ticks per phase."""
-import torch, numpy as np
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from lbaudiodetective_amd import _native as _N
+if os.environ.get("LBAD_LIB"):
+    _N.LIB_PATH = os.path.abspath(os.environ["LBAD_LIB"])
 import lbaudiodetective_amd as lb
 det = lb.Detective().configure(sample_rate=44100.0, window=1024, stride=64)
 n = 20000
