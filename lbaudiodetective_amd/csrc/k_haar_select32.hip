@@ -871,27 +871,34 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void h
 
     // ---- rank: kThreads / 128 threads per candidate, each scans its share of the list --------------------
     {
-        // 192 threads (sparse form): three parts, a thread ranks candidates i and i + 64 over its third of the list
+        // 192 threads (sparse form): three parts of 64 threads, a thread ranks candidates i and i + 64 over its third of the
+        // list -- both against the SAME loaded block of eight keys (round 4: one trip through LDS serves both)
         constexpr uint32_t kGroup = kThreads == 192 ? 64 : 128;                 // threads of a part
         constexpr uint32_t kParts = kThreads / kGroup;
-        const uint32_t part = t / kGroup;
+        constexpr uint32_t kPer = kCand / kGroup;                               // candidates per thread: 2 or 1
+        const uint32_t part = t / kGroup, i0 = t % kGroup;
+        // blocks of 8 keys (the tail is zero-padded and never counts); each part takes its share of the blocks
+        const uint32_t nblk = (nc + 7) >> 3, pblk = (nblk + kParts - 1) / kParts;
+        const uint32_t b0 = part * pblk < nblk ? part * pblk : nblk, b1 = b0 + pblk < nblk ? b0 + pblk : nblk;
+        unsigned long long mine[kPer];
+        uint32_t r[kPer];
 #pragma unroll
-        for (uint32_t i = t % kGroup; i < kCand; i += kGroup) {
-            if (i < nc) {
-                const unsigned long long mine = s_cand[i];
-                // blocks of 8 keys (the tail is zero-padded and never counts); each part takes its share of the blocks
-                const uint32_t nblk = (nc + 7) >> 3, pblk = (nblk + kParts - 1) / kParts;
-                const uint32_t b0 = part * pblk < nblk ? part * pblk : nblk, b1 = b0 + pblk < nblk ? b0 + pblk : nblk;
-                uint32_t r = 0;
-                for (uint32_t b = b0; b < b1; ++b) {
-                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_cand + 8 * b);
-                    const ulonglong2 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
-                    r += (c0.x > mine ? 1u : 0u) + (c0.y > mine ? 1u : 0u) + (c1.x > mine ? 1u : 0u) + (c1.y > mine ? 1u : 0u) +
-                         (c2.x > mine ? 1u : 0u) + (c2.y > mine ? 1u : 0u) + (c3.x > mine ? 1u : 0u) + (c3.y > mine ? 1u : 0u);
-                }
-                if (r) atomicAdd(&s_rank[i], r);
-            }
+        for (uint32_t k = 0; k < kPer; ++k) {
+            const uint32_t i = i0 + k * kGroup;
+            mine[k] = i < nc ? s_cand[i] : ~0ull;                               // (nothing is larger: rank 0, never stored)
+            r[k] = 0;
         }
+        for (uint32_t b = b0; b < b1; ++b) {
+            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(s_cand + 8 * b);
+            const ulonglong2 c0 = src[0], c1 = src[1], c2 = src[2], c3 = src[3];
+#pragma unroll
+            for (uint32_t k = 0; k < kPer; ++k)
+                r[k] += (c0.x > mine[k] ? 1u : 0u) + (c0.y > mine[k] ? 1u : 0u) + (c1.x > mine[k] ? 1u : 0u) + (c1.y > mine[k] ? 1u : 0u) +
+                        (c2.x > mine[k] ? 1u : 0u) + (c2.y > mine[k] ? 1u : 0u) + (c3.x > mine[k] ? 1u : 0u) + (c3.y > mine[k] ? 1u : 0u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < kPer; ++k)
+            if (r[k]) atomicAdd(&s_rank[i0 + k * kGroup], r[k]);
     }
     __syncthreads();
     if (t < (int)nc) {
