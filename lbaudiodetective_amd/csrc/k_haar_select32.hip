@@ -418,11 +418,17 @@ struct SparseArgs {
     uint32_t cols[8];              // 32 ordered positions, one byte each: the columns that can be non-zero, ascending
     uint32_t rank[8];              // ordered position -> its place in that list (0xFF: structurally zero), one byte each
 };
-constexpr int kSparseCols = 24;    // column slots of the sparse form (192 threads); a plan with more live columns keeps the general form
+#ifndef LBAD_SPARSE_COLS
+#define LBAD_SPARSE_COLS 24
+#endif
+#ifndef LBAD_SPARSE_WAVES
+#define LBAD_SPARSE_WAVES 7
+#endif
+constexpr int kSparseCols = LBAD_SPARSE_COLS;    // column slots of the sparse form (192 threads); a plan with more live columns keeps the general form
 __device__ __forceinline__ uint32_t byte_of(const uint32_t (&tbl)[8], uint32_t i) { return (tbl[i >> 2] >> (8u * (i & 3u))) & 0xFFu; }
 
 template <int COLS, bool SPARSE>
-__global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
+__global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? LBAD_SPARSE_WAVES : COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
                                                                           uint32_t subfp_len, uint32_t* __restrict__ packed,
                                                                           float* __restrict__ haar_out, const SparseArgs sp) {
     static_assert(!SPARSE || COLS == 32, "the sparse form is for 32 bands");
