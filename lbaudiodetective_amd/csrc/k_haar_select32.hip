@@ -418,17 +418,14 @@ struct SparseArgs {
     uint32_t cols[8];              // 32 ordered positions, one byte each: the columns that can be non-zero, ascending
     uint32_t rank[8];              // ordered position -> its place in that list (0xFF: structurally zero), one byte each
 };
-#ifndef LBAD_SPARSE_COLS
-#define LBAD_SPARSE_COLS 24
-#endif
-#ifndef LBAD_SPARSE_WAVES
-#define LBAD_SPARSE_WAVES 7
-#endif
-constexpr int kSparseCols = LBAD_SPARSE_COLS;    // column slots of the sparse form (192 threads); a plan with more live columns keeps the general form
+constexpr int kSparseCols = 21;    // column slots of the sparse form (every configuration with a compact layout has 21 live columns: 30 .. 60 kHz x
+                                   // 512 / 1024 / 2048, tests/test_gpu_parity.py); a plan with more keeps the general form.  13.4 KB of
+                                   // transposed coefficients and 64 VGPRs (4 of them spilled): TEN workgroups per CU (nine with 24 slots
+                                   // and 66 VGPRs: 140 -> 137 us)
 __device__ __forceinline__ uint32_t byte_of(const uint32_t (&tbl)[8], uint32_t i) { return (tbl[i >> 2] >> (8u * (i & 3u))) & 0xFFu; }
 
 template <int COLS, bool SPARSE>
-__global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? LBAD_SPARSE_WAVES : COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
+__global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? 8 : COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
                                                                           uint32_t subfp_len, uint32_t* __restrict__ packed,
                                                                           float* __restrict__ haar_out, const SparseArgs sp) {
     static_assert(!SPARSE || COLS == 32, "the sparse form is for 32 bands");

@@ -145,7 +145,7 @@ void plan_sparse(Plan& plan) {
     out[0] = cur[0];
     for (uint32_t c = 0; c < 32; ++c)
         if (out[c]) sp.cols[sp.n_cols++] = (uint8_t)c;
-    if (sp.n_cols == 0 || sp.n_cols > 24) return;   // nothing is ever read / more columns than the sparse stage 2 has slots for
+    if (sp.n_cols == 0 || sp.n_cols > 21) return;   // nothing is ever read / more columns than the sparse stage 2 has slots for (k_haar_select32.hip: kSparseCols)
     sp.ok = true;
     plan.sparse = sp;
 }

@@ -852,6 +852,14 @@ def _frames_cases(rng, cols=32):
     cases["cancelling_levels_small"] = (np.float32(2.0 ** -70) * (np.float32(1.0) + ulps * np.float32(2.0 ** -23))).astype(np.float32)
     nan = base.copy(); nan[77, cols - 1] = np.nan
     cases["one_nan"] = nan
+    # the threshold search by histogram (round 4: 2048 buckets of an eighth of a binade): thousands of DIFFERENT keys inside
+    # one bucket around the threshold (the bisection has to finish inside the bucket), and fewer non-zero coefficients than are
+    # kept (the threshold lies in bucket 0, which is never counted)
+    wobble = (np.float32(1.0) + rng.uniform(-0.01, 0.01, (128, cols)).astype(np.float32))
+    cases["dense_bucket"] = (np.tile(np.array([1.0, -1.0], np.float32), (128, cols // 2)) * np.float32(3.0) * wobble).astype(np.float32)
+    cases["dense_bucket_small"] = (cases["dense_bucket"] * np.float32(2.0 ** -60)).astype(np.float32)
+    few = np.zeros((128, cols), np.float32); few[3, cols - 3] = 5.0; few[3, cols // 2 + 4] = 7.0; few[90, cols - 1] = 1.0
+    cases["three_values_only"] = few
     return cases
 
 
@@ -874,6 +882,38 @@ def test_stage2_corner_frames(lb, gpu, oracle, variant, bands, keep_len):
             assert np.array_equal(got_haar[i], want_haar, equal_nan=True), f"{name}: Haar differs (variant {variant}, {bands} bands)"
         if not np.isnan(want_haar).any():                   # NaN payloads/signs are not comparable across CPU and GPU
             assert np.array_equal(got_bits[i], oracle.extract(want_haar, keep_len)[:keep_len]), f"{name}: bits differ ({bands} bands)"
+
+
+def test_stage2_sparse_form_on_every_configuration_that_has_one(lb, gpu, oracle):
+    """Sample rates 30 .. 60 kHz x windows 512 / 1024 / 2048: wherever the band table leaves a compact layout (the plan decides:
+    32 bands, at most one live band on the left, no empty band with a zero divisor, at most 24 live columns -- 21 or fewer run
+    the ten-workgroups-per-CU build, 22..24 the other one), the sparse form equals the general form and the oracle on random
+    frames masked to the table's live bands."""
+    rng = np.random.default_rng(11)
+    seen = {}
+    for window in (512, 1024, 2048):
+        for rate in range(30000, 60001, 250):
+            det = lb.Detective().configure(sample_rate=rate, window=window)
+            lay = lb.compact_layout(det)
+            if lay is None:
+                continue
+            _, lo, hi = oracle.band_table(rate, window)
+            live = np.asarray(lo) < np.asarray(hi)
+            frames = (np.abs(rng.standard_normal((6, 128, 32))) * 40.0).astype(np.float32) * live
+            frames[1] *= np.float32(2.0 ** -58)
+            frames[2, 3:] = 0
+            dev = gpu.from_numpy(np.ascontiguousarray(frames, np.float32)).cuda()
+            sparse, haar = lb.frames_to_subfingerprints_device(det, dev, want_haar=True, compact=True)
+            full = lb.frames_to_subfingerprints_device(det, dev)
+            assert gpu.equal(sparse, full), (rate, window, lay)
+            got = lb.unpack_packed(sparse.cpu().numpy(), 200)
+            for i in range(frames.shape[0]):
+                want = oracle.haar_2d(frames[i])
+                assert np.array_equal(haar[i].cpu().numpy(), want), (rate, window, lay, i)
+                assert np.array_equal(got[i], oracle.extract(want, 200)[:200]), (rate, window, lay, i)
+            seen.setdefault(lay[1], []).append((rate, window))
+    assert seen, "no configuration with a compact layout"
+    print("live columns -> configurations:", {k: len(v) for k, v in sorted(seen.items())})
 
 
 @pytest.mark.parametrize("keep_len", [200, 31, 256])
