@@ -458,45 +458,62 @@ def files_leg(args, torch, np):
     for p in paths:
         x, rate = lb.read_audio_url(p)
         seconds += x.size / rate
-    rounds = 5
-    if hasattr(det, "process_audio_urls"):
+    import ctypes as C
+    from lbaudiodetective_amd import _native as N
+    L = N.lib()
+
+    def c_call(batch, rounds_, warm):
+        """LBAudioDetectiveProcessAudioURLs itself: the path array is built once, the fingerprints are released outside the
+        clock (what a C host sees; the ctypes mirror adds ~8 us of Python per file on top)."""
+        n_ = len(batch)
+        arr = (C.c_char_p * n_)(*[p.encode() for p in batch])
+        tot = 0.0
+        for r in range(warm + rounds_):
+            refs, sts = (N.Ref * n_)(), (N.OSStatus * n_)()
+            t1 = time.perf_counter()
+            rc = L.LBAudioDetectiveProcessAudioURLs(det._ref, arr, n_, refs, sts)
+            dt_ = time.perf_counter() - t1
+            if rc != 0 or any(int(x) != 0 for x in sts):
+                raise RuntimeError("LBAudioDetectiveProcessAudioURLs failed inside the bench")
+            for i in range(n_):
+                L.LBAudioDetectiveFingerprintDispose(refs[i])
+            if r >= warm:
+                tot += dt_
+        return tot / rounds_
+
+    rounds = 20
+    fps = det.process_audio_urls(paths)                       # (through the mirror once: the objects the parity check reads)
+    dt60 = c_call(paths, rounds, 3)
+    t1 = time.perf_counter()
+    for _ in range(5):
         det.process_audio_urls(paths)
-        t1 = time.perf_counter()
-        for _ in range(rounds):
-            fps = det.process_audio_urls(paths)
-        dt = time.perf_counter() - t1
-        how = "LBAudioDetectiveProcessAudioURLs (one batch call per round)"
-    else:
-        fps = [det.process_audio_url(p) for p in paths]
-        t1 = time.perf_counter()
-        for _ in range(rounds):
-            fps = [det.process_audio_url(p) for p in paths]
-        dt = time.perf_counter() - t1
-        how = "LBAudioDetectiveProcessAudioURL per file"
+    dt60_py = (time.perf_counter() - t1) / 5
+    how = "LBAudioDetectiveProcessAudioURLs (one batch call per round, the C call timed)"
     n_sub = sum(f.number_of_subfingerprints for f in fps)
     out = {
         "workload": f"configs[0]: {os.path.basename(a)} vs {os.path.basename(b)} through LBAudioDetectiveCompareAudioURLs "
                     f"(reference defaults 5512 Hz / 2048 / 64, upstream's file loop); then the {len(paths)} bundled fixtures "
                     f"({seconds:.0f} s of audio) x {rounds} through {how}",
         "compare_audio_urls_ms": round(pair_ms, 4), "match": m,
-        "files_per_s": round(len(paths) * rounds / dt, 1), "ms_per_file": round(dt * 1e3 / (len(paths) * rounds), 4),
-        "audio_seconds_per_s": round(seconds * rounds / dt, 1), "subfingerprints_per_round": n_sub,
+        "files_per_s": round(len(paths) / dt60, 1), "ms_per_call_of_60": round(dt60 * 1e3, 3),
+        "audio_seconds_per_s": round(seconds / dt60, 1), "subfingerprints_per_round": n_sub,
+        "through_the_python_mirror": {"ms_per_call_of_60": round(dt60_py * 1e3, 3), "files_per_s": round(len(paths) / dt60_py, 1)},
     }
-    if hasattr(det, "process_audio_urls"):
-        # the same fixtures a hundred times over in ONE call: what a catalogue build looks like (two-slot pipeline:
-        # read + unpack of one run overlaps the device work of the run before)
-        many = paths * 100
-        det.process_audio_urls(many[:600])
-        t1 = time.perf_counter()
-        big = det.process_audio_urls(many)
-        dtb = time.perf_counter() - t1
-        out["one_call_of_6000_files"] = {
-            "files": len(many), "ms": round(dtb * 1e3, 2), "files_per_s": round(len(many) / dtb, 1),
-            "us_per_file": round(dtb * 1e6 / len(many), 2),
-            "same_as_the_60_file_call": bool(all(x.to_bools().tobytes() == fps[i % len(paths)].to_bools().tobytes()
-                                                 for i, x in enumerate(big[::7], 0) for i in [i * 7])),
-        }
-        del big
+    # the same fixtures a hundred times over in ONE call: what a catalogue build looks like (two-slot pipeline: read + unpack
+    # of one run overlaps the device work of the run before), and the same call with the pipeline switched off
+    many = paths * 100
+    big = det.process_audio_urls(many)
+    same = bool(all(big[i].to_bools().tobytes() == fps[i % len(paths)].to_bools().tobytes() for i in range(0, len(many), 7)))
+    del big
+    dtb = c_call(many, 3, 1)
+    det.set_file_pipeline(False)
+    dtb_off = c_call(many, 3, 1)
+    det.set_file_pipeline(True)
+    out["one_call_of_6000_files"] = {
+        "files": len(many), "ms": round(dtb * 1e3, 2), "files_per_s": round(len(many) / dtb, 1),
+        "us_per_file": round(dtb * 1e6 / len(many), 2), "same_as_the_60_file_call": same,
+        "without_the_pipeline_ms": round(dtb_off * 1e3, 2), "pipeline_gain": round(dtb_off / dtb, 3),
+    }
     if not args.no_cpu_baseline:
         cfg = O.Config()
         sample = paths[:12]
