@@ -229,7 +229,7 @@ OSStatus LBAudioDetectiveSetFileHopMode(LBAudioDetectiveRef inDetective, UInt32 
  * cannot deliver windowSize frames (the last ~windowSize * fileRate / processingRate file frames):
  *   1 (default) the read delivers nothing: inNumberFrames = 0 makes every band of the row 0.0
  *     (LBAudioDetective.m:382-383,404).  This is the behaviour that reproduces the essay's Fig. 24
- *     (eight lossless `_eql` fixtures within 0.5 points, DESIGN.md section 8);
+ *     (eight lossless `_eql` fixtures within 0.5 points, DESIGN.md section 2);
  *   2 partial reads, literally: the unread part of the in-place FFT buffer keeps the previous window's
  *     packed spectrum and nRead replaces the window size in the band arithmetic (:275,281,351-355,373-395);
  *   0 the unread part is cleared (not upstream). */

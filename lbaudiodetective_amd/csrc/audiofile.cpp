@@ -288,7 +288,7 @@ AudioFileStatus read_audio_file(const char* path, std::vector<float>& mono, doub
 // and a multiplication -- a third of the device converter's time).  Mode 1: the same with a
 // short kernel (4 zero crossings, beta 3, cut-off at the Nyquist frequency: a wide transition band that
 // lets the octave above Nyquist alias in at -20..-40 dB).  Mode 2: linear interpolation between the two
-// neighbouring input samples (no anti-alias filter at all).  DESIGN.md section 8 measures the three against
+// neighbouring input samples (no anti-alias filter at all).  HISTORY.md (rounds 1-3 text, section 8.1) measures the three against
 // the essay's figures: the long kernel and the short one are indistinguishable there, linear
 // interpolation is ruled out by Tests 3.1 / 3.2.
 namespace {

@@ -12,7 +12,6 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__device__ const int kImaIndex[16] = {-1, -1, -1, -1, 2, 4, 6, 8, -1, -1, -1, -1, 2, 4, 6, 8};
 __device__ const int kImaStep[89] = {7,     8,     9,     10,    11,    12,    13,    14,    16,    17,    19,    21,    23,
                                      25,    28,    31,    34,    37,    41,    45,    50,    55,    60,    66,    73,    80,
                                      88,    97,    107,   118,   130,   143,   157,   173,   190,   209,   230,   253,   279,
@@ -23,35 +22,60 @@ __device__ const int kImaStep[89] = {7,     8,     9,     10,    11,    12,    1
 
 // one thread per packet position: its `channels` interleaved 34-byte packets (2-byte big-endian header = 9-bit
 // predictor + 7-bit step index, 64 4-bit codes, low nibble first), accumulated into the 64 output frames channel by
-// channel as the host loop does (0.0f + v == v, so the first channel may store)
+// channel as the host loop does (0.0f + v == v, so the first channel may store).  Round 4: the packet is read as
+// seventeen 16-bit words (bytes when the payload starts at an odd offset), the step table comes from LDS, the index adjustment of a
+// code is arithmetic (-1 for codes 0..3, 2 (code & 3) + 2 above), and the frames leave as sixteen 16-byte stores -- whole
+// 64-byte lines per lane -- instead of 64 single floats (the kernel wrote 2.6 x its output in partial lines).
 __device__ __forceinline__ void ima4_packet(const uint8_t* __restrict__ data, uint64_t p, uint32_t channels,
-                                            float* __restrict__ out) {
-    float* o = out + p * 64;
+                                            float* __restrict__ out, const int* s_step) {
+    float4* o = reinterpret_cast<float4*>(out + p * 64);         // (decoded offsets are 256-byte aligned)
     for (uint32_t c = 0; c < channels; ++c) {
-        const uint8_t* pk = data + (p * channels + c) * 34;
-        const int header = (pk[0] << 8) | pk[1];
+        const uint8_t* pk8 = data + (p * channels + c) * 34;
+        const bool even = (reinterpret_cast<uintptr_t>(pk8) & 1u) == 0;            // (a payload may start at an odd file offset)
+        const uint16_t* pk16 = reinterpret_cast<const uint16_t*>(pk8);
+        auto word_at = [&](int k) -> uint32_t {
+            return even ? (uint32_t)pk16[k] : ((uint32_t)pk8[2 * k] | ((uint32_t)pk8[2 * k + 1] << 8));
+        };
+        const uint32_t h = word_at(0);
+        const int header = (int)(((h & 0xFFu) << 8) | (h >> 8));   // big-endian on a little-endian load
         int predictor = (int)(short)(header & 0xFF80);
         int index = header & 0x7F;
         if (index > 88) index = 88;
-        for (int i = 0; i < 64; ++i) {
-            const int nib = (i & 1) ? (pk[2 + (i >> 1)] >> 4) : (pk[2 + (i >> 1)] & 0x0F);
-            const int step = kImaStep[index];
-            int diff = step >> 3;
-            if (nib & 4) diff += step;
-            if (nib & 2) diff += step >> 1;
-            if (nib & 1) diff += step >> 2;
-            predictor += (nib & 8) ? -diff : diff;
-            if (predictor > 32767) predictor = 32767;
-            if (predictor < -32768) predictor = -32768;
-            index += kImaIndex[nib];
-            if (index < 0) index = 0;
-            if (index > 88) index = 88;
-            const float v = __fdiv_rn((float)predictor, 32768.0f);
-            o[i] = c == 0 ? v : __fadd_rn(o[i], v);
+#pragma unroll 2
+        for (int g = 0; g < 16; ++g) {                            // four codes = one 16-bit word, low nibble of the low byte first
+            const uint32_t word = word_at(1 + g);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nib = (int)((word >> (4 * i)) & 0xFu);
+                const int step = s_step[index];
+                int diff = step >> 3;
+                if (nib & 4) diff += step;
+                if (nib & 2) diff += step >> 1;
+                if (nib & 1) diff += step >> 2;
+                predictor += (nib & 8) ? -diff : diff;
+                if (predictor > 32767) predictor = 32767;
+                if (predictor < -32768) predictor = -32768;
+                index += (nib & 4) ? 2 * (nib & 3) + 2 : -1;
+                if (index < 0) index = 0;
+                if (index > 88) index = 88;
+                v[i] = __fdiv_rn((float)predictor, 32768.0f);
+            }
+            if (c == 0) {
+                o[g] = float4{v[0], v[1], v[2], v[3]};
+            } else {
+                const float4 was = o[g];
+                o[g] = float4{__fadd_rn(was.x, v[0]), __fadd_rn(was.y, v[1]), __fadd_rn(was.z, v[2]), __fadd_rn(was.w, v[3])};
+            }
         }
     }
-    if (channels > 1)
-        for (int i = 0; i < 64; ++i) o[i] = __fdiv_rn(o[i], (float)channels);
+    if (channels > 1) {
+        const float n = (float)channels;
+        for (int g = 0; g < 16; ++g) {
+            const float4 was = o[g];
+            o[g] = float4{__fdiv_rn(was.x, n), __fdiv_rn(was.y, n), __fdiv_rn(was.z, n), __fdiv_rn(was.w, n)};
+        }
+    }
 }
 
 // one sample of `bits` width at p -> float in [-1, 1)  (audiofile.cpp: sample_to_float)
@@ -98,12 +122,15 @@ __device__ __forceinline__ void pcm_frame(const uint8_t* __restrict__ data, uint
 // every file of a batch in one launch: blockIdx.y = file, blockIdx.x walks its packets (IMA4) or frames (PCM)
 __global__ __launch_bounds__(kThreads) void decode_batch_kernel(const FileDesc* __restrict__ files, const uint8_t* __restrict__ bytes,
                                                                 float* __restrict__ decoded) {
+    __shared__ int s_step[89];
+    if (threadIdx.x < 89) s_step[threadIdx.x] = kImaStep[threadIdx.x];
+    __syncthreads();
     const FileDesc f = files[blockIdx.y];
     const uint64_t units = f.kind == 1 ? f.total_frames / 64 : f.total_frames;
     const uint8_t* data = bytes + f.bytes_off;
     float* out = decoded + f.dec_off;
     for (uint64_t u = (uint64_t)blockIdx.x * kThreads + threadIdx.x; u < units; u += (uint64_t)gridDim.x * kThreads) {
-        if (f.kind == 1) ima4_packet(data, u, f.channels, out);
+        if (f.kind == 1) ima4_packet(data, u, f.channels, out, s_step);
         else pcm_frame(data, u, f.channels, f.bits, (int)(f.flags & 1u), (int)((f.flags >> 1) & 1u), f.kind == 3 ? 1 : 0, out);
     }
 }

@@ -73,6 +73,19 @@ __device__ void haar_lines(float* in, float* out, float* scratch, uint32_t lines
     }
 }
 
+constexpr uint32_t kHistBuckets = 2048;   // |v| bits >> 20
+
+// inclusive prefix sum over the 64 lanes of a wave (full EXEC): four row shifts, two row broadcasts (gfx9 DPP)
+__device__ __forceinline__ uint32_t wave_prefix_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return x;
+}
+
 // PER = coefficients per thread (128 x bands / 256, rounded up to 8 / 16 / 32): the select works on registers
 template <int PER>
 __global__ __launch_bounds__(kThreads) void haar_select_kernel(const float* __restrict__ frames, uint32_t bands,
@@ -135,6 +148,60 @@ __global__ __launch_bounds__(kThreads) void haar_select_kernel(const float* __re
     uint32_t cnt_lo = n;
     uint32_t idx_bound = n;             // among key == lo only flat indices < idx_bound are candidates
     int parity = 0;
+    // First by histogram, as in k_haar_select32.hip (round 4): 2048 counters over |v| bits >> 20 in the LDS the Haar has
+    // left (the launcher reserves at least 8 KB), summed from the top by one wave; the bucket in which the count of keys
+    // >= its lower bound first reaches `keep` gives the bracket [b, b + 1) << 20 -- final when at most kCand keys lie above
+    // its lower end (the usual case), else the bisection below finishes inside it.  Bucket 0 is never counted.
+    {
+        uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+        __shared__ uint32_t s_sel[4];
+        __syncthreads();                                   // every thread holds its coefficients in registers
+        for (int i = t; i < (int)(kHistBuckets / 4); i += kThreads) reinterpret_cast<uint4*>(hist)[i] = uint4{0u, 0u, 0u, 0u};
+        __syncthreads();
+        {
+            uint32_t any = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) any |= key[j];
+            if (any) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j) atomicAdd(&hist[key[j] >> 20], 1u);     // (padding keys are 0: bucket 0)
+            }
+        }
+        __syncthreads();
+        if (t < 64) {
+            const uint4* hsrc = reinterpret_cast<const uint4*>(hist) + (kHistBuckets / 4 - 8 - 8 * t);
+            uint32_t own = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint4 c = hsrc[q];
+                own += (c.x + c.y) + (c.z + c.w);
+            }
+            if (t == 63) own -= hist[0];
+            const uint32_t incl = wave_prefix_sum(own), excl = incl - own;
+            const unsigned long long m1 = __ballot(excl < keep && keep <= incl);
+            uint32_t out_lo = 0, out_hi = 1u << 20, out_cnt = n;
+            if (m1 != 0ull) {
+                const int L = __ffsll((long long)m1) - 1;
+                const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)excl, L);
+                const uint32_t top = kHistBuckets - 1u - 32u * (uint32_t)L;
+                const uint32_t h = t < 32 ? hist[top - (uint32_t)t] : 0u;
+                const uint32_t p = before + wave_prefix_sum(h);
+                const unsigned long long m2 = __ballot(t < 32 && p - h < keep && keep <= p);
+                const int J = __ffsll((long long)m2) - 1;
+                const uint32_t bkt = top - (uint32_t)J;
+                if (m2 != 0ull && bkt != 0u) {
+                    out_lo = bkt << 20;
+                    out_hi = (bkt + 1u) << 20;
+                    out_cnt = (uint32_t)__builtin_amdgcn_readlane((int)p, J);
+                }
+            }
+            if (t == 0) { s_sel[0] = out_lo; s_sel[1] = out_hi; s_sel[2] = out_cnt; }
+        }
+        __syncthreads();
+        lo = s_sel[0];
+        hi = s_sel[1];
+        cnt_lo = s_sel[2];
+    }
     while (cnt_lo > kCand && hi - lo > 1) {
         const uint32_t mid = lo + ((hi - lo) >> 1);     // >= 1: the padding keys never count
         const uint32_t c = block_count([&](int j) { return key[j] >= mid; }, parity);
@@ -221,7 +288,8 @@ hipError_t launch_haar_select(const Plan& plan, float* d_frames, uint64_t n_fram
                               float* d_haar_out, hipStream_t stream) {
     if (n_frames == 0) return hipSuccess;
     if (n_frames > 0x7fffffffull) return hipErrorInvalidValue;
-    const size_t lds = (size_t)(5 * kRowsPerFrame * plan.bands / 2) * sizeof(float);      // frame, row-pass result, running sums
+    size_t lds = (size_t)(5 * kRowsPerFrame * plan.bands / 2) * sizeof(float);            // frame, row-pass result, running sums
+    if (lds < kHistBuckets * sizeof(uint32_t)) lds = kHistBuckets * sizeof(uint32_t);     // ... and the select's histogram afterwards
     const uint32_t per = (kRowsPerFrame * plan.bands + kThreads - 1) / kThreads;
     if (plan.keep > kCand || per > 32) return hipErrorInvalidValue;
     auto launch = [&](auto kern) -> hipError_t {

@@ -207,41 +207,91 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
 }
 
 // Rational position (audiofile.hpp): output n = the phase's ready-made weights against the inputs around (n p) div q.
-// One thread per output sample; consecutive outputs have consecutive phases (p mod q apart: 1 at 44.1 kHz -> 5512 Hz), so
-// the block reads its weights as contiguous runs of the tap-major table (L2-resident: 4.2 MB) and its input samples --
-// which lanes share eight apart -- from LDS.  Per tap: one 8-byte load, one LDS read, a conversion, a multiplication, an
-// addition; products of taps outside the file are w * (+0.0), which leaves the sum as it is (it is never -0.0).
-__device__ __forceinline__ float rational_sample(const FileDesc& f, const float* __restrict__ in, uint64_t n, bool active,
-                                                 uint64_t n_first, uint64_t n_last, float* s_in) {
-    // the block's input range: from the first output's first possible tap to the last output's last one
-    const long kbase = (long)((n_first * f.ph_p) / f.ph_q) + (long)f.ph_m_min;
-    const long kend = (long)((n_last * f.ph_p) / f.ph_q) + (long)f.ph_m_min + (long)f.ph_m_span - 1;
-    const bool stage_in = kend - kbase + 1 <= (long)kInMax;
-    __syncthreads();                                          // s_in is reused by consecutive blocks
-    if (stage_in) {
-        for (long p = threadIdx.x; p <= kend - kbase; p += kThreads) {
-            const long kk = kbase + p;
-            s_in[p + (p >> 6)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
+// Outputs n and n + q have the SAME phase, hence the same weights, and their inputs lie exactly p samples apart.  A block
+// takes a run of up to 256 positions inside the period of q outputs and kPeriods consecutive periods: a thread loads
+// each of its ~385 weights ONCE (8 bytes, contiguous across the block where p mod q = 1: 44.1 kHz -> 5512 Hz) and uses it
+// for kPeriods outputs, whose input samples -- which lanes share eight apart -- come from kPeriods staged ranges in LDS.
+// (Round 4, first version: one output per thread, i.e. 3 KB of weights per output through L2 -- 4.9 GB per sixty files,
+// the whole kernel time.)  Per tap and output: one LDS read, a conversion, a multiplication, an addition, in the tap
+// order of resample(); products of taps outside the file are w * (+0.0), which leaves the sum as it is (never -0.0).
+constexpr int kPeriods = 3;
+constexpr int kInStride = kInMax + kInMax / 64 + 1;
+
+__device__ __forceinline__ void rational_file(const FileDesc& f, const float* __restrict__ in, float* __restrict__ out,
+                                              float (*s_in)[kInStride]) {
+    const uint64_t Q = f.ph_q, P = f.ph_p;
+    const uint64_t chunks = (Q + kThreads - 1) / kThreads;
+    const uint64_t periods = (f.n_write + Q - 1) / Q;
+    const uint64_t groups = (periods + kPeriods - 1) / kPeriods;
+    for (uint64_t slot = blockIdx.x; slot < chunks * groups; slot += gridDim.x) {
+        const uint64_t c = slot % chunks, g = slot / chunks;
+        const uint64_t t0 = c * kThreads;                                   // first position of the run inside the period
+        const uint64_t lanes = Q - t0 < (uint64_t)kThreads ? Q - t0 : (uint64_t)kThreads;
+        long kbase[kPeriods];
+        bool staged[kPeriods], any[kPeriods];
+        __syncthreads();                                                    // s_in is reused by consecutive slots
+#pragma unroll
+        for (int k = 0; k < kPeriods; ++k) {
+            const uint64_t nf = (g * kPeriods + (uint64_t)k) * Q + t0;      // the run's first output in period k
+            any[k] = nf < f.n_write;
+            staged[k] = false;
+            kbase[k] = 0;
+            if (!any[k]) continue;                                          // (uniform)
+            const uint64_t nl = nf + lanes - 1 < f.n_write ? nf + lanes - 1 : f.n_write - 1;
+            kbase[k] = (long)((nf * P) / Q) + (long)f.ph_m_min;
+            const long kend = (long)((nl * P) / Q) + (long)f.ph_m_min + (long)f.ph_m_span - 1;
+            staged[k] = kend - kbase[k] + 1 <= (long)kInMax;
+            if (staged[k]) {
+                for (long p = threadIdx.x; p <= kend - kbase[k]; p += kThreads) {
+                    const long kk = kbase[k] + p;
+                    s_in[k][p + (p >> 6)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
+                }
+            }
         }
-    }
-    __syncthreads();
-    if (!active) return 0.0f;
-    const uint64_t np = n * f.ph_p, r = np % f.ph_q;
-    const long ip = (long)(np / f.ph_q), m0 = (long)f.ph_first[r];
-    const uint32_t cnt = f.ph_count[r];
-    const double* w = f.ph_w + (size_t)(m0 - (long)f.ph_m_min) * f.ph_q + r;
-    double acc = 0.0;
-    if (stage_in) {
-        uint32_t q = (uint32_t)(ip + m0 - kbase);
-        for (uint32_t j = 0; j < cnt; ++j, w += f.ph_q, ++q) acc += *w * (double)s_in[q + (q >> 6)];
-    } else {
-        for (uint32_t j = 0; j < cnt; ++j, w += f.ph_q) {
-            const long k = ip + m0 + (long)j;
-            if (k >= 0 && (uint64_t)k < f.n_in) acc += *w * (double)in[(uint64_t)k];
+        __syncthreads();
+        if (threadIdx.x >= lanes) continue;
+        const uint64_t n0 = g * kPeriods * Q + t0 + threadIdx.x;            // this thread's output in the group's first period
+        if (n0 >= f.n_write) continue;
+        const uint64_t np = n0 * P, r = np % Q;
+        const long ip0 = (long)(np / Q), m0 = (long)f.ph_first[r];
+        const uint32_t cnt = f.ph_count[r];
+        const double* w = f.ph_w + (size_t)(m0 - (long)f.ph_m_min) * Q + r;
+        double acc[kPeriods];
+        bool act[kPeriods];
+        uint32_t q[kPeriods];
+        bool all_staged = true;
+#pragma unroll
+        for (int k = 0; k < kPeriods; ++k) {
+            acc[k] = 0.0;
+            act[k] = n0 + (uint64_t)k * Q < f.n_write;
+            // (an output behind the file's end walks the front of its buffer instead: read, never stored)
+            q[k] = act[k] ? (uint32_t)(ip0 + (long)((uint64_t)k * P) + m0 - kbase[k]) : 0u;
+            all_staged = all_staged && (staged[k] || !any[k]);
         }
+        if (all_staged) {                                                   // (uniform) the usual case
+            for (uint32_t j = 0; j < cnt; ++j, w += Q) {
+                const double wv = *w;
+#pragma unroll
+                for (int k = 0; k < kPeriods; ++k) {
+                    acc[k] += wv * (double)s_in[k][q[k] + (q[k] >> 6)];
+                    ++q[k];
+                }
+            }
+        } else {
+            for (uint32_t j = 0; j < cnt; ++j, w += Q) {
+                const double wv = *w;
+#pragma unroll
+                for (int k = 0; k < kPeriods; ++k) {
+                    const long kk = ip0 + (long)((uint64_t)k * P) + m0 + (long)j;
+                    if (act[k] && kk >= 0 && (uint64_t)kk < f.n_in) acc[k] += wv * (double)in[(uint64_t)kk];
+                }
+            }
+        }
+        const double wsum = f.ph_wsum[r];
+#pragma unroll
+        for (int k = 0; k < kPeriods; ++k)
+            if (act[k]) out[n0 + (uint64_t)k * Q] = (float)(wsum != 0.0 ? acc[k] / wsum : 0.0);
     }
-    const double wsum = f.ph_wsum[r];
-    return (float)(wsum != 0.0 ? acc / wsum : 0.0);
 }
 
 // every file of a batch in one launch: blockIdx.y = file, blockIdx.x walks its output samples; a file whose rate is
@@ -249,13 +299,21 @@ __device__ __forceinline__ float rational_sample(const FileDesc& f, const float*
 __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc* __restrict__ files, const float* __restrict__ decoded,
                                                                   int res, const double* __restrict__ table, uint64_t table_n,
                                                                   float* __restrict__ pcm) {
-    __shared__ double s_rows[kTapGroup][kRowLen];
+    // one block of LDS, two uses: the tiled path's table rows + one staged input range, or the rational path's kPeriods ranges
+    constexpr size_t kTiledBytes = sizeof(double) * kTapGroup * kRowLen + sizeof(float) * kInStride;
+    constexpr size_t kRationalBytes = sizeof(float) * kPeriods * kInStride;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTiledBytes > kRationalBytes ? kTiledBytes : kRationalBytes];
     __shared__ uint32_t s_lo[kTapGroup];
     __shared__ uint32_t s_stat[8];
-    __shared__ float s_in[kInMax + kInMax / 64 + 1];
+    double (*s_rows)[kRowLen] = reinterpret_cast<double (*)[kRowLen]>(s_raw);
+    float* s_in = reinterpret_cast<float*>(s_raw + sizeof(double) * kTapGroup * kRowLen);
     const FileDesc f = files[blockIdx.y];
     const float* in = decoded + f.dec_off + f.first;
     float* out = pcm + f.out_off;
+    if (!f.copy && f.mode != 2 && f.ph_q) {
+        rational_file(f, in, out, reinterpret_cast<float (*)[kInStride]>(s_raw));
+        return;
+    }
     for (uint64_t n0 = (uint64_t)blockIdx.x * kThreads; n0 < f.n_write; n0 += (uint64_t)gridDim.x * kThreads) {
         const uint64_t n = n0 + threadIdx.x;
         const bool active = n < f.n_write;
@@ -264,9 +322,6 @@ __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc
             if (active) v = in[n];
         } else if (f.mode == 2) {
             if (active) v = linear_sample(in, f.n_in, f.ratio, n);
-        } else if (f.ph_q) {
-            const uint64_t n_last = n0 + kThreads - 1 < f.n_write ? n0 + kThreads - 1 : f.n_write - 1;
-            v = rational_sample(f, in, n, active, n0, n_last, s_in);
         } else {
             // (a lane past the end works on the file's last sample, so that every lane reads inside the staged runs)
             v = sinc_sample_tiled(in, f.n_in, f.ratio, f.scale, f.half, res, table, table_n, active ? n : f.n_write - 1, active,

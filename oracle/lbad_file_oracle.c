@@ -2,7 +2,7 @@
  * lbad_file_oracle.c -- CPU oracle of the FILE front end: container, payload decode and sample-rate conversion.
  *
  * TEST INFRASTRUCTURE ONLY (see lbad_oracle.h).  Written from the published formats and from the converter
- * definitions in DESIGN.md section 8, sharing no source with lbaudiodetective_amd/csrc/audiofile.cpp or the device
+ * definitions in lbaudiodetective_amd/csrc/audiofile.hpp and HISTORY.md (rounds 1-3 text, section 8), sharing no source with lbaudiodetective_amd/csrc/audiofile.cpp or the device
  * kernels (k_decode.hip, k_resample.hip) it checks.
  *
  * What it stands in for upstream: ExtAudioFileOpenURL / ExtAudioFileRead with a mono float32 client format at the
@@ -296,7 +296,7 @@ int lbo_file_decode(const char* path, float** out_mono, uint64_t* out_frames, do
 
 void lbo_file_free(float* p) { free(p); }
 
-/* ---- sample-rate conversion: the three documented models -------------------------------
+/* ---- sample-rate conversion: the three documented models (audiofile.hpp; HISTORY.md section 8) -------------------------------
  * Output sample n is taken at input position x = n * r with r = rate_in / rate_out (double); the output has
  * floor(n_in / r) samples.
  *   model 2  linear interpolation between in[floor x] and in[floor x + 1] (0 past the end), in double.

@@ -23,7 +23,7 @@ DIR = os.path.join(ROOT, "tests", "golden", "birds")
 ESSAY = json.load(open(os.path.join(ROOT, "tests", "golden", "essay_figures.json")))
 TESTS = ["test1", "test2", "test3_1", "test3_2", "test4"]
 
-# Two fixtures cannot reproduce Fig. 24 whatever the converter or tail model:
+# Two fixtures cannot reproduce Fig. 24 whatever the converter or tail model (HISTORY.md, rounds 1-3 text, section 8.1):
 #   Chaffinch  Chaffinch_eql.caf is the only `_eql` file that is NOT a bit-exact prefix of its original (it was
 #              re-encoded: rms error 0.014, 5.7 dB SNR in the 231-2040 Hz band the bands read), so its first 19
 #              sub-fingerprints match at ~0.57 instead of 1.0; the essay's 93.0 equals the lossless birds' value.

@@ -2,8 +2,8 @@
 """Randomized GPU-vs-oracle sweep of the ragged corpus (not part of the test suite): tools/fuzz_ragged.py [trials] [seed].
 Corpora of 1..400 entries with 1..90 sub-fingerprints each (every length distribution: all short, all long, mixed,
 a few very long ones past the record's saturating position fields), sub-fingerprint lengths 1..200, queries of
-1..130 sub-fingerprints (shorter than, equal to and longer than the entries: all three kernel modes and the
-long-against-long kernel), every range, planted windows, duplicated entries (lowest index wins), empty
+1..130 sub-fingerprints (shorter than, equal to and longer than the entries: the systolic kernel for short windows, the
+task kernel's "A" and "B" passes and corpora that need both), every range, planted windows, duplicated entries (lowest index wins), empty
 sub-fingerprints, 11 pairs; the per-entry scores (float bit patterns) and the top-1 against
 oracle/lbad_oracle.c:lbo_corpus_best_ragged; every fifth trial also through save / load and the sharded entry point."""
 import os, sys, tempfile, time
@@ -19,7 +19,7 @@ bad = 0
 t0 = time.time()
 comm = lb.make_comm(0, 1)
 tmp = tempfile.mkdtemp()
-modes = {"A": 0, "B": 0, "mixed": 0, "long": 0}
+modes = {"short (systolic kernel)": 0, "A only": 0, "B only": 0, "A and B": 0}
 
 
 def rand_fp(n, L, p_zero, p_both):
@@ -67,7 +67,7 @@ for t in range(trials):
         q ^= flip.astype(np.uint8)
     rg = int(rng.choice([0, 1, 2, L // 2 + 1, L, L + 7]))
     look = min(nq, int(counts.max())) - 1
-    modes["long" if look >= 64 else "A" if counts.min() > nq else "B" if counts.max() <= nq else "mixed"] += 1
+    modes["short (systolic kernel)" if look <= 14 else "A only" if counts.min() > nq else "B only" if counts.max() <= nq else "A and B"] += 1
     corpus = lb.Corpus.ragged(L, n + 1, int(counts.sum()) + 200)
     flat = np.concatenate(entries, axis=0)
     packed = np.stack([lb.pack_subfingerprint(r) for r in flat]).view(np.uint8).reshape(-1, 32)
@@ -95,5 +95,5 @@ for t in range(trials):
         bad += 1
         wrong = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
         print("RAGGED MISMATCH", t, L, n, shape, nq, rg, look, top, (bi, bs), wrong[:5], lens[wrong[:5]], flush=True)
-print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.1f} s; chunks by kind {modes}")
+print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.1f} s; corpora by kernel path {modes}")
 sys.exit(1 if bad else 0)

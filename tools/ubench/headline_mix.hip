@@ -1,4 +1,4 @@
-// Micro-kernel for DESIGN.md section 4.1 "route (b)": does a THIRD wave per SIMD pay for the instructions it costs?
+// Micro-kernel for HISTORY.md (rounds 1-3 text) section 4.1 "route (b)": does a THIRD wave per SIMD pay for the instructions it costs?
 //
 // frame_rows_pruned_kernel (k_rows_pruned.hip) issues, per wave and unit of 8 windows, 629 packed (v_pk_fma / v_pk_add /
 // v_pk_mul) + 192 plain VALU + 150 LDS instructions from ~240 VGPRs: two waves per SIMD.  The 16-lanes-per-window
