@@ -214,8 +214,11 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
 // (Round 4, first version: one output per thread, i.e. 3 KB of weights per output through L2 -- 4.9 GB per sixty files,
 // the whole kernel time.)  Per tap and output: one LDS read, a conversion, a multiplication, an addition, in the tap
 // order of resample(); products of taps outside the file are w * (+0.0), which leaves the sum as it is (never -0.0).
-constexpr int kPeriods = 3;
-constexpr int kInStride = kInMax + kInMax / 64 + 1;
+#ifndef LBAD_RS_PERIODS
+#define LBAD_RS_PERIODS 3
+#endif
+constexpr int kPeriods = LBAD_RS_PERIODS;
+constexpr int kInStride = kInMax + kInMax / 32 + 1;     // one pad word per 32 samples: lanes 8 samples apart, 32 lanes, 32 distinct banks
 
 __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __restrict__ in, float* __restrict__ out,
                                               float (*s_in)[kInStride]) {
@@ -244,7 +247,7 @@ __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __
             if (staged[k]) {
                 for (long p = threadIdx.x; p <= kend - kbase[k]; p += kThreads) {
                     const long kk = kbase[k] + p;
-                    s_in[k][p + (p >> 6)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
+                    s_in[k][p + (p >> 5)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
                 }
             }
         }
@@ -273,7 +276,7 @@ __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __
                 const double wv = *w;
 #pragma unroll
                 for (int k = 0; k < kPeriods; ++k) {
-                    acc[k] += wv * (double)s_in[k][q[k] + (q[k] >> 6)];
+                    acc[k] += wv * (double)s_in[k][q[k] + (q[k] >> 5)];
                     ++q[k];
                 }
             }
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void resample_batch_kernel(const FileDesc
                                                                   int res, const double* __restrict__ table, uint64_t table_n,
                                                                   float* __restrict__ pcm) {
     // one block of LDS, two uses: the tiled path's table rows + one staged input range, or the rational path's kPeriods ranges
-    constexpr size_t kTiledBytes = sizeof(double) * kTapGroup * kRowLen + sizeof(float) * kInStride;
+    constexpr size_t kTiledBytes = sizeof(double) * kTapGroup * kRowLen + sizeof(float) * (kInMax + kInMax / 64 + 1);
     constexpr size_t kRationalBytes = sizeof(float) * kPeriods * kInStride;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kTiledBytes > kRationalBytes ? kTiledBytes : kRationalBytes];
     __shared__ uint32_t s_lo[kTapGroup];
