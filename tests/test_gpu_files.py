@@ -36,6 +36,46 @@ def test_device_front_end_equals_oracle_on_every_fixture(lb, gpu, oracle):
     assert np.array_equal(d3.convert_audio_url(_all_birds()[3])[0], oracle.resample(x, 44100.0, 48000.0, 0))
 
 
+def test_ima4_payload_at_an_odd_file_offset_and_stereo(lb, gpu, oracle, tmp_path):
+    """The IMA4 decoder reads a packet as 16-bit words when it may (round 4): a `free` chunk of odd length in front of the
+    data chunk puts every packet at an odd address (the byte path), and a two-channel file whose packets interleave goes
+    through the accumulate-and-average branch.  Decoded samples, converted samples and fingerprints equal the oracle's."""
+    import struct
+    src = open(os.path.join(BIRDS, "BlackBird.caf"), "rb").read()
+    at, chunks = 8, []
+    while at + 12 <= len(src):
+        size = struct.unpack(">q", src[at + 4:at + 12])[0]
+        ln = len(src) - (at + 12) if size < 0 else size
+        chunks.append((src[at:at + 4], src[at + 12:at + 12 + ln]))
+        at += 12 + ln
+    def build(pad, stereo):
+        out = src[:8]
+        for tag, body in chunks:
+            if tag == b"desc" and stereo:                     # same packets, declared as the two channels of a stereo file
+                rate, fourcc, flags, bpp, fpp, ch, bits = struct.unpack(">d4sIIIII", body)
+                body = struct.pack(">d4sIIIII", rate, fourcc, flags, 2 * bpp, fpp, 2, bits)
+            if tag == b"pakt" and stereo:
+                n_packets, n_frames, prime, remain = struct.unpack(">qqii", body[:24])
+                body = struct.pack(">qqii", n_packets // 2, (n_packets // 2) * 64, 0, 0) + body[24:]
+            if tag == b"data":
+                out += b"free" + struct.pack(">q", pad) + bytes(pad)
+                if stereo:
+                    body = body[:4] + body[4:4 + ((len(body) - 4) // 68) * 68]
+            out += tag + struct.pack(">q", len(body)) + body
+        return out
+    det = lb.Detective()
+    for name, pad, stereo in (("odd.caf", 7, False), ("even.caf", 8, False), ("odd_stereo.caf", 5, True)):
+        path = str(tmp_path / name)
+        open(path, "wb").write(build(pad, stereo))
+        x, rate = oracle.decode_audio_file(path)
+        d44 = lb.Detective().configure(sample_rate=rate)
+        assert np.array_equal(d44.convert_audio_url(path)[0], x), name            # the decoded samples themselves
+        got, frames, frate = det.convert_audio_url(path)
+        assert frames == x.size and frate == rate
+        assert np.array_equal(got, oracle.resample(x, rate, 5512.0, 0)), name
+        assert np.array_equal(det.process_audio_url(path).to_bools(), oracle.fingerprint_file(path, oracle.Config(), 1, 1, 0)), name
+
+
 @pytest.mark.parametrize("hop_mode,tail_mode", [(1, 1), (1, 0), (1, 2), (0, 1)])
 def test_batch_of_all_fixtures_equals_single_calls_and_oracle(lb, gpu, oracle, hop_mode, tail_mode):
     """LBAudioDetectiveProcessAudioURLs on the sixty fixtures at once == sixty LBAudioDetectiveProcessAudioURL calls
