@@ -351,12 +351,16 @@ OSStatus LBAudioDetectiveFramesToSubfingerprintsDevice(LBAudioDetectiveRef inDet
                                                        void* inStream);
 /* Round 4: where more than half of the bands are structurally empty (a band whose bin range is empty is +0.0 in every
  * window: 17 of the 32 bands at 44.1 kHz / 1024-sample windows) and only one of bands 0..15 is live, the two kernels
- * exchange COMPACT frames -- LBAD_COMPACT_FRAME_FLOATS floats: 128 rows of bands 16..31, then the 128 means of that one
- * band -- and stage 2 runs a sparse form with the same results.  GetCompactLayout: noErr and the live left band (32: none)
- * / the number of columns of the row transform that can be non-zero, or ArgumentInvalid when the configuration has no such
- * layout.  CompactFramesToSubfingerprintsDevice: the sparse stage 2 alone (tests, fuzzers). */
+ * exchange COMPACT frames -- 128 rows of ONLY the bands that can be non-zero: the live ones of bands 16..31 in ascending
+ * order, then that one band (15 floats per row instead of 32 at 44.1 kHz / 1024; never more than 17, hence
+ * LBAD_COMPACT_FRAME_FLOATS as an upper bound for buffers) -- and stage 2 runs a sparse form with the same results.
+ * GetCompactLayout: noErr and the live left band (32: none) / the number of columns of the row transform that can be
+ * non-zero, or ArgumentInvalid when the configuration has no such layout.  GetCompactBands: which bands a row holds, in
+ * the order they are stored (outBands may be NULL; *outCount <= 17): a frame is 128 x *outCount floats.
+ * CompactFramesToSubfingerprintsDevice: the sparse stage 2 alone on such frames (tests, fuzzers). */
 #define LBAD_COMPACT_FRAME_FLOATS 2176
 OSStatus LBAudioDetectiveGetCompactLayout(LBAudioDetectiveRef inDetective, UInt32* outLeftBand, UInt32* outLiveColumns);
+OSStatus LBAudioDetectiveGetCompactBands(LBAudioDetectiveRef inDetective, UInt32* outBands, UInt32* outCount);
 OSStatus LBAudioDetectiveCompactFramesToSubfingerprintsDevice(LBAudioDetectiveRef inDetective, const Float32* inFrames,
                                                               UInt64 inNumberOfFrames, void* outPacked,
                                                               Float32* outFramesHaar, void* inStream);

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "LBAudioDetectiveFingerprintClipsDeviceFormat": (OSStatus, [Ref, C.c_void_p, UInt32, UInt64, UInt64, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveSetFilePipeline": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveGetCompactLayout": (OSStatus, [Ref, _P(UInt32), _P(UInt32)]),
+    "LBAudioDetectiveGetCompactBands": (OSStatus, [Ref, _P(UInt32), _P(UInt32)]),
     "LBAudioDetectiveCompactFramesToSubfingerprintsDevice": (OSStatus, [Ref, C.c_void_p, UInt64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveFramesToSubfingerprintsDevice": (OSStatus, [Ref, C.c_void_p, UInt64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "LBAudioDetectiveStreamNew": (Ref, [Ref]),

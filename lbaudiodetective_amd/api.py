@@ -420,10 +420,17 @@ def compact_layout(det: "Detective"):
     return (int(left.value), int(cols.value)) if st == 0 else None
 
 
+def compact_bands(det: "Detective"):
+    """The bands a row of a compact inter-stage frame holds, in storage order (LBAudioDetectiveGetCompactBands), or None."""
+    bands, count = (N.UInt32 * 17)(), N.UInt32(0)
+    st = N.lib().LBAudioDetectiveGetCompactBands(det._ref, bands, C.byref(count))
+    return [int(bands[i]) for i in range(count.value)] if st == 0 else None
+
+
 def frames_to_subfingerprints_device(det: "Detective", frames, want_haar: bool = False, stream=None, compact: bool = False):
     """Stage 2 alone on torch frames [n, 128, bands] float32 (cuda) -> packed uint8 [n, 32] (and the Haar frames).
     compact: through the SPARSE form -- the frames (whose structurally empty bands must be zero) are packed into the
-    compact layout first (128 rows of bands 16..31, then the live left band's 128 means)."""
+    compact layout first (128 rows of the bands that can be non-zero)."""
     import torch
     assert frames.is_cuda and frames.dtype == torch.float32 and frames.is_contiguous()
     n = frames.shape[0]
@@ -433,8 +440,7 @@ def frames_to_subfingerprints_device(det: "Detective", frames, want_haar: bool =
         lay = compact_layout(det)
         if lay is None:
             raise LBAudioDetectiveError(1, "this configuration has no compact frame layout")
-        left = frames[:, :, lay[0]] if lay[0] < 32 else torch.zeros((n, 128), dtype=torch.float32, device=frames.device)
-        cf = torch.cat([frames[:, :, 16:32].reshape(n, 128 * 16), left.reshape(n, 128)], dim=1).contiguous()
+        cf = frames[:, :, compact_bands(det)].contiguous()          # [n, 128, stored bands]
         _check(N.lib().LBAudioDetectiveCompactFramesToSubfingerprintsDevice(det._ref, cf.data_ptr(), n, out.data_ptr(),
                                                                             haar.data_ptr() if want_haar else None, _stream_ptr(stream)),
                "CompactFramesToSubfingerprintsDevice")

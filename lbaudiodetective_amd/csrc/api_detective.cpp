@@ -94,9 +94,9 @@ OSStatus ensure_plan(LBAudioDetective* d) {
         tbl[3 * p.bands + b] = p.bands;
         tbl[4 * p.bands + b] = b;
         uint32_t mult = 0, off = 0xFFFFFFFFu;
-        if (p.sparse.ok) {
-            if (b >= 16) { mult = 16; off = b - 16; }
-            else if (b == p.sparse.left) { mult = 1; off = 128 * 16; }
+        if (p.sparse.ok) {               // rows of the n_stored bands that can be non-zero; an empty band is not stored
+            const uint32_t pos = b >= 16 ? p.sparse.pos_right[b - 16] : (b == p.sparse.left ? p.sparse.pos_left : 0xFFu);
+            if (pos != 0xFFu) { mult = p.sparse.n_stored; off = pos; }
         }
         tbl[5 * p.bands + b] = mult;
         tbl[6 * p.bands + b] = off;
@@ -599,8 +599,8 @@ OSStatus LBAudioDetectiveFramesToSubfingerprintsDevice(LBAudioDetectiveRef d, co
 }
 
 // The sparse form of stage 2 alone, on compact frames (what the pruned stage 1 writes when more than half of the bands are
-// structurally empty): LBAD_COMPACT_FRAME_FLOATS floats per frame -- 128 rows of bands 16..31, then the 128 means of the one
-// live band among bands 0..15 (*outLeftBand of LBAudioDetectiveGetCompactLayout; 32: none).  ArgumentInvalid when the
+// structurally empty): per frame 128 rows of the bands that can be non-zero (LBAudioDetectiveGetCompactBands: which, in
+// the order they are stored; at most 17, hence LBAD_COMPACT_FRAME_FLOATS as an upper bound).  ArgumentInvalid when the
 // configuration has no such layout.  For tests and fuzzers: the batch entry points choose the layout themselves.
 OSStatus LBAudioDetectiveGetCompactLayout(LBAudioDetectiveRef d, UInt32* outLeftBand, UInt32* outLiveColumns) {
     LBAD_LOCK(d);
@@ -610,6 +610,18 @@ OSStatus LBAudioDetectiveGetCompactLayout(LBAudioDetectiveRef d, UInt32* outLeft
     if (!d->plan.sparse.ok || !lbad::haar_select32_supported(d->plan)) return kLBAudioDetectiveArgumentInvalid;
     if (outLeftBand) *outLeftBand = d->plan.sparse.left;
     if (outLiveColumns) *outLiveColumns = d->plan.sparse.n_cols;
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveGetCompactBands(LBAudioDetectiveRef d, UInt32* outBands, UInt32* outCount) {
+    LBAD_LOCK(d);
+    if (!d || !outCount) return kLBAudioDetectiveArgumentInvalid;
+    OSStatus st = ensure_plan(d);
+    if (st != noErr) return st;
+    if (!d->plan.sparse.ok || !lbad::haar_select32_supported(d->plan)) return kLBAudioDetectiveArgumentInvalid;
+    *outCount = d->plan.sparse.n_stored;
+    if (outBands)
+        for (uint32_t i = 0; i < d->plan.sparse.n_stored; ++i) outBands[i] = d->plan.sparse.stored[i];
     return noErr;
 }
 

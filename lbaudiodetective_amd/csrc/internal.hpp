@@ -18,7 +18,7 @@ namespace lbad {
 constexpr uint32_t kRowsPerFrame = 128;  // LBAudioDetective.m:25
 constexpr uint32_t kPackedWords = LBAD_PACKED_WORDS;
 constexpr uint32_t kMaxBands = 64;
-constexpr uint32_t kSparseFrameDw = 128 * 16 + 128;   // a compact frame (Plan::Sparse): 128 rows of 16 floats, then 128 floats
+constexpr uint32_t kSparseFrameDwMax = 128 * 17;       // the largest compact frame (Plan::Sparse): 128 rows of at most 16 + 1 stored bands
 constexpr uint32_t kMinWindow = 16;
 constexpr uint32_t kMaxWindow = 8192;
 
@@ -88,7 +88,8 @@ struct Plan {
     uint32_t* d_claim = nullptr;  // its per-XCD claim counters (8 words)
     // Structurally empty bands (round 4): a band whose bin range is empty is +0.0 in every window (17 of the 32
     // bands at 44.1 kHz / 1024).  `sparse.ok`: 32 bands and at most ONE live band among the left sixteen -- stage 1 then
-    // writes compact frames (kSparseFrameDw floats: 128 rows of the right sixteen bands, then the left band's 128 means)
+    // writes compact frames (128 rows of the `n_stored` bands that can be non-zero: the live ones of the right sixteen in
+    // ascending order, then the left half's one live band)
     // and stage 2 runs its sparse form (k_haar_select32.hip): one thread per row, and only the columns of the row
     // transform that can be non-zero go through the column transform and the select.
     struct Sparse {
@@ -96,6 +97,11 @@ struct Plan {
         uint32_t left = 32;            // the live band of the left half (32: none)
         uint32_t n_cols = 0;           // columns of the row transform's output that can be non-zero ...
         uint8_t cols[32] = {};         // ... in ascending ordered position
+        uint32_t n_stored = 0;         // bands a compact frame's row holds
+        uint8_t stored[17] = {};       // ... which ones, by position in the row
+        uint8_t pos_right[16];         // position of band 16 + j in the row (0xFF: structurally empty, not stored)
+        uint8_t pos_left = 0xFF;       // position of the left half's live band
+        uint32_t frame_dw() const { return 128u * n_stored; }
     } sparse;
     // measurement knobs of the generic stage-1 kernel (LBAudioDetectiveSetKernelTuning): waves per workgroup
     // (0 = automatic) and whether the per-lane twiddle cache is used

@@ -406,7 +406,8 @@ __device__ __forceinline__ float cross_levels(float cur, int h, float root2, boo
 //     and a zero never sets a Boolean (its sign code is 0) nor changes the rank of a non-zero coefficient (every non-zero
 //     key is larger), whether it would have been selected or not -- frames with fewer than `keep` non-zero coefficients
 //     included (tests/test_gpu_parity.py::test_stage2_corner_frames runs them through both forms);
-//   * input: the compact frame stage 1 writes for such a plan (kSparseFrameDw floats), half of the bytes;
+//   * input: the compact frame stage 1 writes for such a plan (128 rows of the bands that can be non-zero: 15 of 32 at
+//     44.1 kHz / 1024), less than half of the bytes;
 //   * a workgroup is THREE waves (192 threads: 128 rows, up to 24 column slots of 8 threads) with 15 KB of transposed
 //     coefficients instead of 20: nine workgroups fit a CU where the general form has seven.  That, not the smaller
 //     instruction count, is what the sparse form returns: the kernel is bound by the life time of a workgroup (a chain
@@ -415,6 +416,9 @@ __device__ __forceinline__ float cross_levels(float cur, int h, float root2, boo
 // Every value that is computed is computed by the same operations on the same operands as in the general form.
 struct SparseArgs {
     uint32_t left, n_cols;
+    uint32_t row_dw;               // bands a compact frame's row holds (Plan::Sparse::n_stored); a frame is 128 such rows
+    uint32_t pos_left;             // position of the left half's live band in the row
+    uint32_t pos_right[4];         // 16 bytes: position of band 16 + j in the row (0xFF: structurally empty, not stored)
     uint32_t cols[8];              // 32 ordered positions, one byte each: the columns that can be non-zero, ascending
     uint32_t rank[8];              // ordered position -> its place in that list (0xFF: structurally zero), one byte each
 };
@@ -424,7 +428,15 @@ constexpr int kSparseCols = 21;    // column slots of the sparse form (every con
                                    // and 66 VGPRs: 140 -> 137 us)
 __device__ __forceinline__ uint32_t byte_of(const uint32_t (&tbl)[8], uint32_t i) { return (tbl[i >> 2] >> (8u * (i & 3u))) & 0xFFu; }
 
-template <int COLS, bool SPARSE>
+// RMASK (sparse form): the live bands of the right half as a compile-time mask (bit j: band 16 + j), with HAS_LEFT a live
+// band on the left -- the row of a compact frame is then read with 16-byte loads and unpacked by name.  RMASK = 0: the
+// positions come from the plan at run time (one 4-byte load per band: 146 us instead of 133 per 31 250 frames).
+constexpr uint32_t kRmask44k = 0xFFF5u;   // 44.1 kHz / 1024: bands 16, 18, 20..31
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int COLS, bool SPARSE, uint32_t RMASK = 0u, bool HAS_LEFT = false>
 __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? 8 : COLS == 64 ? 6 : 7) void haar_select32_kernel(const float* __restrict__ frames, uint32_t keep,
                                                                           uint32_t subfp_len, uint32_t* __restrict__ packed,
                                                                           float* __restrict__ haar_out, const SparseArgs sp) {
@@ -458,28 +470,63 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? 8 : COLS == 64 ? 
 #endif
     STAMP(0);
 
-    // the thread's sixteen frame values are asked for before anything else: the LDS set-up below runs while they travel
-    float4 pre[4];
+    // the thread's sixteen frame values are asked for before anything else: the LDS set-up below runs while they travel.
+    // Sparse form: the row of a compact frame holds only the bands that can be non-zero (sp.pos_right / sp.pos_left say
+    // where; the plan's positions are uniform, so every load has a scalar offset or is skipped), the others are +0.0 here
+    float pre[16];
     float pre_left = 0.0f;
-    {
-        const float4* src;
-        bool mine = true;
-        if constexpr (SPARSE) {
-            const int row = t < (int)kRowsPerFrame ? t : 0;
-            mine = t < (int)kRowsPerFrame;
-            src = reinterpret_cast<const float4*>(frames + frame * kSparseFrameDw + row * 16);
-            if (mine && sp.left < 32u) pre_left = frames[frame * kSparseFrameDw + kRowsPerFrame * 16 + row];
-        } else {
-            src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + (t / H) * kCols + 16 * (t % H));
-        }
-        if (mine) {
+    auto fetch_row = [&](float (&a)[16], float& left_value) {
+        if constexpr (SPARSE && RMASK != 0u) {
+            constexpr int kRight = __builtin_popcount(RMASK), kRow = kRight + (HAS_LEFT ? 1 : 0);
+            const bool mine = t < (int)kRowsPerFrame;
+            const float* rowp = frames + frame * (kRowsPerFrame * kRow) + (mine ? t : 0) * kRow;
+            float got[kRow + 3];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pre[q] = src[q];
-        } else {
+            for (int q = 0; q + 4 <= kRow; q += 4) {
+                const f4u v = *reinterpret_cast<const f4u*>(rowp + q);
+                got[q] = v.x; got[q + 1] = v.y; got[q + 2] = v.z; got[q + 3] = v.w;
+            }
+            constexpr int kDone = kRow & ~3;
+            if constexpr (kRow - kDone == 3) {
+                const f3u v = *reinterpret_cast<const f3u*>(rowp + kDone);
+                got[kDone] = v.x; got[kDone + 1] = v.y; got[kDone + 2] = v.z;
+            } else if constexpr (kRow - kDone == 2) {
+                const f2u v = *reinterpret_cast<const f2u*>(rowp + kDone);
+                got[kDone] = v.x; got[kDone + 1] = v.y;
+            } else if constexpr (kRow - kDone == 1) {
+                got[kDone] = rowp[kDone];
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pre[q] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int jj = 0; jj < 16; ++jj)
+                a[jj] = ((RMASK >> jj) & 1u) ? got[__builtin_popcount(RMASK & ((1u << jj) - 1u))] : 0.0f;
+            left_value = HAS_LEFT ? got[kRight] : 0.0f;
+        } else if constexpr (SPARSE) {
+            const bool mine = t < (int)kRowsPerFrame;
+            const float* rowp = frames + frame * (kRowsPerFrame * sp.row_dw) + (mine ? t : 0) * sp.row_dw;
+            // branch-free: an empty band reads the row's first float and drops it (sixteen loads in flight together)
+            float got[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const uint32_t pos = (sp.pos_right[jj >> 2] >> (8 * (jj & 3))) & 0xFFu;     // (uniform)
+                got[jj] = rowp[pos != 0xFFu ? pos : 0u];
+            }
+            const float got_left = rowp[sp.left < 32u ? sp.pos_left : 0u];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const uint32_t pos = (sp.pos_right[jj >> 2] >> (8 * (jj & 3))) & 0xFFu;
+                a[jj] = pos != 0xFFu ? got[jj] : 0.0f;
+            }
+            left_value = sp.left < 32u ? got_left : 0.0f;
+        } else {
+            const float4* src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + (t / H) * kCols + 16 * (t % H));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = src[q];
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
         }
-    }
+    };
+    fetch_row(pre, pre_left);
     bool first_read = true;
 
     if (t < (int)kPackedWords) s_bits[t] = 0;
@@ -497,14 +544,14 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? 8 : COLS == 64 ? 
     if constexpr (SPARSE) {
         if (t < (int)kRowsPerFrame) {
             const int row = t;
-            const float* fr = frames + frame * kSparseFrameDw;
-            const float4* src = reinterpret_cast<const float4*>(fr + row * 16);
             float d[15];
             auto load = [&](float (&a)[16]) {       // the first call takes what was fetched at the top, a redo reads again
+                if (first_read) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 v = first_read ? pre[q] : src[q];
-                    a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+                    for (int jj = 0; jj < 16; ++jj) a[jj] = pre[jj];
+                } else {
+                    float again;
+                    fetch_row(a, again);
                 }
                 first_read = false;
             };
@@ -583,13 +630,14 @@ __global__ __launch_bounds__(SPARSE ? 192 : COLS * 8, SPARSE ? 8 : COLS == 64 ? 
     // ---- row pass: thread = (row, sixteenth h of the row) ------------------------------------------------
     {
         const int row = t / H, h = t % H;
-        const float4* src = reinterpret_cast<const float4*>(frames + frame * (kRowsPerFrame * kCols) + row * kCols + 16 * h);
         float d[15];
         auto load = [&](float (&a)[16]) {
+            if (first_read) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v = first_read ? pre[q] : src[q];
-                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+                for (int jj = 0; jj < 16; ++jj) a[jj] = pre[jj];
+            } else {
+                float unused;
+                fetch_row(a, unused);
             }
             first_read = false;
         };
@@ -942,14 +990,24 @@ hipError_t launch_haar_select32(const Plan& plan, const float* d_frames, uint64_
         if (plan.sparse.n_cols > (uint32_t)kSparseCols) return hipErrorInvalidValue;
         sp.left = plan.sparse.left;
         sp.n_cols = plan.sparse.n_cols;
+        sp.row_dw = plan.sparse.n_stored;
+        sp.pos_left = plan.sparse.pos_left;
+        for (uint32_t j = 0; j < 16; ++j) sp.pos_right[j >> 2] |= (uint32_t)plan.sparse.pos_right[j] << (8u * (j & 3u));
         for (uint32_t i = 0; i < 8; ++i) sp.rank[i] = 0xFFFFFFFFu;
         for (uint32_t c = 0; c < 32; ++c) sp.cols[c >> 2] |= (uint32_t)plan.sparse.cols[c] << (8u * (c & 3u));
         for (uint32_t c = 0; c < plan.sparse.n_cols; ++c) {
             const uint32_t pos = plan.sparse.cols[c];
             sp.rank[pos >> 2] = (sp.rank[pos >> 2] & ~(0xFFu << (8u * (pos & 3u)))) | (c << (8u * (pos & 3u)));
         }
-        hipLaunchKernelGGL((haar_select32_kernel<32, true>), dim3((uint32_t)n_frames), dim3(192), 0, stream, d_frames, plan.keep,
-                           plan.subfp_len, d_packed, d_haar_out, sp);
+        uint32_t rmask = 0;
+        for (uint32_t j = 0; j < 16; ++j)
+            if (plan.sparse.pos_right[j] != 0xFF) rmask |= 1u << j;
+        if (rmask == kRmask44k && plan.sparse.left < 32)
+            hipLaunchKernelGGL((haar_select32_kernel<32, true, kRmask44k, true>), dim3((uint32_t)n_frames), dim3(192), 0, stream, d_frames,
+                               plan.keep, plan.subfp_len, d_packed, d_haar_out, sp);
+        else
+            hipLaunchKernelGGL((haar_select32_kernel<32, true>), dim3((uint32_t)n_frames), dim3(192), 0, stream, d_frames, plan.keep,
+                               plan.subfp_len, d_packed, d_haar_out, sp);
         return hipGetLastError();
     }
     if (plan.bands == 16)

@@ -224,8 +224,8 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
     const uint32_t b_lo = band_tbl[band], b_hi = band_tbl[kBands + band];
     const float b_div = __uint_as_float(band_tbl[2 * kBands + band]);
     // where the band's mean of row w goes inside a frame of frame_dw floats: w * b_mult + b_off -- rows of 32 bands, or
-    // the compact frame of plan.sparse (128 rows of the right sixteen bands, then the 128 means of the one live band of
-    // the left half; b_off = 0xFFFFFFFF: a band that is +0.0 in every window and that nobody reads)
+    // the compact frame of plan.sparse (128 rows of the bands that can be non-zero; b_off = 0xFFFFFFFF: a band that is +0.0
+    // in every window and that nobody reads)
     const uint32_t b_mult = band_tbl[place_tbl * kBands + band], b_off = band_tbl[(place_tbl + 1) * kBands + band];
 
     const int w8 = lane >> 3, r = lane & 7;
@@ -450,7 +450,7 @@ static hipError_t launch_rows_fmt(const Plan& plan, const float* d_bin_const, co
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(frame_rows_pruned_kernel<FMT>, dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), kLdsBytes,
                        stream, d_pcm, samples_per_clip, frames_per_clip, n_units, units_per_xcd, d_bin_const,
-                       plan.d_bands, claim, d_frames, compact ? kSparseFrameDw : 128u * kBands, compact ? 5u : 3u);
+                       plan.d_bands, claim, d_frames, compact ? plan.sparse.frame_dw() : 128u * kBands, compact ? 5u : 3u);
     return hipGetLastError();
 }
 

@@ -146,6 +146,13 @@ void plan_sparse(Plan& plan) {
     for (uint32_t c = 0; c < 32; ++c)
         if (out[c]) sp.cols[sp.n_cols++] = (uint8_t)c;
     if (sp.n_cols == 0 || sp.n_cols > 21) return;   // nothing is ever read / more columns than the sparse stage 2 has slots for (k_haar_select32.hip: kSparseCols)
+    // what a compact frame's row holds: the live bands of the right half in ascending order, then the left half's live band
+    for (uint32_t j = 0; j < 16; ++j) {
+        sp.pos_right[j] = 0xFF;
+        if (live[16 + j]) { sp.pos_right[j] = (uint8_t)sp.n_stored; sp.stored[sp.n_stored++] = (uint8_t)(16 + j); }
+    }
+    if (sp.left < 32) { sp.pos_left = (uint8_t)sp.n_stored; sp.stored[sp.n_stored++] = (uint8_t)sp.left; }
+    if (sp.n_stored == 0) return;
     sp.ok = true;
     plan.sparse = sp;
 }
