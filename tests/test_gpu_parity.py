@@ -918,7 +918,7 @@ def test_stage2_sparse_form_on_every_configuration_that_has_one(lb, gpu, oracle)
 
 @pytest.mark.parametrize("keep_len", [200, 31, 256])
 def test_stage2_sparse_form_on_corner_frames(lb, gpu, oracle, keep_len):
-    """The sparse form of stage 2 (compact frames: bands 16..31 plus the one live band of the left half -- what 44.1 kHz /
+    """The sparse form of stage 2 (compact frames: only the bands that can be non-zero, 15 of 32 -- what 44.1 kHz /
     1024 produces) against the oracle on the corner frames, masked to that structure: division-shortcut tiers,
     plateaus, inf / NaN, and -- the tie rule the sparse form must keep -- frames with FEWER non-zero coefficients than are
     kept (digital silence in all but a few rows; a single non-zero value; nothing at all).  Bits and Haar frames equal the
