@@ -34,8 +34,9 @@ __device__ __forceinline__ unsigned long long make_key(float score, uint64_t glo
            (unsigned long long)(0xFFFFFFFFu - (uint32_t)global_index);
 }
 
+template <int WAVES = kThreads / 64>
 __device__ __forceinline__ void block_max_key(unsigned long long k, unsigned long long* out) {
-    __shared__ unsigned long long s_k[kThreads / 64];
+    __shared__ unsigned long long s_k[WAVES];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(k, off, 64);
@@ -45,7 +46,7 @@ __device__ __forceinline__ void block_max_key(unsigned long long k, unsigned lon
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long m = s_k[0];
-        for (int i = 1; i < kThreads / 64; ++i) m = s_k[i] > m ? s_k[i] : m;
+        for (int i = 1; i < WAVES; ++i) m = s_k[i] > m ? s_k[i] : m;
         if (m) atomicMax(out, m);
     }
 }
@@ -63,8 +64,9 @@ struct ScanFinish {
     unsigned long long seq;
 };
 
+template <int WAVES = kThreads / 64>
 __device__ __forceinline__ unsigned long long block_reduce_max(unsigned long long k) {
-    __shared__ unsigned long long s_m[kThreads / 64];
+    __shared__ unsigned long long s_m[WAVES];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(k, off, 64);
@@ -75,17 +77,18 @@ __device__ __forceinline__ unsigned long long block_reduce_max(unsigned long lon
     __syncthreads();
     unsigned long long m = s_m[0];
 #pragma unroll
-    for (int i = 1; i < kThreads / 64; ++i) m = s_m[i] > m ? s_m[i] : m;
+    for (int i = 1; i < WAVES; ++i) m = s_m[i] > m ? s_m[i] : m;
     return m;
 }
 
+template <int WAVES = kThreads / 64>
 __device__ __forceinline__ void block_max_key_finish(unsigned long long k, unsigned long long* out, const ScanFinish fin) {
     if (fin.ticket == nullptr) {
-        block_max_key(k, out);
+        block_max_key<WAVES>(k, out);
         return;
     }
     __shared__ unsigned int s_last;
-    const unsigned long long m = block_reduce_max(k);
+    const unsigned long long m = block_reduce_max<WAVES>(k);
     if (threadIdx.x == 0) {
         __hip_atomic_store(&fin.block_keys[blockIdx.x], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();                                    // the slot before the ticket
@@ -95,11 +98,11 @@ __device__ __forceinline__ void block_max_key_finish(unsigned long long k, unsig
     if (s_last) {
         __threadfence();
         unsigned long long best = 0ull;
-        for (uint32_t b = threadIdx.x; b < gridDim.x; b += kThreads) {
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += 64 * WAVES) {
             const unsigned long long v = __hip_atomic_load(&fin.block_keys[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             best = v > best ? v : best;
         }
-        best = block_reduce_max(best);
+        best = block_reduce_max<WAVES>(best);
         if (threadIdx.x == 0) {
             fin.host_out[0] = best;
             __threadfence_system();
@@ -312,16 +315,30 @@ struct PlaneQueryArg {
     uint32_t w[kPlaneQueryWords];
 };
 
+// The single-query scan runs ONE workgroup of 1024 threads per CU: with 256 threads a CU had four waves and eight 16-byte
+// loads each in flight, and a million entries (15 trips per thread) took 26.3 us of mostly exposed latency; sixteen waves
+// per CU: 23.3 us = 5.4 TB/s of the Infinity Cache (10 M entries: 217 us either way, tools/exp/query_latency.py).
+#ifndef LBAD_PLANE_THREADS
+#define LBAD_PLANE_THREADS 1024
+#endif
+#ifndef LBAD_PLANE_WG_SMALL
+#define LBAD_PLANE_WG_SMALL 256
+#endif
+#ifndef LBAD_PLANE_WG_LARGE
+#define LBAD_PLANE_WG_LARGE 256
+#endif
+constexpr int kPlaneThreads = LBAD_PLANE_THREADS;      // the single-query scan
+
 template <int NSUB>
-__global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* __restrict__ planes, uint64_t stride,
+__global__ __launch_bounds__(kPlaneThreads) void compare_planes_kernel(const uint4* __restrict__ planes, uint64_t stride,
                                                                   uint64_t n_entries, const PlaneQueryArg qc,
                                                                   uint64_t index_base, float* __restrict__ scores,
                                                                   unsigned long long* __restrict__ key_out,
                                                                   const ScanFinish fin) {
     using S = PlaneShape<NSUB>;
     unsigned long long best = 0ull;
-    for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
-         e += (uint64_t)gridDim.x * kThreads) {
+    for (uint64_t e = (uint64_t)blockIdx.x * kPlaneThreads + threadIdx.x; e < n_entries;
+         e += (uint64_t)gridDim.x * kPlaneThreads) {
         uint32_t y[S::planes * 4];
 #pragma unroll
         for (uint32_t p = 0; p < S::planes; ++p) {
@@ -352,7 +369,7 @@ __global__ __launch_bounds__(kThreads) void compare_planes_kernel(const uint4* _
         const unsigned long long k = make_key(match, index_base + e);
         best = k > best ? k : best;
     }
-    block_max_key_finish(best, key_out, fin);
+    block_max_key_finish<kPlaneThreads / 64>(best, key_out, fin);
 }
 
 // Batch form: up to QB queries share one pass over the corpus (the scan is HBM-bound, so a handful of
@@ -429,7 +446,10 @@ hipError_t launch_planes_n(const uint4* d_planes, uint64_t stride, uint64_t n_en
     PlaneQueryArg arg;
     std::memset(&arg, 0, sizeof(arg));
     std::memcpy(arg.w, h_qc, PlaneShape<NSUB>::total * sizeof(uint32_t));
-    hipLaunchKernelGGL(compare_planes_kernel<NSUB>, dim3(grid_for(n_entries)), dim3(kThreads), 0, stream, d_planes,
+    const uint64_t blocks = (n_entries + kPlaneThreads - 1) / kPlaneThreads;
+    const uint64_t cap = n_entries <= (1ull << 21) ? (uint64_t)LBAD_PLANE_WG_SMALL : (uint64_t)LBAD_PLANE_WG_LARGE;
+    const uint32_t grid = (uint32_t)(blocks < cap ? (blocks ? blocks : 1) : cap);
+    hipLaunchKernelGGL(compare_planes_kernel<NSUB>, dim3(grid), dim3(kPlaneThreads), 0, stream, d_planes,
                        stride, n_entries, arg, index_base, d_scores, d_key, fin);
     return hipGetLastError();
 }

@@ -1,5 +1,7 @@
 """Latency of the corpus query paths for a given library build: python tools/exp/query_latency.py [lib.so ...]"""
 import sys, os, subprocess, json, time
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))))
 import lbaudiodetective_amd._native as N
 child = "--child" in sys.argv
 libs = [a for a in sys.argv[1:] if a != "--child"] or [N.LIB_PATH]
