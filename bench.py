@@ -353,18 +353,31 @@ def sliding_leg(args, torch, np):
     q[:, 1::2] = np.where(flip, pos, q[:, 1::2])
     fq = lb.Fingerprint.from_bools(q)
     key = torch.zeros(1, dtype=torch.int64, device="cuda")
-    for _ in range(3):
-        corpus.query_key_device(fq, key)
-    torch.cuda.synchronize()
-    reps = 50
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        corpus.query_key_device(fq, key)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    best = lb.Corpus.decode_key(int(key.item()) & (2**64 - 1))
+
+    def timed_scan(fp, reps=50):
+        for _ in range(3):
+            corpus.query_key_device(fp, key)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            corpus.query_key_device(fp, key)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, lb.Corpus.decode_key(int(key.item()) & (2**64 - 1))
+
+    # `scan_ms` and the roofline are the FULL scan: every sliding offset of every entry evaluated (bound pruning off).  The
+    # library's default for top-1 queries drops groups of offsets that cannot reach the best match published so far (exact;
+    # LBAudioDetectiveCorpusSetBoundPruning): reported beside it, with the planted match and with a query that matches nothing.
+    corpus.set_bound_pruning(False)
+    ms, best = timed_scan(fq)
+    corpus.set_bound_pruning(True)
+    ms_pruned, best_pruned = timed_scan(fq)
+    stranger = lb.Fingerprint.from_bools(O.synth_entry(CSEED ^ 0x5555, 123, nq, 200))
+    ms_stranger, best_stranger = timed_scan(stranger)
+    corpus.set_bound_pruning(False)
+    ms_stranger_full, best_stranger_full = timed_scan(stranger)
+    corpus.set_bound_pruning(True)
     t1 = time.perf_counter()
     for _ in range(20):
         api = corpus.query(fq)
@@ -385,6 +398,12 @@ def sliding_leg(args, torch, np):
                     f"({total} records, {32 * total / 1e9:.2f} GB in HBM), every sliding offset of every entry",
         "best_index": best[0], "best_score": best[1], "planted_index": PLANTED_1GPU, "found_planted": bool(best[0] == PLANTED_1GPU),
         "scan_ms": round(ms, 4), "query_latency_ms": round(lat_ms, 4),
+        "with_bound_pruning": {"what": "the library's default for top-1 queries: exact, data-dependent; query_latency_ms above runs with it",
+                               "scan_ms_planted_match": round(ms_pruned, 4), "same_result": bool(best_pruned == best),
+                               "scan_ms_query_that_matches_nothing": round(ms_stranger, 4),
+                               "full_scan_ms_query_that_matches_nothing": round(ms_stranger_full, 4),
+                               "same_result_no_match": bool(best_stranger == best_stranger_full),
+                               "best_score_no_match": best_stranger[1]},
         "subfingerprint_compares_per_s": round(nq * total / (ms * 1e-3), 1),
         "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel (k_sliding.hip, round 4: only the sliding offsets that "
                      "exist; 2 v_bitop3 + 1 v_bcnt per 32 sign pairs, 8 DPP moves per step of 4 pairs): integer VALU issue, not HBM",
@@ -398,14 +417,9 @@ def sliding_leg(args, torch, np):
     others = {}
     for n_other in (5, 48):
         qo = lb.Fingerprint.from_bools(O.synth_entry(CSEED, PLANTED_1GPU, max(int(counts[PLANTED_1GPU]), n_other), 200)[:n_other])
-        for _ in range(2):
-            corpus.query_key_device(qo, key)
-        e0.record()
-        for _ in range(20):
-            corpus.query_key_device(qo, key)
-        e1.record()
-        torch.cuda.synchronize()
-        mo = e0.elapsed_time(e1) / 20
+        corpus.set_bound_pruning(False)
+        mo, _ = timed_scan(qo, 20)
+        corpus.set_bound_pruning(True)
         others[f"query_of_{n_other}"] = {"scan_ms": round(mo, 4), "algorithmic_GBps": round(alg / (mo * 1e-3) / 1e9, 1),
                                          "layout_GBps": round(32 * total / (mo * 1e-3) / 1e9, 1)}
     out["other_query_lengths"] = others

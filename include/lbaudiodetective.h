@@ -451,6 +451,13 @@ OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef i
                                                      LBAudioDetectiveAllReduceMaxFn inAllReduce, void* inContext,
                                                      void* inStream, SInt64* outIndices, Float32* outScores);
 void LBAudioDetectiveSetExchangeTimeout(UInt32 inMilliseconds);
+
+/* Ragged corpora, top-1 queries (no per-entry scores asked for): a match of 0.7 or better found anywhere in the scan is
+ * published at once, and groups of sliding offsets whose sums can no longer reach it -- an upper bound: every remaining
+ * sub-fingerprint ratio counted as 1 -- are not finished.  Exact: nothing that could win or tie is dropped, the result is
+ * the full scan's (LBAudioDetectiveTests.m:57-91 keeps the best match only).  On by default; 0 switches it off (every
+ * offset of every entry is evaluated, as when scores are requested). */
+OSStatus LBAudioDetectiveCorpusSetBoundPruning(LBAudioDetectiveCorpusRef inCorpus, UInt32 inEnabled);
 /* the corpus' own key block of a sharded query (LBAD_SHARD_KEYS words on the device, and its pinned host twin) */
 unsigned long long* LBAudioDetectiveCorpusShardKeysDevice(LBAudioDetectiveCorpusRef inCorpus);
 unsigned long long* LBAudioDetectiveCorpusShardKeysHost(LBAudioDetectiveCorpusRef inCorpus);

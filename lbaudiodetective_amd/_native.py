@@ -145,6 +145,7 @@ _SIGNATURES = {
     "LBAudioDetectiveCorpusQueryBatchShardedWith": (OSStatus, [Ref, _P(Ref), UInt32, UInt32, UInt64, C.c_void_p, C.c_void_p,
                                                                C.c_void_p, _P(SInt64), _P(Float32)]),
     "LBAudioDetectiveSetExchangeTimeout": (None, [UInt32]),
+    "LBAudioDetectiveCorpusSetBoundPruning": (OSStatus, [Ref, UInt32]),
     "LBAudioDetectiveCorpusShardKeysDevice": (C.c_void_p, [Ref]),
     "LBAudioDetectiveCorpusShardKeysHost": (C.c_void_p, [Ref]),
     "LBAudioDetectiveCommGetUniqueId": (OSStatus, [C.c_void_p]),

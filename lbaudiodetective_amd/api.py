@@ -501,6 +501,12 @@ class Corpus:
             raise LBAudioDetectiveError(1, "CorpusNewRagged (unsupported length, zero capacity or no HIP device)")
         return cls(subfingerprint_length, 0, entry_capacity, _ref=ref)
 
+    def set_bound_pruning(self, enabled: bool):
+        """Ragged corpora, top-1 queries: drop groups of sliding offsets that cannot reach the best match found so far
+        (exact; on by default).  LBAudioDetectiveCorpusSetBoundPruning."""
+        _check(self._L.LBAudioDetectiveCorpusSetBoundPruning(self._ref, 1 if enabled else 0), "CorpusSetBoundPruning")
+        return self
+
     @property
     def subfingerprint_total(self) -> int:
         return int(self._L.LBAudioDetectiveCorpusGetSubfingerprintTotal(self._ref))

@@ -76,7 +76,7 @@ OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFinge
     }
     LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, (uint32_t)(c->rec_capacity + kRecordSlack / 2),
                                     tasks_a, tasks_b, sh, c->d_plan, c->subfp_len, dq, q->count, range, index_base,
-                                    reinterpret_cast<unsigned int*>(d_scores), key_dst, stream));
+                                    reinterpret_cast<unsigned int*>(d_scores), key_dst, stream, c->bound_pruning));
     if (!c->plan_used) LBAD_HIP(hipEventCreateWithFlags(&c->plan_used, hipEventDisableTiming));
     LBAD_HIP(hipEventRecord(c->plan_used, stream));
     // behind the SCAN, not just the copy: the slot's device half is read by the kernel, and the query that reuses the
@@ -692,6 +692,12 @@ OSStatus LBAudioDetectiveCorpusQuery(LBAudioDetectiveCorpusRef c, LBAudioDetecti
     if (st != noErr) return st;
     LBAD_HIP(hipMemcpy(&key, c->d_key, sizeof(key), hipMemcpyDeviceToHost));
     LBAudioDetectiveCorpusDecodeKey(key, outIndex, outScore);
+    return noErr;
+}
+
+OSStatus LBAudioDetectiveCorpusSetBoundPruning(LBAudioDetectiveCorpusRef c, UInt32 inEnabled) {
+    if (!c) return kLBAudioDetectiveArgumentInvalid;
+    c->bound_pruning = inEnabled != 0;
     return noErr;
 }
 

@@ -280,7 +280,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
                                   uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
                                   uint32_t subfp_len, const uint32_t* d_query, uint32_t n_query, uint32_t range,
                                   uint64_t index_base, unsigned int* d_score_bits, unsigned long long* d_key,
-                                  hipStream_t stream);
+                                  hipStream_t stream, bool bound_pruning = true);
 constexpr uint32_t kRecordSlack = 8;   // records allocated behind a ragged corpus' capacity (zero: over-read + the zero record)
 
 // measurement: ticks of the shader clock and of the constant 100 MHz clock over ~usec microseconds (2 words)
@@ -430,6 +430,7 @@ struct LBAudioDetectiveCorpus {
     // the scan's plan for ONE query length (k_sliding.hip): rebuilt when the length, the entries or the grid change
     uint32_t* d_plan = nullptr;
     uint32_t plan_nq = 0, plan_grid = 0;
+    bool bound_pruning = true;     // top-1 scans of a ragged corpus may drop passes that cannot reach the best match so far (exact)
     uint64_t plan_count = 0;
     hipEvent_t plan_built = nullptr;             // behind the plan's kernels, on plan_stream
     hipEvent_t plan_used = nullptr;              // behind the latest scan that read the plan

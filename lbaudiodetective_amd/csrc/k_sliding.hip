@@ -71,6 +71,7 @@ constexpr uint32_t kTriSize = (kTriPairs + 1) * (kTriPairs + 2) / 2;   // 5151 q
 constexpr uint32_t kQWords = 16;      // per query sub-fingerprint: P[4] N[4] NZ[4] tri-base possible - -
 constexpr uint32_t kQHeader = 16;     // words in front of the query (reserved, zero)
 constexpr uint32_t kSlots = 128;      // queue slots per wave (at most 63 left over + 64 new)
+constexpr float kPruneFrom = 0.7f;    // top-1 scans: matches from this score on are published and bound the passes that follow
 
 __device__ __forceinline__ unsigned long long sl_key(float score, uint64_t global_index) {
     return ((unsigned long long)__float_as_uint(score) << 32) |
@@ -93,6 +94,7 @@ struct SlideArgs {                // the scalars of a scan (the pointers are ker
     uint32_t zero_rec;            // index of an all-zero record
     uint32_t rm[4];               // RANGE over pair bits
     uint32_t dense_a, dense_b;    // entries that hold about 128 tasks of a kind (two passes): the least a wave claims
+    uint32_t prune;               // 1: a top-1 scan (no per-entry scores wanted) may drop passes that cannot reach the best match so far
 };
 
 struct SlidePtrs {
@@ -100,6 +102,7 @@ struct SlidePtrs {
     const uint32_t* __restrict__ off;      // n_entries + 1 record positions
     const uint32_t* __restrict__ q;        // the query, kQWords per sub-fingerprint
     unsigned int* score_bits;              // optional, per entry
+    unsigned long long* key_out;           // the scan's result word: also where a strong match is published while the scan runs
 };
 
 #ifdef LBAD_SLIDE_PROF
@@ -222,8 +225,12 @@ constexpr int kRing = LBAD_SLIDE_RING;        // record slots per lane: the 4 of
 // rather than from scalar registers: a vector instruction with a scalar operand issues at the slow rate on this chip
 // (v_bitop3_b32 1.85 ns against 1.13 ns per SIMD, tools/ubench/slide_rates.hip), and the step has 32 of them.
 template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
-__device__ __forceinline__ void run_pass(const SlideArgs& a, const uint4* __restrict__ recs, const uint32_t* __restrict__ q,
-                                         const uint32_t* s_q, const Task& t, const float* s_tri, float (&acc)[4]) {
+// stop_below (A passes of a top-1 scan, else 0): once every lane's best sum so far plus one whole point per step still to
+// come stays under it, nothing in this pass can reach the best match known -- the pass ends and returns false (its sums
+// are then meaningless).
+__device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __restrict__ recs, const uint32_t* __restrict__ q,
+                                         const uint32_t* s_q, const Task& t, const float* s_tri, float (&acc)[4],
+                                         const float stop_below) {
     constexpr int S = kRing;
     constexpr int D = S - 4;
     static_assert(S >= 5 && S <= 8, "ring of 5..8 slots");
@@ -361,13 +368,20 @@ __device__ __forceinline__ void run_pass(const SlideArgs& a, const uint4* __rest
     // whole rounds of the ring without a branch inside (one block for the scheduler: the next step's query words and
     // this step's table look-ups are in flight across the steps), then the last nq % S steps one by one
     uint32_t i0 = 0;
+    bool alive = true;
     for (; i0 + (uint32_t)S <= nq; i0 += (uint32_t)S) {
 #pragma unroll
         for (int u = 0; u < S; ++u) step(u, i0 + (uint32_t)u);
+        if (!MODE_B && stop_below > 0.0f) {                     // (uniform) a ratio is at most 1: an upper bound of every sum
+            const float top = fmaxf(fmaxf(acc[0] + pend[0], acc[1] + pend[1]), fmaxf(acc[2] + pend[2], acc[3] + pend[3]));
+            if (!__any(t.active && top + (float)(nq - (i0 + (uint32_t)S)) >= stop_below)) { alive = false; break; }
+        }
     }
+    if (alive) {
 #pragma unroll
-    for (int u = 0; u < S - 1; ++u)
-        if (i0 + (uint32_t)u < nq) step(u, i0 + (uint32_t)u);   // uniform
+        for (int u = 0; u < S - 1; ++u)
+            if (i0 + (uint32_t)u < nq) step(u, i0 + (uint32_t)u);   // uniform
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = __fadd_rn(acc[k], pend[k]);
     // Nothing of this pass may still be in flight when the ring's registers are reused.  The wait NAMES every slot:
@@ -376,6 +390,7 @@ __device__ __forceinline__ void run_pass(const SlideArgs& a, const uint4* __rest
     // the late records then land in the task's results.
 #pragma unroll
     for (int n = 0; n < S; ++n) asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[n].lo), "+v"(R[n].hi) : : "memory");
+    return alive;
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v, uint32_t lane) {
@@ -511,7 +526,17 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         float acc[4];
         LBAD_PROF_T(p2);
         LBAD_PROF_ADD(1, p1, p2);
-        run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc);
+        // Top-1 scans: a strong match (score >= kPruneFrom) found by ANY wave is published in the scan's result word at once;
+        // every wave looks at that word before a pass and lets run_pass give up a pass that cannot reach it (an upper bound:
+        // exact -- nothing that could win or tie is dropped; per-entry scores are never asked for together with this).
+        float stop_below = 0.0f;
+        if (!MODE_B && a.prune) {
+            const unsigned long long seen = __hip_atomic_load(p.key_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            best = seen > best ? seen : best;
+            const float bs = __uint_as_float((uint32_t)(best >> 32));
+            if (bs >= kPruneFrom) stop_below = bs * (float)nq * 0.999f;
+        }
+        const bool alive = run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc, stop_below);
         LBAD_PROF_T(p3);
         LBAD_PROF_ADD(2, p2, p3);
         LBAD_PROF_ADD(5, 0ull, 1ull);
@@ -527,7 +552,7 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         int m = -1;                                          // sums are >= 0: as integers their bits order like the floats
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (t.active && t.o0 + (uint32_t)k < t.n_off) m = max(m, __float_as_int(acc[k]));
+            if (alive && t.active && t.o0 + (uint32_t)k < t.n_off) m = max(m, __float_as_int(acc[k]));
         const float n2f = (float)(MODE_B ? t.ne : nq);
         const float thr = __uint_as_float((uint32_t)(best >> 32)) * 0.99999f;
         const bool need = m >= 0 && (p.score_bits != nullptr || __int_as_float(m) >= thr * n2f);
@@ -537,6 +562,7 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
             if (p.score_bits) atomicMax(&p.score_bits[t.ent], __float_as_uint(match));
             const unsigned long long key = sl_key(match, a.index_base + t.ent);
             best = key > best ? key : best;
+            if (!MODE_B && a.prune && match >= kPruneFrom) atomicMax(p.key_out, key);      // (rare: only a real match gets here)
         }
         LBAD_PROF_T(p4);
         LBAD_PROF_ADD(3, p3, p4);
@@ -573,7 +599,7 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     uint32_t* s_ne = s_off + kSlots;
     uint32_t* s_ent = s_ne + kSlots;
     SlidePtrs p;
-    p.recs = recs; p.off = off; p.q = q; p.score_bits = score_bits;
+    p.recs = recs; p.off = off; p.q = q; p.score_bits = score_bits; p.key_out = key_out;
     const uint32_t* s_q = QLDS ? s_qbuf : nullptr;
     unsigned long long best = 0ull;
 #ifdef LBAD_SLIDE_PROF
@@ -1206,7 +1232,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
                                   uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
                                   uint32_t subfp_len, const uint32_t* d_query, uint32_t n_query, uint32_t range,
                                   uint64_t index_base, unsigned int* d_score_bits, unsigned long long* d_key,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, bool bound_pruning) {
     if (n_entries == 0 || n_query == 0 || tasks_a + tasks_b == 0) return hipSuccess;
     if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return hipErrorInvalidValue;    // the plan counts in 32 bits
     const float* tri = sliding_tri_table();
@@ -1242,6 +1268,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     };
     a.dense_a = dense(tasks_a);
     a.dense_b = dense(tasks_b);
+    a.prune = (bound_pruning && d_score_bits == nullptr) ? 1u : 0u;
     bool full, all_feed, qlds;
     uint32_t dyn_lds;
     sliding_variant(subfp_len, n_query, range, full, all_feed, qlds, dyn_lds);

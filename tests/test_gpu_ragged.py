@@ -139,6 +139,41 @@ def _record_words(row, L, old_layout):
     return w
 
 
+def test_bound_pruning_of_top1_scans_is_exact(lb, gpu, oracle):
+    """Top-1 scans of a ragged corpus drop groups of offsets that cannot reach the best match published so far (round 4):
+    with strong matches planted at several places (early, late, twice with equal scores -- the lower index must win -- and
+    none at all) the key equals the unpruned scan's and the oracle's best entry, for queries shorter and longer than the
+    entries around them."""
+    rng = np.random.default_rng(17)
+    SEED = 0x4C424145
+    n = 60_000
+    counts = oracle.synth_ragged_counts(SEED, 0, n, 20, 70)
+    flat = oracle.synth_ragged_entries(SEED, 0, counts, 200)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    for nq, plants in ((21, [50_000]), (21, [5]), (21, [31_000, 44_000]), (33, [59_999, 10]), (21, [])):
+        src = oracle.synth_entry(SEED ^ 77, 1, nq, 200)
+        ent = flat.copy()
+        for e in plants:
+            ne = int(counts[e])
+            k = min(nq, ne)
+            at = int(starts[e]) + int(rng.integers(0, ne - k + 1))
+            ent[at:at + k] = src[:k]                            # the same window in every planted entry: equal scores where the lengths allow
+        corpus = lb.Corpus.ragged(200, n, int(counts.sum()))
+        packed = np.stack([lb.pack_subfingerprint(r) for r in ent]).view(np.uint8).reshape(-1, 32)
+        corpus.append_ragged_packed_device(gpu.from_numpy(packed).cuda(), counts)
+        q = lb.Fingerprint.from_bools(src)
+        corpus.set_bound_pruning(True)
+        pruned = corpus.query(q)
+        corpus.set_bound_pruning(False)
+        full = corpus.query(q)
+        want_i, want_s, _ = oracle.corpus_best_ragged(src, (ent, counts), 200, nthreads=8, want_scores=True)
+        assert pruned == full, (nq, plants, pruned, full)
+        assert pruned[0] == want_i and np.float32(pruned[1]).view(np.uint32) == np.float32(want_s).view(np.uint32), (nq, plants, pruned, want_i, want_s)
+        if plants:
+            assert pruned[1] > 0.7, (plants, pruned)
+        corpus.dispose()
+
+
 def test_corpus_file_records_are_not_trusted(lb, gpu, oracle, tmp_path):
     """Round-3 advice: a corpus file's records carried index fields the scan wrote through.  Now nothing a record
     carries besides its Booleans survives the loader: a file with garbage in every reserved / derived bit and in the

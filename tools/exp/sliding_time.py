@@ -17,6 +17,8 @@ ap.add_argument("--hi", type=int, default=70)
 ap.add_argument("--nq", type=int, nargs="+", default=[21])
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--json")
+ap.add_argument("--prune", type=int, default=0, help="1: leave the bound pruning of top-1 scans on (default here: off = every offset is evaluated)")
+ap.add_argument("--no-match", action="store_true", help="a query that matches nothing in the corpus")
 a = ap.parse_args()
 SEED = 0x4C424145
 counts = O.synth_ragged_counts(SEED, 0, a.n, a.lo, a.hi)
@@ -25,11 +27,14 @@ packed = lb.synth_ragged_corpus_device(SEED, 0, counts, 200)
 c = lb.Corpus.ragged(200, a.n, total)
 c.append_ragged_packed_device(packed, counts)
 del packed
+c.set_bound_pruning(bool(a.prune))
 key = torch.zeros(1, dtype=torch.int64, device="cuda")
 out = []
 for nq in a.nq:
     planted = min(777_777, a.n - 1)
     src = O.synth_entry(SEED, planted, max(int(counts[planted]), nq), 200)
+    if a.no_match:
+        src = O.synth_entry(SEED ^ 0x5555, 123, nq, 200)
     q = lb.Fingerprint.from_bools(src[:nq])
     for _ in range(3):
         c.query_key_device(q, key)

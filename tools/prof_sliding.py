@@ -22,6 +22,7 @@ total = int(counts.sum())
 packed = lb.synth_ragged_corpus_device(SEED, 0, counts, 200)
 c = lb.Corpus.ragged(200, n, total)
 c.append_ragged_packed_device(packed, counts)
+c.set_bound_pruning(False)          # the profile is of the full scan: every sliding offset of every entry
 planted = min(777_777, n - 1)
 src = O.synth_entry(SEED, planted, max(int(counts[planted]), nq), 200)
 q = lb.Fingerprint.from_bools(src[:nq])
