@@ -16,6 +16,7 @@ total = int(counts.sum())
 packed = lb.synth_ragged_corpus_device(SEED, 0, counts, 200)
 c = lb.Corpus.ragged(200, n, total)
 c.append_ragged_packed_device(packed, counts)
+c.set_bound_pruning(False)
 del packed
 L = C.CDLL(_N.LIB_PATH)
 key = torch.zeros(1, dtype=torch.int64, device="cuda")
