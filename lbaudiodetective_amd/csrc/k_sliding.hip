@@ -190,6 +190,24 @@ __device__ __forceinline__ void slot_load_masked(const uint4* __restrict__ recs,
                  : "memory");
 }
 
+// The same with the address split into a wave-uniform base (scalar registers: advancing it per step costs no vector
+// instruction) and a per-lane byte offset that stays put for the whole pass ("A" passes: a lane's records are consecutive).
+__device__ __forceinline__ void slot_load_masked_at(const uint4* base_in, uint32_t byte_off, unsigned long long mask, Slot& s) {
+    // (the base IS uniform; saying so keeps it in scalar registers whatever the compiler's divergence analysis concluded)
+    const unsigned long long bits = reinterpret_cast<unsigned long long>(base_in);
+    const unsigned long long base = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bits) |
+                                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bits >> 32)) << 32);
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %2, exec\n\t"
+                 "s_mov_b64 exec, %5\n\t"
+                 "global_load_dwordx4 %0, %3, %4\n\t"
+                 "global_load_dwordx4 %1, %3, %4 offset:16\n\t"
+                 "s_mov_b64 exec, %2"
+                 : "+v"(s.lo), "+v"(s.hi), "=&s"(saved)
+                 : "v"(byte_off), "s"(base), "s"(mask)
+                 : "memory");
+}
+
 __device__ __forceinline__ void slot_from_right(Slot& d, const Slot& s) {
     d.lo.x = from_right_lane(s.lo.x); d.lo.y = from_right_lane(s.lo.y); d.lo.z = from_right_lane(s.lo.z); d.lo.w = from_right_lane(s.lo.w);
     d.hi.x = from_right_lane(s.hi.x); d.hi.y = from_right_lane(s.hi.y); d.hi.z = from_right_lane(s.hi.z); d.hi.w = from_right_lane(s.hi.w);
@@ -248,6 +266,13 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
         return (t.active && p >= 0 && (uint32_t)p < t.ne) ? t.rec0 + (uint32_t)p : a.zero_rec;
     };
     auto mod = [](int n) { return ((n % S) + S) % S; };
+    // "A" passes: record rec0 + n of a lane lies at a_base + 2 n (uint4 units), a_off bytes further on.  The lanes of a pass
+    // are in entry order, lane 0 first; what separates two lanes are whole entries that hold at most 64 tasks together, i.e.
+    // fewer than 64 (n_query + 260) records: the offset fits 32 bits with room to spare (the launcher refuses queries of a
+    // million sub-fingerprints and more).
+    const uint32_t rec_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.rec0);
+    const uint4* a_base = recs + 2 * (uint64_t)rec_first;
+    const uint32_t a_off = MODE_B ? 0u : (t.rec0 - rec_first) * 32u;
     LBAD_PROF_T(q0);
     // The ring at step 0, ONE exposed round trip to memory: every lane fetches the four records of its window; the D
     // records behind it come from the neighbour's window once that has landed, and in feeder lanes from memory -- as
@@ -265,7 +290,7 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
             else slot_from_right(R[n], R[n - 4]);
         }
 #pragma unroll
-        for (int n = 4; n < S; ++n) slot_load_masked(recs, rec_index(n), feeders, R[n]);
+        for (int n = 4; n < S; ++n) slot_load_masked_at(a_base + 2 * n, a_off, feeders, R[n]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             uint32_t w[8];
@@ -358,7 +383,7 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
             LBAD_PROF_ADD(14, 0ull, 1ull);
 #endif
             if (!ALL_FEED) slot_from_right(R[u], R[(u + D) % S]);
-            slot_load_masked(recs, rec_index((int32_t)i + S), feeders, R[u]);
+            slot_load_masked_at(a_base + 2 * (size_t)(i + (uint32_t)S), a_off, feeders, R[u]);
         } else {
             slot_wait_n<2 * (D - 1)>(R[mod(u + 1)]);
             if (!ALL_FEED) slot_from_left(R[mod(u - 3)], R[mod(u + S - 7)]);
@@ -1235,6 +1260,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
                                   hipStream_t stream, bool bound_pruning) {
     if (n_entries == 0 || n_query == 0 || tasks_a + tasks_b == 0) return hipSuccess;
     if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return hipErrorInvalidValue;    // the plan counts in 32 bits
+    if (n_query >= (1u << 20)) return hipErrorInvalidValue;                                  // (run_pass: 32-bit lane offsets)
     const float* tri = sliding_tri_table();
     if (!tri) return hipErrorOutOfMemory;
     if (sliding_short(n_query, ne_max)) {
