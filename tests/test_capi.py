@@ -136,6 +136,13 @@ def test_compute_calls_fail_loudly_without_gpu(lb):
     with pytest.raises(lb.LBAudioDetectiveError):
         lb.Corpus(200, 5, 10)
     assert lb.lib().LBAudioDetectiveDeviceCount() == 0
+    # round 4's additions: layout queries have no answer without a device (the plan lives there), null handles are refused
+    assert lb.compact_layout(d) is None and lb.compact_bands(d) is None
+    L = lb.lib()
+    assert L.LBAudioDetectiveCorpusSetBoundPruning(None, 1) == lb.constant("kLBAudioDetectiveArgumentInvalid")
+    assert L.LBAudioDetectiveSetFilePipeline(None, 1) != 0
+    n = C.c_uint32(7)
+    assert L.LBAudioDetectiveGetCompactBands(None, None, C.byref(n)) != 0
 
 
 def test_missing_library_raises(lb, monkeypatch, tmp_path):
