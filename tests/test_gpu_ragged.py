@@ -150,7 +150,7 @@ def test_bound_pruning_of_top1_scans_is_exact(lb, gpu, oracle):
     counts = oracle.synth_ragged_counts(SEED, 0, n, 20, 70)
     flat = oracle.synth_ragged_entries(SEED, 0, counts, 200)
     starts = np.concatenate([[0], np.cumsum(counts)])
-    for nq, plants in ((21, [50_000]), (21, [5]), (21, [31_000, 44_000]), (33, [59_999, 10]), (21, [])):
+    for nq, plants in ((21, [50_000]), (21, [5]), (21, [31_000, 44_000]), (33, [59_999, 10]), (60, [40_000, 123]), (75, [7]), (21, [])):
         src = oracle.synth_entry(SEED ^ 77, 1, nq, 200)
         ent = flat.copy()
         for e in plants:
