@@ -134,6 +134,10 @@ def parse_args(argv=None):
     ap.add_argument("--min-seconds", type=float, default=3.0,
                     help="lower bound of the timed region; a step becomes as many passes over the batch as that takes")
     ap.add_argument("--passes-per-step", type=int, default=0, help="override the calibration (0 = from --min-seconds)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (and take every collective branch) even at one rank: executes the "
+                         "N > 1 plumbing -- init_process_group, all_gather_object, the MAX all-reduces, the id broadcast of "
+                         "the library's communicator, barrier, destroy -- on a single GPU")
     ap.add_argument("--no-sliding", action="store_true", help="skip the ragged-corpus (sliding compare) leg")
     ap.add_argument("--no-files", action="store_true", help="skip the file leg (BASELINE configs[0] on the bird fixtures)")
     return ap.parse_args(argv)
@@ -557,6 +561,9 @@ def run_rank(args) -> int:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with matching values\n")
         return 2
     dry = args.backend == "gloo"
+    dist_on = world > 1 or args.force_dist          # every branch below that talks to torch.distributed
+    if dist_on and "MASTER_PORT" not in os.environ:
+        os.environ["MASTER_PORT"] = str(free_port())
     if dry and args.clips != 0:
         sys.stderr.write("bench.py: --backend gloo is the CPU dry run and needs --clips 0\n")
         return 2
@@ -564,7 +571,7 @@ def run_rank(args) -> int:
     if dry:
         os.environ.setdefault("MASTER_PORT", "29533")
         dev = torch.device("cpu")
-        if world > 1:
+        if dist_on:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         if torch.cuda.device_count() < world:
@@ -572,23 +579,24 @@ def run_rank(args) -> int:
             return 3
         torch.cuda.set_device(local_rank if world > 1 else 0)
         dev = torch.device("cuda", torch.cuda.current_device())
-        if world > 1:
+        if dist_on:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     n_gpus = world
-    rccl_ranks = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+    rccl_ranks = dist.get_world_size() if (dist_on and dist.is_initialized()) else 1
     me = {"rank": rank, "local_rank": local_rank, "device": (str(dev)),
           "name": (torch.cuda.get_device_name(dev) if not dry else "cpu"), "pid": os.getpid()}
     devices = [me]
-    if world > 1:
+    if dist_on:
         devices = [None] * world
         dist.all_gather_object(devices, me)
 
     from lbaudiodetective_amd import sharded
+    sharded.FORCE_COLLECTIVES = bool(args.force_dist)
 
     def barrier():
         if not dry:
             torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         if not dry:
             torch.cuda.synchronize()
@@ -599,6 +607,11 @@ def run_rank(args) -> int:
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "rccl_ranks": rccl_ranks, "backend": args.backend, "devices": devices,
     }
+    if args.force_dist:
+        result["force_dist"] = ("torch.distributed initialised at this world size and every collective branch taken: "
+                                "init_process_group, all_gather_object, MAX all-reduces (passes, elapsed, stats), "
+                                "broadcast_object_list of the communicator id, all_reduce(MIN) of the communicator check, "
+                                "barrier, destroy_process_group")
     if dry:
         result["dry_run"] = "CPU dry run of launcher, rendezvous, shard arithmetic and key reduction; no kernel ran"
 
@@ -626,7 +639,7 @@ def run_rank(args) -> int:
         torch.cuda.synchronize()
         pass_s = (time.perf_counter() - c0) / 2
         passes = args.passes_per_step or max(1, int(-(-args.min_seconds // (args.steps * pass_s))))
-        if world > 1:                                       # every rank must run the same number of passes
+        if dist_on:                                         # every rank must run the same number of passes
             t = torch.tensor([passes], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             passes = int(t.item())
@@ -652,12 +665,19 @@ def run_rank(args) -> int:
         elapsed = time.perf_counter() - t0
         if tele:
             tele.stop()
-        if world > 1:
+        if dist_on:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         ms_per_step = elapsed * 1e3 / args.steps
         value = n_gpus * n_clips * passes * args.steps / elapsed       # audio-seconds per second, whole job
+        if dist_on:
+            # the OPTIONAL gather of sharded fingerprinting (160 B per clip; the path itself needs no collective), untimed:
+            # every rank's first clips in rank order, checked against what this rank holds
+            head = min(16, n_clips)
+            allp = sharded.gather_packed(packed[:head])
+            assert allp.shape[0] == head * world and torch.equal(allp[rank * head:(rank + 1) * head], packed[:head])
+            result["gather_packed"] = {"clips_per_rank": head, "gathered": int(allp.shape[0])}
         step_ms = [a.elapsed_time(b) for a, b in ev]
         kern_avg_ms = sum(step_ms) / len(step_ms) / passes              # one pass, HIP events on the launch stream
         stage1_ms, stage2_ms, launches = det.stage_times()      # summed over the timed passes
@@ -832,7 +852,7 @@ def run_rank(args) -> int:
             except Exception as e:                          # noqa: BLE001 -- keep the scaling run alive, say what happened
                 comm_note = f"LBAudioDetectiveCommInitRank failed ({e}); keys reduced through torch.distributed instead"
                 sys.stderr.write("bench.py: " + comm_note + "\n")
-            if world > 1:                                   # all ranks on the same path, or none
+            if dist_on:                                     # all ranks on the same path, or none
                 ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
                 if int(ok.item()) == 0 and comm is not None:
@@ -849,6 +869,9 @@ def run_rank(args) -> int:
             q[:, 0::2] = np.where(flip, qsrc[:, 1::2], qsrc[:, 0::2])
             q[:, 1::2] = np.where(flip, qsrc[:, 0::2], qsrc[:, 1::2])
             fq = lb.Fingerprint.from_bools(q)
+            if dist_on:                                         # the 160-byte query broadcast of the sharded compare
+                fq = sharded.broadcast_fingerprint(fq if rank == 0 else None, src=0)
+                assert np.array_equal(fq.to_bools(), q)
             key = torch.zeros(1, dtype=torch.int64, device=dev)
             for _ in range(3):
                 best = sc.query(fq)
@@ -862,7 +885,7 @@ def run_rank(args) -> int:
             scan_ms = e0.elapsed_time(e1) / reps
             local_key = key.clone()
             ar_ms = None
-            if world > 1:                                       # for reference: 8 bytes through torch.distributed's RCCL
+            if dist_on:                                         # for reference: 8 bytes through torch.distributed's RCCL
                 barrier()
                 t1 = time.perf_counter()
                 for _ in range(reps):
@@ -886,7 +909,7 @@ def run_rank(args) -> int:
                 api_lat_ms = (time.perf_counter() - t1) * 1e3 / (reps * 5)
                 assert best_api == best, (best_api, best)
             stats = torch.tensor([scan_ms, ar_ms or 0.0, lat_ms], dtype=torch.float64, device=dev)
-            if world > 1:
+            if dist_on:
                 dist.all_reduce(stats, op=dist.ReduceOp.MAX)
             scan_ms, ar_max, lat_ms = (float(v) for v in stats.tolist())
             n_local_max = -(-total // world)
@@ -897,7 +920,7 @@ def run_rank(args) -> int:
                                  f"{total // world} per rank x{world}, RCCL all-reduce(MAX) of the (score, ~index) key"),
                     "best_index": best[0], "best_score": best[1], "planted_index": planted, "planted_rank": planted_rank,
                     "found_planted": bool(best[0] == planted),
-                    "scan_ms": round(scan_ms, 4), "allreduce_ms": (round(ar_max, 4) if world > 1 else None),
+                    "scan_ms": round(scan_ms, 4), "allreduce_ms": (round(ar_max, 4) if dist_on else None),
                     "query_latency_ms": round(api_lat_ms if api_lat_ms is not None else lat_ms, 4),
                     "query_latency_sharded_path_ms": round(lat_ms, 4),
                     "collective_fallback": comm is None,
@@ -999,7 +1022,7 @@ def run_rank(args) -> int:
         if files:
             result["configs0_files"] = files
 
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     rc = 0
@@ -1009,7 +1032,7 @@ def run_rank(args) -> int:
         if bad:
             sys.stderr.write("bench.py: SELF-CHECK FAILED: " + "; ".join(bad) + "\n")
             rc = 4
-        if world > 1 and result.get("compare", {}).get("collective_fallback"):
+        if dist_on and result.get("compare", {}).get("collective_fallback"):
             sys.stderr.write("bench.py: the library's RCCL communicator could not be created; the compare leg fell back to "
                              "torch.distributed -- a scaling run must not pass like this\n")
             rc = rc or 5

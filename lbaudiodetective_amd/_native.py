@@ -12,7 +12,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "liblbaudiodetective.so")
+# LBAD_LIB=<path>: another build of the SAME library (the A/B variants of tools/exp/build_variants.sh); never a fallback
+LIB_PATH = os.path.abspath(os.environ["LBAD_LIB"]) if os.environ.get("LBAD_LIB") else os.path.join(_HERE, "lib", "liblbaudiodetective.so")
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "lbaudiodetective.h")
 
 # MacTypes

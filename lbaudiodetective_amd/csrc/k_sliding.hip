@@ -140,8 +140,13 @@ template <bool MODE_B, bool FULL>
 __device__ __forceinline__ uint32_t pair_index(const uint32_t (&r)[8], const uint32_t (&qv)[8], const uint32_t (&nzq)[4],
                                                uint32_t row, const uint32_t (&rm)[4]) {
     uint32_t h = 0;
+#ifdef LBAD_EXP_SLIDE_WORDS
+    constexpr int kWords = LBAD_EXP_SLIDE_WORDS;
+#else
+    constexpr int kWords = 4;
+#endif
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < kWords; ++w) {
         uint32_t u;
         if (MODE_B) u = __builtin_amdgcn_bitop3_b32(nzq[w], r[w], qv[w], 0x90);
         else u = __builtin_amdgcn_bitop3_b32(r[w], r[4 + w], qv[w], 0xA4);
@@ -224,6 +229,65 @@ __device__ __forceinline__ void slot_wait_n(Slot& s) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.lo), "+v"(s.hi) : "n"(IN_FLIGHT));
 }
 
+// The windows of an "A" pass at step 0: four consecutive records = 128 contiguous bytes per lane, and the windows of an
+// entry's lanes lie back to back.  Fetched lane by lane (round 4) that is eight load instructions which touch 64 lines
+// each, sixteen bytes at a time: the vector L1 serves one line per clock and keeps few of them until the next of the
+// eight instructions asks again -- a quarter of the scan's time (knock-out: 0.473 -> 0.356 ms without the fill, 0.400
+// with the same bytes fetched as whole lines).  Here the pass's 8 KB are fetched as whole lines and dealt out through LDS:
+//   chunk x = 8 t + m (m = 0..7) is half m & 1 of record m >> 1 of task t's window; load j (0..7) of lane l fetches
+//   chunk 64 j + l, i.e. bytes 16 (l & 7) .. of task 8 j + (l >> 3) -- eight lanes cover a window's 128 bytes;
+//   a half of the tasks at a time (4.5 KB of LDS per wave): four loads are written to LDS, 144 bytes per task (the 16
+//   bytes of padding put the sixteen lanes of a ds_read_b128 on distinct banks), and the half's 32 lanes read their
+//   eight chunks back.  The first records of the tasks travel the same way (one word each).
+constexpr uint32_t kStageTask = 9;                    // uint4 per task in the staging block
+constexpr uint32_t kStageWords = 32 * kStageTask + 16;  // uint4 per wave: half a pass + the 64 first-record indices
+__device__ __forceinline__ void fill_windows(const uint4* __restrict__ recs, const Task& t, uint32_t rec_first, uint4* s_stage,
+                                             Slot& w0, Slot& w1, Slot& w2, Slot& w3) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* s_first = reinterpret_cast<uint32_t*>(s_stage + 32 * kStageTask);
+    s_first[(lane & 7u) * 8u + (lane >> 3)] = t.active ? t.rec0 : rec_first;     // idle lanes: any record that exists
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint4 f0 = reinterpret_cast<const uint4*>(s_first)[2u * (lane >> 3)];      // first records of tasks (lane >> 3) + 8 j
+    const uint4 f1 = reinterpret_cast<const uint4*>(s_first)[2u * (lane >> 3) + 1u];
+    const uint32_t first[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+    // all eight loads first, by hand: left to itself the compiler fetches the second half only after the first half has
+    // been dealt out (two round trips to memory per pass), and -- seeing no dependence between lanes -- moves a half's
+    // LDS writes into the branch of the lanes that read them.  The wave barriers below are what tells it that all 64
+    // lanes write before any lane reads.
+    u32x4 c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint4* src = recs + 2 * (uint64_t)first[j] + (lane & 7u);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(c[j]) : "v"(src) : "memory");
+    }
+    Slot* w[4] = {&w0, &w1, &w2, &w3};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // loads return in order: with at most four in flight the first four have landed
+        if (h == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : : "memory");
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const u32x4 v = c[4 * h + jj];
+            s_stage[(64u * jj + lane) + (8u * jj + (lane >> 3))] = make_uint4(v.x, v.y, v.z, v.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if ((lane >> 5) == (uint32_t)h) {
+            const uint4* mine = s_stage + kStageTask * (lane & 31u);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint4 lo = mine[2 * n], hi = mine[2 * n + 1];
+                w[n]->lo = u32x4{lo.x, lo.y, lo.z, lo.w};
+                w[n]->hi = u32x4{hi.x, hi.y, hi.z, hi.w};
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 #ifndef LBAD_SLIDE_RING
 #define LBAD_SLIDE_RING 6
 #endif
@@ -248,7 +312,7 @@ template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
 // are then meaningless).
 __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __restrict__ recs, const uint32_t* __restrict__ q,
                                          const uint32_t* s_q, const Task& t, const float* s_tri, float (&acc)[4],
-                                         const float stop_below) {
+                                         const float stop_below, uint4* s_stage) {
     constexpr int S = kRing;
     constexpr int D = S - 4;
     static_assert(S >= 5 && S <= 8, "ring of 5..8 slots");
@@ -279,11 +343,16 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
     // masked loads of the step loop's kind, issued in slot order right here, so that the loop's own waits (everything
     // but the last 2 (D - 1) loads has landed) cover them: they are still in flight when step 0 starts.
     if (!MODE_B) {
+#if defined(LBAD_EXP_SLIDE_LANEFILL)
+        // (round 4's fill: every lane fetches its own 128 bytes -- eight instructions that touch 64 lines each)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             asm volatile("" : "=v"(R[n].lo), "=v"(R[n].hi));       // idle lanes: whatever the registers hold (never used)
             if (t.active) slot_load(recs, rec_index(n), R[n]);
         }
+#else
+        fill_windows(recs, t, rec_first, s_stage, R[0], R[1], R[2], R[3]);
+#endif
 #pragma unroll
         for (int n = 4; n < S; ++n) {
             if (ALL_FEED) asm volatile("" : "=v"(R[n].lo), "=v"(R[n].hi));
@@ -353,7 +422,9 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
     // one step; u = i % S is a compile-time constant (the ring's slots are registers)
     auto step = [&](const int u, const uint32_t i) {
         const QStep qc = qn;
+#ifndef LBAD_EXP_SLIDE_NOQ
         fetch_q(i + 1u, qn);                                    // (one sub-fingerprint of slack behind the query)
+#endif
         if (!MODE_B) {
             uint32_t w[8];
             slot_words(R[(u + 3) % S], w);
@@ -369,21 +440,38 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             acc[k] = __fadd_rn(acc[k], pend[k]);                // step i - 1's term (0.0 in front of the first)
+#ifdef LBAD_EXP_SLIDE_NOTRI
+            pend[k] = __uint_as_float(h[k]);
+#else
             pend[k] = s_tri[h[k]];
+#endif
         }
         // the window moves on: the record fetched D steps ago has landed by now
 #ifdef LBAD_SLIDE_PROF_STEP
         LBAD_PROF_T(w0);
 #endif
         if (!MODE_B) {
+#ifndef LBAD_EXP_SLIDE_NOLOADS
             slot_wait_n<2 * (D - 1)>(R[(u + 4) % S]);
+#endif
 #ifdef LBAD_SLIDE_PROF_STEP
             LBAD_PROF_T(w1);
             LBAD_PROF_ADD(13, w0, w1);
             LBAD_PROF_ADD(14, 0ull, 1ull);
 #endif
+#ifndef LBAD_EXP_SLIDE_NODPP
             if (!ALL_FEED) slot_from_right(R[u], R[(u + D) % S]);
-            slot_load_masked_at(a_base + 2 * (size_t)(i + (uint32_t)S), a_off, feeders, R[u]);
+#endif
+#if defined(LBAD_EXP_SLIDE_NOFEED)
+            slot_load_masked_at(a_base + 2 * (size_t)(i + (uint32_t)S), a_off, 0ull, R[u]);
+#elif !defined(LBAD_EXP_SLIDE_NOLOADS)
+            // the last record any offset of the pass uses is relative record nq + 2 (offset 3, step nq - 1): the loads
+            // behind it still issue (the waits count instructions) but with no lane switched on -- round 4 read up to
+            // six records past every entry's end, 13 % of the scan's traffic
+            unsigned long long fnow;                            // (scalar by hand: the compiler selects 64-bit values in vector registers)
+            asm("s_cmp_le_u32 %1, %2\n\ts_cselect_b64 %0, %3, 0" : "=s"(fnow) : "s"((uint32_t)__builtin_amdgcn_readfirstlane((int)(i + (uint32_t)S))), "s"(nq + 2u), "s"(feeders) : "scc");
+            slot_load_masked_at(a_base + 2 * (size_t)(i + (uint32_t)S), a_off, fnow, R[u]);
+#endif
         } else {
             slot_wait_n<2 * (D - 1)>(R[mod(u + 1)]);
             if (!ALL_FEED) slot_from_left(R[mod(u - 3)], R[mod(u + S - 7)]);
@@ -439,7 +527,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v, uint32_t lane
 template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
 __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, const SlidePtrs& p, const float* s_tri, const uint32_t* s_q,
                                                         uint32_t* s_cursor, uint32_t* s_start, uint32_t* s_off, uint32_t* s_ne,
-                                                        uint32_t* s_ent, unsigned long long best) {
+                                                        uint32_t* s_ent, uint4* s_stage, unsigned long long best) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nq = a.nq;
     const uint32_t run_end = s_cursor[1];
@@ -561,7 +649,7 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
             const float bs = __uint_as_float((uint32_t)(best >> 32));
             if (bs >= kPruneFrom) stop_below = bs * (float)nq * 0.999f;
         }
-        const bool alive = run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc, stop_below);
+        const bool alive = run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc, stop_below, s_stage);
         LBAD_PROF_T(p3);
         LBAD_PROF_ADD(2, p2, p3);
         LBAD_PROF_ADD(5, 0ull, 1ull);
@@ -597,7 +685,7 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
 
 // the query in LDS (dynamic, 64 bytes per sub-fingerprint): up to kQueryLds sub-fingerprints; longer queries are read
 // through the scalar cache
-constexpr uint32_t kQueryLds = 512;
+constexpr uint32_t kQueryLds = 480;
 
 // starts_a / starts_b: grid + 1 entry indices: workgroup g owns the entries [starts[g], starts[g + 1])
 template <bool FULL, bool ALL_FEED, bool QLDS>
@@ -609,6 +697,7 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     __shared__ uint32_t s_queue[kScanWaves][4 * kSlots + 4];
     __shared__ unsigned long long s_k[kScanWaves];
     __shared__ uint32_t s_cursor[2][2];                                    // per mode: next entry to claim, end of the run
+    __shared__ __attribute__((aligned(16))) uint4 s_stage_all[kScanWaves][kStageWords];   // fill_windows' staging block, per wave
     extern __shared__ __attribute__((aligned(16))) uint32_t s_qbuf[];      // QLDS: nq * kQWords words
     for (uint32_t i = threadIdx.x; i < kTriSize; i += kScanThreads) s_tri[i] = tri_tbl[i];
     if (QLDS)
@@ -638,10 +727,10 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     // other kind.  Where B entries are rare (a short query: the few entries not longer than it) finding them is a walk
     // over the whole run's offsets -- latency, not arithmetic -- and hides behind the others' A passes this way.
     const bool b_first = wave >= kScanWaves - 2;
-    if (b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, best);
-    best = scan_mode<false, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[0], s_start, s_off, s_ne, s_ent, best);
+    if (b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
+    best = scan_mode<false, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[0], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     LBAD_PROF_T(k1);
-    if (!b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, best);
+    if (!b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     LBAD_PROF_T(k2);
     LBAD_PROF_ADD(6, k0, k1);
     LBAD_PROF_ADD(7, k1, k2);

@@ -10,6 +10,18 @@ tests of this reduction logic.
 """
 from __future__ import annotations
 
+# True: the helpers below run their collectives whenever torch.distributed is initialised, also in a group of ONE rank
+# (bench.py --force-dist: the N > 1 code paths executed on a single GPU); False: a lone rank skips them.
+FORCE_COLLECTIVES = False
+
+
+def _collective(group=None) -> bool:
+    """Is there a process group this call should talk to?"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return FORCE_COLLECTIVES or dist.get_world_size(group) > 1
+
 
 def shard_range(n_entries: int, rank: int, world_size: int):
     """Contiguous [begin, end) of rank's shard; sizes differ by at most one."""
@@ -35,7 +47,7 @@ def decode_key(key: int):
 def allreduce_best(key_tensor, group=None):
     """In-place MAX all-reduce of an int64 key tensor (any device the backend supports)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective(group):
         dist.all_reduce(key_tensor, op=dist.ReduceOp.MAX, group=group)
     return key_tensor
 
@@ -46,7 +58,7 @@ def gather_packed(local_packed, group=None):
     may hold different numbers of clips.  The fingerprint path itself needs no collective."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective(group):
         return local_packed
     world = dist.get_world_size(group)
     n = torch.tensor([local_packed.shape[0]], dtype=torch.int64, device=local_packed.device)
@@ -69,7 +81,7 @@ def broadcast_fingerprint(fp, src: int = 0, group=None, device=None):
     import torch
     import torch.distributed as dist
     from .api import Fingerprint
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective(group):
         return fp
     if device is None:
         device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
@@ -103,7 +115,7 @@ def make_comm(rank: int = 0, world_size: int = 1, group=None):
             uid[0] = Comm.unique_id()
         except Exception as e:          # noqa: BLE001 -- the other ranks are waiting in the broadcast: tell them
             err = e
-    if world_size > 1:
+    if world_size > 1 or _collective(group):
         import torch.distributed as dist
         dist.broadcast_object_list(uid, src=0, group=group)
     if uid[0] is None:

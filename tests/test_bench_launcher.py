@@ -66,6 +66,17 @@ def test_world_size_eight_with_empty_shards():
     assert c["best_index"] == c["planted_index"] == 1 and abs(c["best_score"] - 0.93) < 1e-6
 
 
+def test_force_dist_takes_the_collective_branches_at_one_rank():
+    """`--force-dist` at world size 1 (gloo here; tests/test_gpu_parity.py runs the same switch on the nccl backend):
+    the process group exists, the reduction goes through torch.distributed and the line says so."""
+    out = _run("--gpus", "1", "--force-dist", "--backend", "gloo", "--clips", "0", "--corpus", "2000")
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and "force_dist" in r and [d["rank"] for d in r["devices"]] == [0]
+    c = r["compare"]
+    assert c["entries_per_rank"] == [2000] and c["best_index"] == c["planted_index"] and c["allreduce_ms"] > 0
+
+
 def _bench_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))

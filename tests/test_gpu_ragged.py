@@ -438,3 +438,35 @@ def test_sharded_entry_point_with_two_ranks_in_one_process(lb, gpu, oracle):
     out = both(shards, bases, many)
     assert out[0] == out[1] and out[0][0] == "ok" and out[0][1] == [want[i % len(fps)] for i in range(len(many))]
     assert [c - b for c, b in zip(calls, before)] == [2, 2]
+
+
+def test_bench_collective_paths_on_nccl_at_one_rank(gpu):
+    """Every branch bench.py takes at N > 1 that is well defined at one rank, on the REAL backend: `torch.distributed.run
+    --nproc-per-node=1 bench.py --gpus 1 --force-dist` initialises the nccl (= RCCL) process group on this GPU, gathers
+    the device descriptions, MAX-reduces passes / elapsed / stats, broadcasts the library communicator's id and the
+    query, gathers packed fingerprints, runs the sharded query through ncclAllReduce inside the library, and tears the
+    group down.  The bench is a CHILD process (a process that has touched the GPU must never exec another program)."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--clips", "2000",
+           "--corpus", "200000", "--corpus-hbm", "0", "--steps", "2", "--warmup", "1", "--min-seconds", "0.2",
+           "--no-cpu-baseline", "--no-other-configs", "--no-sliding", "--no-files"]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["backend"] == "nccl" and "force_dist" in r
+    assert r["devices"][0]["rank"] == 0 and r["value"] > 0
+    assert r["gather_packed"] == {"clips_per_rank": 16, "gathered": 16}
+    c = r["compare"]
+    assert c["collective_fallback"] is False and c["found_planted"] is True and c["allreduce_ms"] is not None
+    assert r["parity"]["bit_exact"] is True if "parity" in r else True
+    assert r["self_check"]["ok"]
