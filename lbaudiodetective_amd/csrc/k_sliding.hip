@@ -71,6 +71,11 @@ constexpr uint32_t kTriSize = (kTriPairs + 1) * (kTriPairs + 2) / 2;   // 5151 q
 constexpr uint32_t kQWords = 16;      // per query sub-fingerprint: P[4] N[4] NZ[4] tri-base possible - -
 constexpr uint32_t kQHeader = 16;     // words in front of the query (reserved, zero)
 constexpr uint32_t kSlots = 128;      // queue slots per wave (at most 63 left over + 64 new)
+#ifndef LBAD_CLAIM_DIV
+#define LBAD_CLAIM_DIV 2u          // a claim takes 1 / (LBAD_CLAIM_DIV * waves) of what is left of the workgroup's run ...
+#define LBAD_CLAIM_PASSES 2u       // ... but at least this many passes' worth of entries
+#define LBAD_CLAIM_MIN 8u
+#endif
 constexpr float kPruneFrom = 0.7f;    // top-1 scans: matches from this score on are published and bound the passes that follow
 
 __device__ __forceinline__ unsigned long long sl_key(float score, uint64_t global_index) {
@@ -105,9 +110,17 @@ struct SlidePtrs {
     unsigned long long* key_out;           // the scan's result word: also where a strong match is published while the scan runs
 };
 
+#if defined(LBAD_SLIDE_PROF) || defined(LBAD_SLIDE_STAMPS)
+// per wave: start, cursor dry (A), end of A, end (100 MHz stamps); tasks queued when dry, passes after it, their ticks, passes
+__device__ unsigned long long g_slide_times[1024 * 16 * 8];
+#define LBAD_STAMP(slot, value) do { if ((threadIdx.x & 63u) == 0) g_slide_times[(blockIdx.x * kScanWaves + (threadIdx.x >> 6)) * 8 + (slot)] = (value); } while (0)
+#else
+#define LBAD_STAMP(slot, value)
+#endif
 #ifdef LBAD_SLIDE_PROF
 // bring-up aid: shader-clock ticks per phase, summed over the waves (tools/exp/sliding_prof.py reads them)
 __device__ unsigned long long g_slide_prof[16];
+__device__ unsigned int g_slide_passes[256 * 16 * 64 * 4];          // per wave and A pass (up to 64): start (100 MHz, low word), shader ticks       // per wave: start, cursor dry (A), end of A, end -- 100 MHz ticks
 #define LBAD_PROF_T(x) const unsigned long long x = __builtin_readcyclecounter()
 __shared__ unsigned long long s_slide_prof[kScanWaves][16];     // per wave, flushed once when the kernel ends
 #define LBAD_PROF_ADD(slot, a, b) do { if ((threadIdx.x & 63u) == 0) s_slide_prof[threadIdx.x >> 6][slot] += (b) - (a); } while (0)
@@ -241,8 +254,10 @@ __device__ __forceinline__ void slot_wait_n(Slot& s) {
 //   eight chunks back.  The first records of the tasks travel the same way (one word each).
 constexpr uint32_t kStageTask = 9;                    // uint4 per task in the staging block
 constexpr uint32_t kStageWords = 32 * kStageTask + 16;  // uint4 per wave: half a pass + the 64 first-record indices
+// `touched`: a register that loads issued before the call are still on their way into (the feeders' line touches of
+// run_pass); it stays reserved until they have landed.
 __device__ __forceinline__ void fill_windows(const uint4* __restrict__ recs, const Task& t, uint32_t rec_first, uint4* s_stage,
-                                             Slot& w0, Slot& w1, Slot& w2, Slot& w3) {
+                                             Slot& w0, Slot& w1, Slot& w2, Slot& w3, uint32_t& touched) {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* s_first = reinterpret_cast<uint32_t*>(s_stage + 32 * kStageTask);
     s_first[(lane & 7u) * 8u + (lane >> 3)] = t.active ? t.rec0 : rec_first;     // idle lanes: any record that exists
@@ -265,7 +280,7 @@ __device__ __forceinline__ void fill_windows(const uint4* __restrict__ recs, con
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         // loads return in order: with at most four in flight the first four have landed
-        if (h == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : : "memory");
+        if (h == 0) asm volatile("s_waitcnt vmcnt(4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(touched) : : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : : "memory");
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -351,7 +366,8 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
             if (t.active) slot_load(recs, rec_index(n), R[n]);
         }
 #else
-        fill_windows(recs, t, rec_first, s_stage, R[0], R[1], R[2], R[3]);
+        uint32_t touched = 0;          // (no loads of this pass are in flight yet)
+        fill_windows(recs, t, rec_first, s_stage, R[0], R[1], R[2], R[3], touched);
 #endif
 #pragma unroll
         for (int n = 4; n < S; ++n) {
@@ -414,6 +430,14 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
             }
         }
     };
+#ifdef LBAD_SLIDE_PROF
+    // (profiling build) wait for the fill here so that its duration can be read off
+#pragma unroll
+    for (int n = 0; n < S; ++n) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(R[n].lo), "+v"(R[n].hi) : : "memory");
+    LBAD_PROF_T(q1);
+    LBAD_PROF_ADD(4, q0, q1);
+    if ((threadIdx.x & 63u) == 0) s_slide_prof[threadIdx.x >> 6][15] = q1 - q0;
+#endif
     QStep qn;
 #pragma unroll
     for (int w = 0; w < 4; ++w) qn.nz[w] = 0;
@@ -548,14 +572,21 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
                     const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(s_cursor);
                     const uint32_t left = seen < run_end ? run_end - seen : 0u;
                     const uint32_t least = MODE_B ? a.dense_b : a.dense_a;
-                    size = left / (2u * kScanWaves);
+                    size = left / (LBAD_CLAIM_DIV * kScanWaves);
                     size = size < least ? least : size;
-                    size = size < 8u ? 8u : (size > 4096u ? 4096u : size);
+                    size = size < LBAD_CLAIM_MIN ? LBAD_CLAIM_MIN : (size > 4096u ? 4096u : size);
                     c0 = atomicAdd(s_cursor, size);
                 }
                 c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
                 size = (uint32_t)__builtin_amdgcn_readfirstlane((int)size);
-                if (c0 >= run_end) { more = false; break; }
+                if (c0 >= run_end) {
+                    if (!MODE_B) {
+                        LBAD_STAMP(1, __builtin_amdgcn_s_memrealtime());
+                        LBAD_STAMP(4, total - done);
+                    }
+                    more = false;
+                    break;
+                }
                 cur = c0;
                 cur_end = run_end - c0 < size ? run_end : c0 + size;
             }
@@ -614,8 +645,14 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         // ---- one pass over the next 64 tasks ------------------------------------------------------------------
         Task t;
         const uint32_t tid = done + lane;
-        t.active = tid < total;
-        const uint32_t key_t = t.active ? tid : total - 1u;
+#ifdef LBAD_EXP_SLIDE_PARTIAL
+        // (experiment) every pass takes at most LBAD_EXP_SLIDE_PARTIAL tasks: are partly filled passes slow by themselves?
+        const uint32_t pass_tasks = total - done < LBAD_EXP_SLIDE_PARTIAL ? total - done : LBAD_EXP_SLIDE_PARTIAL;
+#else
+        const uint32_t pass_tasks = total - done < 64u ? total - done : 64u;
+#endif
+        t.active = lane < pass_tasks;
+        const uint32_t key_t = t.active ? tid : done + pass_tasks - 1u;
         uint32_t lo = 0, hi = n_slots;                       // s_start[lo] <= key_t < s_start[hi]
 #pragma unroll
         for (int it = 0; it < 7; ++it) {
@@ -637,8 +674,31 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         else if (MODE_B) t.feeder = t.active && (tl == 0u || lane == 0u);
         else t.feeder = t.active && (t.o0 + 4u >= t.n_off || lane == 63u);
         float acc[4];
+#ifdef LBAD_SLIDE_PROBE
+        {   // (profiling build) one timed load of a line nobody has touched lately: the memory latency at this moment
+            const uint32_t far_rec = (uint32_t)(((uint64_t)t.rec0 * 2654435761ull + 12345ull) % (uint64_t)p.off[a.n_entries]);
+            const unsigned long long m0 = __builtin_readcyclecounter();
+            const uint32_t pv = *(reinterpret_cast<const volatile uint32_t*>(p.recs + 2 * (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)far_rec)));
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(pv) : "memory");
+            const unsigned long long m1 = __builtin_readcyclecounter();
+            // ... and of a line that is in the L2 for sure (the offsets of this wave's entries, just read by the refill)
+            const uint32_t pw = *(reinterpret_cast<const volatile uint32_t*>(p.off + (uint32_t)__builtin_amdgcn_readfirstlane((int)t.ent)));
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(pw) : "memory");
+            const unsigned long long m2 = __builtin_readcyclecounter();
+            // ... and a SCALAR load of a line of the query block (scalar cache / L2, not the vector memory path)
+            uint32_t sv;
+            const uint32_t* sp = p.q + ((uint32_t)__builtin_amdgcn_readfirstlane((int)(t.ent & 15u)) * 16u);
+            asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(sv) : "s"(sp) : "memory");
+            const unsigned long long m3 = __builtin_readcyclecounter();
+            if (lane == 0) s_slide_prof[threadIdx.x >> 6][12] = (m1 - m0) | ((m2 - m1) << 32);
+            if (lane == 0) s_slide_prof[threadIdx.x >> 6][11] = (m3 - m2) + (sv == 0x1234567u ? 1u : 0u);
+        }
+#endif
         LBAD_PROF_T(p2);
         LBAD_PROF_ADD(1, p1, p2);
+#ifdef LBAD_SLIDE_PROF
+        const unsigned long long r2 = __builtin_amdgcn_s_memrealtime();
+#endif
         // Top-1 scans: a strong match (score >= kPruneFrom) found by ANY wave is published in the scan's result word at once;
         // every wave looks at that word before a pass and lets run_pass give up a pass that cannot reach it (an upper bound:
         // exact -- nothing that could win or tie is dropped; per-entry scores are never asked for together with this).
@@ -652,8 +712,25 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         const bool alive = run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc, stop_below, s_stage);
         LBAD_PROF_T(p3);
         LBAD_PROF_ADD(2, p2, p3);
+#ifdef LBAD_SLIDE_PROF
+        if (!MODE_B && lane == 0 && blockIdx.x < 256) {
+            const uint32_t wv = blockIdx.x * kScanWaves + (threadIdx.x >> 6);
+            const uint32_t ord = (uint32_t)g_slide_times[wv * 8 + 7];
+            if (ord < 64) {
+                g_slide_passes[(wv * 64 + ord) * 4] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                g_slide_passes[(wv * 64 + ord) * 4 + 1] = (uint32_t)(p3 - p2);
+                g_slide_passes[(wv * 64 + ord) * 4 + 2] = (uint32_t)(s_slide_prof[threadIdx.x >> 6][12] >> 32) | ((uint32_t)s_slide_prof[threadIdx.x >> 6][11] << 16);
+                g_slide_passes[(wv * 64 + ord) * 4 + 3] = (uint32_t)s_slide_prof[threadIdx.x >> 6][12];
+            }
+            g_slide_times[wv * 8 + 7] = ord + 1;
+        }
+        if (!MODE_B && !more && lane == 0) {
+            g_slide_times[(blockIdx.x * kScanWaves + (threadIdx.x >> 6)) * 8 + 5] += 1;
+            g_slide_times[(blockIdx.x * kScanWaves + (threadIdx.x >> 6)) * 8 + 6] += p3 - p2;
+        }
+#endif
         LBAD_PROF_ADD(5, 0ull, 1ull);
-        done = done + 64u < total ? done + 64u : total;
+        done += pass_tasks;
 #ifdef LBAD_SLIDE_DEBUG
         if (t.active)
             printf("wg %u wave %u mode %d lane %u ent %u ne %u o0 %u n_off %u rec0 %u feeder %d acc %g %g %g %g total %u n_slots %u\n",
@@ -720,7 +797,7 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     if (lane < 16) s_slide_prof[wave][lane] = 0ull;
 #endif
     LBAD_PROF_T(k0);
-#ifdef LBAD_SLIDE_PROF
+#if defined(LBAD_SLIDE_PROF) || defined(LBAD_SLIDE_STAMPS)
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // Two of the sixteen waves take the B entries first, the others the A entries; whoever runs out moves on to the
@@ -730,6 +807,8 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     if (b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     best = scan_mode<false, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[0], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     LBAD_PROF_T(k1);
+    LBAD_STAMP(0, rt0);
+    LBAD_STAMP(2, __builtin_amdgcn_s_memrealtime());
     if (!b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     LBAD_PROF_T(k2);
     LBAD_PROF_ADD(6, k0, k1);
@@ -744,11 +823,27 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     }
     if (lane < 10 || lane == 13 || lane == 14) atomicAdd(&g_slide_prof[lane], s_slide_prof[wave][lane]);
 #endif
+    LBAD_STAMP(3, __builtin_amdgcn_s_memrealtime());
 #pragma unroll
     for (int off2 = 32; off2 > 0; off2 >>= 1) {
         const unsigned long long o = __shfl_xor(best, off2, 64);
         best = o > best ? o : best;
     }
+#ifdef LBAD_EXP_SLIDE_KEEPWARM
+    // (experiment) waves that are done keep the CU's memory path busy with loads that hit until the whole workgroup is done
+    if (lane == 0) atomicAdd(&s_cursor[0][1], 0x10000u);            // (the run's end is no longer needed: a counter of finished waves above it)
+    {
+        uint32_t spin = 0, sink = 0;
+        while ((*reinterpret_cast<volatile uint32_t*>(&s_cursor[0][1]) >> 16) - (starts_a[blockIdx.x + 1] >> 16) < (uint32_t)kScanWaves && spin < 200000u) {
+            sink += *reinterpret_cast<const volatile uint32_t*>(off + ((spin * 64u + lane) & 1023u));
+            ++spin;
+        }
+        if (sink == 0x12345u) best ^= 1ull;
+    }
+#endif
+#ifdef LBAD_EXP_SLIDE_NOBARRIER
+    if (lane == 0 && best) atomicMax(key_out, best);
+#else
     if (lane == 0) s_k[wave] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -756,6 +851,7 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
         for (int i = 1; i < kScanWaves; ++i) m = s_k[i] > m ? s_k[i] : m;
         if (m) atomicMax(key_out, m);
     }
+#endif
 }
 
 // ---- the plan of a query length: where every workgroup's run of entries starts ---------------------------------------
@@ -1378,7 +1474,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     a.rm[0] = rm.x; a.rm[1] = rm.y; a.rm[2] = rm.z; a.rm[3] = rm.w;
     auto dense = [&](uint64_t tasks) -> uint32_t {
         if (tasks == 0) return 8u;
-        const uint64_t e = (128ull * n_entries + tasks - 1) / tasks;
+        const uint64_t e = (64ull * LBAD_CLAIM_PASSES * n_entries + tasks - 1) / tasks;
         return (uint32_t)(e < 8ull ? 8ull : (e > 4096ull ? 4096ull : e));
     };
     a.dense_a = dense(tasks_a);
@@ -1404,7 +1500,20 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     return hipGetLastError();
 }
 
+#if defined(LBAD_SLIDE_PROF) || defined(LBAD_SLIDE_STAMPS)
+extern "C" int LBAudioDetectiveDebugSlideTimes(unsigned long long* out, int n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slide_times), sizeof(unsigned long long) * (size_t)n_words) == hipSuccess ? 0 : 1;
+}
+extern "C" int LBAudioDetectiveDebugSlideTimesReset() {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_slide_times)) != hipSuccess) return 1;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 1024 * 16 * 8) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef LBAD_SLIDE_PROF
+extern "C" int LBAudioDetectiveDebugSlidePasses(unsigned int* out, int n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_slide_passes), sizeof(unsigned int) * (size_t)n_words) == hipSuccess ? 0 : 1;
+}
 extern "C" int LBAudioDetectiveDebugSlideProfile(unsigned long long* out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_slide_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
     if (reset) {
