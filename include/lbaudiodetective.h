@@ -458,6 +458,13 @@ void LBAudioDetectiveSetExchangeTimeout(UInt32 inMilliseconds);
  * the full scan's (LBAudioDetectiveTests.m:57-91 keeps the best match only).  On by default; 0 switches it off (every
  * offset of every entry is evaluated, as when scores are requested). */
 OSStatus LBAudioDetectiveCorpusSetBoundPruning(LBAudioDetectiveCorpusRef inCorpus, UInt32 inEnabled);
+/* The score from which a match is published and bounds the rest of the scan (0 < score <= 1; default 0.7: unrelated
+ * fingerprints score 0.5 +- 0.03, LBAudioDetective essay p.43).  The bound and its margin: a group of offsets is given up
+ * when its largest sum so far + one point per remaining step < published score * query length * 0.999; with float32 sums of
+ * at most 8192 terms the rounding of the sums stays three orders of magnitude inside that margin (k_sliding.hip:
+ * kPruneMargin), longer queries are scanned without pruning. */
+OSStatus LBAudioDetectiveCorpusSetBoundPruningThreshold(LBAudioDetectiveCorpusRef inCorpus, Float32 inScore);
+Float32 LBAudioDetectiveCorpusGetBoundPruningThreshold(LBAudioDetectiveCorpusRef inCorpus);
 /* the corpus' own key block of a sharded query (LBAD_SHARD_KEYS words on the device, and its pinned host twin) */
 unsigned long long* LBAudioDetectiveCorpusShardKeysDevice(LBAudioDetectiveCorpusRef inCorpus);
 unsigned long long* LBAudioDetectiveCorpusShardKeysHost(LBAudioDetectiveCorpusRef inCorpus);
@@ -469,9 +476,12 @@ unsigned long long* LBAudioDetectiveCorpusShardKeysHost(LBAudioDetectiveCorpusRe
 OSStatus LBAudioDetectiveCommGetUniqueId(void* outUniqueId);
 OSStatus LBAudioDetectiveCommInitRank(void** outComm, SInt32 inNumberOfRanks, const void* inUniqueId, SInt32 inRank);
 OSStatus LBAudioDetectiveCommDestroy(void* inComm);
-/* Several queries against one pass over the corpus (the scan is HBM-bound: up to 8 queries share each
- * read of an entry).  Results are those of inCount separate LBAudioDetectiveCorpusQuery calls.  The
- * KeysDevice form writes inCount keys to the device pointer outKeys for a sharded max-reduction. */
+/* Several queries against one pass over the corpus -- the shape of the reference's own test, Q originals against N
+ * candidates (LBAudioDetectiveTests.m:57-91).  Uniform corpus: up to 8 queries share each read of an entry.  Ragged
+ * corpus (round 5): queries of ONE length share their passes over the records, four per launch (eight in the scan of short
+ * queries); a batch of mixed lengths runs one group per length.  Results are those of inCount separate
+ * LBAudioDetectiveCorpusQuery calls, bit for bit.  The KeysDevice form writes inCount keys to the device pointer
+ * outKeys for a sharded max-reduction. */
 OSStatus LBAudioDetectiveCorpusQueryBatch(LBAudioDetectiveCorpusRef inCorpus, const LBAudioDetectiveFingerprintRef* inQueries,
                                           UInt32 inCount, UInt32 inRange, SInt64* outIndices, Float32* outScores);
 OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef inCorpus,

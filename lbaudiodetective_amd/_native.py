@@ -147,6 +147,8 @@ _SIGNATURES = {
                                                                C.c_void_p, _P(SInt64), _P(Float32)]),
     "LBAudioDetectiveSetExchangeTimeout": (None, [UInt32]),
     "LBAudioDetectiveCorpusSetBoundPruning": (OSStatus, [Ref, UInt32]),
+    "LBAudioDetectiveCorpusSetBoundPruningThreshold": (OSStatus, [Ref, Float32]),
+    "LBAudioDetectiveCorpusGetBoundPruningThreshold": (Float32, [Ref]),
     "LBAudioDetectiveCorpusShardKeysDevice": (C.c_void_p, [Ref]),
     "LBAudioDetectiveCorpusShardKeysHost": (C.c_void_p, [Ref]),
     "LBAudioDetectiveCommGetUniqueId": (OSStatus, [C.c_void_p]),

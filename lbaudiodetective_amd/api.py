@@ -507,6 +507,15 @@ class Corpus:
         _check(self._L.LBAudioDetectiveCorpusSetBoundPruning(self._ref, 1 if enabled else 0), "CorpusSetBoundPruning")
         return self
 
+    def set_bound_pruning_threshold(self, score: float):
+        """The score from which a match is published and bounds the rest of a top-1 scan (default 0.7)."""
+        _check(self._L.LBAudioDetectiveCorpusSetBoundPruningThreshold(self._ref, float(score)), "CorpusSetBoundPruningThreshold")
+        return self
+
+    @property
+    def bound_pruning_threshold(self) -> float:
+        return float(self._L.LBAudioDetectiveCorpusGetBoundPruningThreshold(self._ref))
+
     @property
     def subfingerprint_total(self) -> int:
         return int(self._L.LBAudioDetectiveCorpusGetSubfingerprintTotal(self._ref))

@@ -3,6 +3,7 @@
 // against N candidates, strict '<', first maximum wins) to an HBM-resident database.
 #include "internal.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -24,16 +25,39 @@ OSStatus reserve_query(LBAudioDetectiveCorpus* c, size_t words) {
     return noErr;
 }
 
-// ragged corpus: the sliding scan of k_sliding.hip (any query length, any entry lengths).  The query block travels
-// through a ring of kQuerySlots pinned + device slots, one event per slot: a call waits only for the copy that used
-// its slot kQuerySlots queries ago (long done), not for the stream -- back-to-back queries leave no gap on the GPU.
+// ragged corpus: the sliding scan of k_sliding.hip (any query length, any entry lengths).  A launch's query blocks travel
+// through a ring of kQuerySlots pinned + device slots, one event per slot: a call waits only for the scan that used
+// its slot kQuerySlots launches ago (long done), not for the stream -- back-to-back queries leave no gap on the GPU.
+// Round 5: a single query of up to kSlideQueryArgSubs sub-fingerprints travels in the kernel's argument segment (no copy
+// node), the result words are cleared by the previous scan's last workgroup (no memset node), and up to four queries of
+// ONE length share a pass over the corpus (eight in the systolic scan of short queries).
 constexpr uint32_t kQuerySlots = 8;
+constexpr uint32_t kScanOutWords = 16;      // per slot: 8 running maxima, the ticket, padding
 
-OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
-                          uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
-    std::vector<uint32_t> block;
-    build_sliding_query(q->data.data(), q->count, c->subfp_len, range, block);
-    const size_t slot_words = (block.size() + 63) & ~(size_t)63;
+// tasks of either kind for queries of nq sub-fingerprints, from the histogram of entry lengths (Fp.m:123-136: an entry
+// longer than the query slides the query along itself, any other entry slides along the query)
+void ragged_tasks(const LBAudioDetectiveCorpus* c, uint64_t nq, uint64_t& tasks_a, uint64_t& tasks_b) {
+    tasks_a = tasks_b = 0;
+    for (const auto& kv : c->len_hist) {
+        const uint64_t ne = kv.first;
+        if (ne > nq) tasks_a += kv.second * ((ne - nq + 4) / 4);
+        else tasks_b += kv.second * ((nq - ne + 4) / 4);
+    }
+}
+
+// ONE launch: the n_q queries qs[0..n_q) (all of qs[0]->count sub-fingerprints), their keys to keys + pos[i]
+OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprintRef* qs, const uint32_t* pos, uint32_t n_q,
+                       uint32_t range, uint64_t index_base, float* d_scores, unsigned long long* keys, hipStream_t stream) {
+    const uint32_t nq = qs[0]->count;
+    const size_t block_words = ((size_t)nq + 1u) * 16u;
+    std::vector<uint32_t> block, all;
+    all.reserve(block_words * n_q);
+    for (uint32_t i = 0; i < n_q; ++i) {
+        build_sliding_query(qs[i]->data.data(), nq, c->subfp_len, range, block);
+        all.insert(all.end(), block.begin() + (block.size() - block_words), block.end());      // (without the header)
+    }
+    const bool in_args = n_q == 1 && nq <= kSlideQueryArgSubs && !sliding_short(nq, c->ne_max);
+    const size_t slot_words = (all.size() + 63) & ~(size_t)63;
     if (c->query_slot_words < slot_words) {               // (re)size the ring: everything that used it must be done
         for (hipEvent_t e : c->query_ev)
             if (e) LBAD_HIP(hipEventSynchronize(e));
@@ -42,47 +66,88 @@ OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFinge
         if (st != noErr) return st;
         c->query_slot_words = slot_words;
     }
+    if (!c->d_scan_out) {
+        LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scan_out), (size_t)kQuerySlots * kScanOutWords * 8));
+        LBAD_HIP(hipMemset(c->d_scan_out, 0, (size_t)kQuerySlots * kScanOutWords * 8));
+    }
     const uint32_t slot = (uint32_t)(c->query_seq++ % kQuerySlots);
     if (!c->query_ev[slot]) LBAD_HIP(hipEventCreateWithFlags(&c->query_ev[slot], hipEventDisableTiming));
     else LBAD_HIP(hipEventSynchronize(c->query_ev[slot]));
     uint32_t* h = c->h_query + (size_t)slot * c->query_slot_words;
     uint32_t* dq = c->d_query + (size_t)slot * c->query_slot_words;
-    std::memcpy(h, block.data(), block.size() * sizeof(uint32_t));
-    LBAD_HIP(hipMemcpyAsync(dq, h, block.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    LBAD_HIP(hipMemsetAsync(key_dst, 0, sizeof(unsigned long long), stream));
+    std::memcpy(h, all.data(), all.size() * sizeof(uint32_t));
+    if (!in_args) LBAD_HIP(hipMemcpyAsync(dq, h, all.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     if (d_scores) LBAD_HIP(hipMemsetAsync(d_scores, 0, c->count * sizeof(float), stream));
-    // groups of four sliding offsets the scan will run, from the histogram of entry lengths (Fp.m:123-136: an entry
-    // longer than the query slides the query along itself, any other entry slides along the query)
     uint64_t tasks_a = 0, tasks_b = 0;
-    for (const auto& kv : c->len_hist) {
-        const uint64_t ne = kv.first, nq = q->count;
-        if (ne > nq) tasks_a += kv.second * ((ne - nq + 4) / 4);
-        else tasks_b += kv.second * ((nq - ne + 4) / 4);
-    }
+    ragged_tasks(c, nq, tasks_a, tasks_b);
     if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return kLBAudioDetectiveArgumentInvalid;   // the plan counts in 32 bits
-    const SlideShape sh = sliding_shape(tasks_a, tasks_b);
+    const SlideShape sh = sliding_shape(tasks_a, tasks_b, n_q);
     // the plan of this query length: kept while the length and the entries stay (queries of one length are the rule)
-    if (c->count && !sliding_short(q->count, c->ne_max) &&
-        (c->plan_nq != q->count || c->plan_count != c->count || c->plan_grid != sh.grid)) {
-        if (c->plan_used) LBAD_HIP(hipEventSynchronize(c->plan_used));       // a scan on another stream may still read it
+    if (!sliding_short(nq, c->ne_max) && (c->plan_nq != nq || c->plan_count != c->count || c->plan_grid != sh.grid)) {
+        // scans on other streams may still read the old plan: every scan leaves its slot's event behind, and a slot is
+        // reused only after its event -- the eight events cover everything that can still be running
+        for (hipEvent_t e : c->query_ev)
+            if (e) LBAD_HIP(hipEventSynchronize(e));
         if (!c->plan_built) LBAD_HIP(hipEventCreateWithFlags(&c->plan_built, hipEventDisableTiming));
         c->plan_nq = 0;
-        LBAD_HIP(launch_sliding_plan(c->d_off, c->count, q->count, sh, c->d_plan, stream));
+        LBAD_HIP(launch_sliding_plan(c->d_off, c->count, nq, sh, c->d_plan, stream));
         LBAD_HIP(hipEventRecord(c->plan_built, stream));
         c->plan_stream = stream;
-        c->plan_nq = q->count; c->plan_count = c->count; c->plan_grid = sh.grid;
+        c->plan_nq = nq; c->plan_count = c->count; c->plan_grid = sh.grid;
     } else if (c->plan_built && c->plan_stream != stream) {
         LBAD_HIP(hipStreamWaitEvent(stream, c->plan_built, 0));
     }
+    SlideScan scan;
+    scan.d_queries = in_args ? nullptr : dq;
+    scan.h_query = in_args ? h : nullptr;
+    scan.n_q = n_q;
+    scan.d_acc = c->d_scan_out + (size_t)slot * kScanOutWords;
+    scan.d_ticket = reinterpret_cast<unsigned int*>(scan.d_acc + 8);
+    scan.d_keys = keys;
+    for (uint32_t i = 0; i < 8; ++i) scan.key_pos[i] = i < n_q ? pos[i] : 0u;
     LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, (uint32_t)(c->rec_capacity + kRecordSlack / 2),
-                                    tasks_a, tasks_b, sh, c->d_plan, c->subfp_len, dq, q->count, range, index_base,
-                                    reinterpret_cast<unsigned int*>(d_scores), key_dst, stream, c->bound_pruning));
-    if (!c->plan_used) LBAD_HIP(hipEventCreateWithFlags(&c->plan_used, hipEventDisableTiming));
-    LBAD_HIP(hipEventRecord(c->plan_used, stream));
-    // behind the SCAN, not just the copy: the slot's device half is read by the kernel, and the query that reuses the
-    // slot eight calls later may arrive on another stream
+                                    tasks_a, tasks_b, sh, c->d_plan, c->subfp_len, scan, nq, range, index_base,
+                                    reinterpret_cast<unsigned int*>(d_scores), stream, c->bound_pruning, c->prune_from));
+    // behind the SCAN, not just the copy: the slot's device half and its result words are the kernel's, and the launch
+    // that reuses the slot eight launches later may arrive on another stream
     LBAD_HIP(hipEventRecord(c->query_ev[slot], stream));
     return noErr;
+}
+
+// n queries against the ragged corpus, key i to keys[i]: queries of one length share launches
+OSStatus run_queries_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprintRef* qs, uint32_t n, uint32_t range,
+                            uint64_t index_base, float* d_scores, unsigned long long* keys, hipStream_t stream) {
+    if (c->count == 0) {                                   // nothing to scan: every key is "no match"
+        LBAD_HIP(hipMemsetAsync(keys, 0, (size_t)n * sizeof(unsigned long long), stream));
+        return noErr;
+    }
+    bool any_short = false;                                // the systolic scan of short queries max-es its keys in place
+    for (uint32_t i = 0; i < n; ++i) any_short = any_short || sliding_short(qs[i]->count, c->ne_max);
+    if (any_short) LBAD_HIP(hipMemsetAsync(keys, 0, (size_t)n * sizeof(unsigned long long), stream));
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return qs[x]->count < qs[y]->count; });
+    for (uint32_t at = 0; at < n;) {
+        uint32_t same = 1;
+        while (at + same < n && qs[order[at + same]]->count == qs[order[at]]->count) ++same;
+        while (same) {
+            const uint32_t g = d_scores ? 1u : sliding_queries_per_launch(qs[order[at]]->count, c->ne_max, same);
+            LBAudioDetectiveFingerprintRef group[8];
+            uint32_t pos[8];
+            for (uint32_t i = 0; i < g; ++i) { group[i] = qs[order[at + i]]; pos[i] = order[at + i]; }
+            OSStatus st = launch_ragged(c, group, pos, g, range, index_base, d_scores, keys, stream);
+            if (st != noErr) return st;
+            at += g;
+            same -= g;
+        }
+    }
+    return noErr;
+}
+
+OSStatus run_query_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerprint* q, uint32_t range,
+                          uint64_t index_base, float* d_scores, unsigned long long* key_dst, hipStream_t stream) {
+    LBAudioDetectiveFingerprintRef one = const_cast<LBAudioDetectiveFingerprint*>(q);
+    return run_queries_ragged(c, &one, 1, range, index_base, d_scores, key_dst, stream);
 }
 
 // stage the query on the device and launch the scan; key_dst is a device pointer
@@ -231,8 +296,8 @@ LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNew(UInt32 inSubfingerprintLengt
 
 LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusNewRagged(UInt32 inSubfingerprintLength, UInt64 inEntryCapacity,
                                                           UInt64 inSubfingerprintCapacity) {
-    if (inEntryCapacity == 0 || inEntryCapacity > 0xFFFF0000ull) return NULL;   // the key carries a 32-bit index (and the scan's claim cursor a little slack)
-    if (inSubfingerprintCapacity < inEntryCapacity || inSubfingerprintCapacity > 0xFFFFFF00ull) return NULL;
+    if (inEntryCapacity == 0 || inEntryCapacity > lbad::kMaxRaggedEntries) return NULL;   // the key carries a 32-bit index (and the scan's claim cursor a little slack)
+    if (inSubfingerprintCapacity < inEntryCapacity || inSubfingerprintCapacity > lbad::kMaxRaggedRecords) return NULL;
     if (!lbad::sliding_supported(inSubfingerprintLength)) return NULL;
     if (!lbad::device_ready()) {
         fprintf(stderr, "lbaudiodetective: no HIP device, cannot create a corpus\n");
@@ -319,9 +384,9 @@ OSStatus LBAudioDetectiveCorpusAppendRaggedPackedDevice(LBAudioDetectiveCorpusRe
 
 void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (!c) return;
-    if (c->plan_used) { (void)hipEventSynchronize(c->plan_used); (void)hipEventDestroy(c->plan_used); }
     if (c->plan_built) { (void)hipEventSynchronize(c->plan_built); (void)hipEventDestroy(c->plan_built); }
     if (c->d_plan) (void)hipFree(c->d_plan);
+    if (c->d_scan_out) (void)hipFree(c->d_scan_out);
     if (c->d_shard_keys) (void)hipFree(c->d_shard_keys);
     if (c->h_shard_keys) (void)hipHostFree(c->h_shard_keys);
     if (c->d_recs) (void)hipFree(c->d_recs);
@@ -424,6 +489,11 @@ OSStatus LBAudioDetectiveCorpusQueryBatchKeysDevice(LBAudioDetectiveCorpusRef c,
     for (UInt32 i = 0; i < inCount && all_fast; ++i)
         all_fast = inQueries[i] && lbad::planes_fast_supported(c->subfp_len, c->n_sub, inQueries[i]->count) &&
                    inQueries[i]->length == c->subfp_len;
+    if (c->ragged) {   // queries of one length share their passes over the records (k_sliding.hip)
+        for (UInt32 i = 0; i < inCount; ++i)
+            if (!inQueries[i] || inQueries[i]->length != c->subfp_len || inQueries[i]->count == 0) return kLBAudioDetectiveArgumentInvalid;
+        return lbad::run_queries_ragged(c, inQueries, inCount, inRange ? inRange : c->subfp_len, inIndexBase, nullptr, keys, stream);
+    }
     if (!all_fast) {   // shapes without the specialised scan: one pass per query
         for (UInt32 i = 0; i < inCount; ++i) {
             OSStatus st = lbad::run_query(c, inQueries[i], inRange, inIndexBase, nullptr, keys + i, stream);
@@ -526,7 +596,7 @@ LBAudioDetectiveCorpusRef load_ragged(FILE* f, long file_size, uint64_t capacity
     if (file_size < (long)sizeof(h) || std::fread(&h, sizeof(h), 1, f) != 1) return NULL;
     const bool old_layout = std::memcmp(h.magic, "LBADCRP2", 8) == 0;
     // untrusted header: the file must really hold what it announces before anything is allocated from it
-    if (!lbad::sliding_supported(h.subfp_len) || h.count > 0xFFFFFFFFull || h.n_pos > 0xFFFFFFFFull || h.n_pos < h.count)
+    if (!lbad::sliding_supported(h.subfp_len) || h.count > lbad::kMaxRaggedEntries || h.n_pos > lbad::kMaxRaggedRecords || h.n_pos < h.count)
         return NULL;
     if ((uint64_t)(file_size - (long)sizeof(h)) < h.count * 4 + h.n_pos * 32) return NULL;
     std::vector<uint32_t> counts;
@@ -538,11 +608,12 @@ LBAudioDetectiveCorpusRef load_ragged(FILE* f, long file_size, uint64_t capacity
         total += counts[e];
     }
     if (total != h.n_pos) return NULL;
-    const uint64_t cap = capacity > h.count ? capacity : (h.count ? h.count : 1);
+    uint64_t cap = capacity > h.count ? capacity : (h.count ? h.count : 1);
+    if (cap > lbad::kMaxRaggedEntries) cap = lbad::kMaxRaggedEntries;           // (NewRagged's own limits: a large request is clamped, not refused)
     // room for records in proportion to the entry capacity
-    uint64_t rec_cap = h.count ? (h.n_pos * cap + h.count - 1) / h.count : cap * 64;
+    uint64_t rec_cap = h.count ? (uint64_t)(((unsigned __int128)h.n_pos * cap + h.count - 1) / h.count) : cap * 64;
     if (rec_cap < cap) rec_cap = cap;
-    if (rec_cap > 0xFFFFFFFFull) rec_cap = 0xFFFFFFFFull;
+    if (rec_cap > lbad::kMaxRaggedRecords) rec_cap = lbad::kMaxRaggedRecords;
     LBAudioDetectiveCorpusRef c = LBAudioDetectiveCorpusNewRagged(h.subfp_len, cap, rec_cap);
     if (!c) return NULL;
     bool ok = true;
@@ -700,5 +771,13 @@ OSStatus LBAudioDetectiveCorpusSetBoundPruning(LBAudioDetectiveCorpusRef c, UInt
     c->bound_pruning = inEnabled != 0;
     return noErr;
 }
+
+OSStatus LBAudioDetectiveCorpusSetBoundPruningThreshold(LBAudioDetectiveCorpusRef c, Float32 inScore) {
+    if (!c || !(inScore > 0.0f) || !(inScore <= 1.0f)) return kLBAudioDetectiveArgumentInvalid;
+    c->prune_from = inScore;
+    return noErr;
+}
+
+Float32 LBAudioDetectiveCorpusGetBoundPruningThreshold(LBAudioDetectiveCorpusRef c) { return c ? c->prune_from : 0.0f; }
 
 }  // extern "C"

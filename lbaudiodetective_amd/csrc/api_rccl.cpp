@@ -150,6 +150,17 @@ OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef i
     if (inCount == 0 || !inAllReduce) return kLBAudioDetectiveArgumentInvalid;      // (the same on every rank, or a caller's bug)
     hipStream_t stream = static_cast<hipStream_t>(inStream);
     OSStatus first_error = noErr;
+    // the key block is ONE per corpus: two threads with sharded queries on the same corpus take turns (round-4 advice)
+    std::unique_lock<std::mutex> keys_lock;
+    if (inCorpus) keys_lock = std::unique_lock<std::mutex>(inCorpus->shard_lock);
+    if (inCorpus && inCorpus->shard_stale) {
+        // an earlier call gave up waiting: its copy and its collective may still be queued behind the block -- they must
+        // have drained before the block is written again (this wait has the same deadline; a stream that is still stuck
+        // fails the call, on every rank alike)
+        OSStatus drained = lbad::wait_with_deadline(inCorpus->shard_stale_stream);
+        if (drained != noErr) first_error = drained;
+        else inCorpus->shard_stale = false;
+    }
     for (UInt32 done = 0; done < inCount; done += lbad::kKeysPerExchange) {
         const UInt32 n = inCount - done < lbad::kKeysPerExchange ? inCount - done : lbad::kKeysPerExchange;
         unsigned long long* keys = inCorpus ? LBAudioDetectiveCorpusShardKeysDevice(inCorpus) : nullptr;
@@ -169,7 +180,10 @@ OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef i
         OSStatus st = keys ? inAllReduce(inContext, reinterpret_cast<UInt64*>(keys), n, stream) : kLBAudioDetectiveDeviceError;
         if (st == noErr && local == noErr)
             st = lbad::hip_status(hipMemcpyAsync(host, keys, (size_t)n * 8, hipMemcpyDeviceToHost, stream), "keys D2H", __LINE__);
-        if (st == noErr) st = lbad::wait_with_deadline(stream);
+        if (st == noErr) {
+            st = lbad::wait_with_deadline(stream);
+            if (st != noErr && inCorpus) { inCorpus->shard_stale = true; inCorpus->shard_stale_stream = stream; }
+        }
         if (st == noErr && local == noErr)
             for (UInt32 i = 0; i < n; ++i)
                 LBAudioDetectiveCorpusDecodeKey(host[i], outIndices ? outIndices + done + i : NULL, outScores ? outScores + done + i : NULL);

@@ -268,7 +268,23 @@ struct SlideShape {
     uint32_t grid = 0, chunk_a = 0, chunk_b = 0;
 };
 constexpr uint32_t kSlideMaxGrid = 1024;
-SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b);
+SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b, uint32_t n_q = 1);
+// how many of n_left queries of one length a single launch takes (1, 2, 4; 8 for the systolic scan of short queries)
+uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t n_left);
+// One launch of the scan: n_q queries of one length.  d_queries: their blocks (build_sliding_query without the header),
+// (n_query + 1) * 16 words each, on the device; h_query: the same block of a single query on the host -- short enough it
+// travels in the kernel's arguments and d_queries may be null.  d_acc (n_q words) and d_ticket are zero between scans
+// (the scan leaves them so); d_keys receives the n_q results.
+struct SlideScan {
+    const uint32_t* d_queries = nullptr;
+    const uint32_t* h_query = nullptr;
+    uint32_t n_q = 1;
+    unsigned long long* d_acc = nullptr;
+    unsigned int* d_ticket = nullptr;
+    unsigned long long* d_keys = nullptr;
+    uint32_t key_pos[8] = {};     // query i's key goes to d_keys[key_pos[i]]
+};
+constexpr uint32_t kSlideQueryArgSubs = 47;   // longest query that travels as a kernel argument
 size_t sliding_plan_words(uint64_t capacity);
 // the plan of a query length (where every workgroup's run of entries starts) into d_plan
 hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, const SlideShape& sh, uint32_t* d_plan,
@@ -278,9 +294,12 @@ hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32
 bool sliding_short(uint32_t n_query, uint32_t ne_max);    // the systolic scan of short queries applies (no plan needed)
 hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries, uint32_t ne_max,
                                   uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
-                                  uint32_t subfp_len, const uint32_t* d_query, uint32_t n_query, uint32_t range,
-                                  uint64_t index_base, unsigned int* d_score_bits, unsigned long long* d_key,
-                                  hipStream_t stream, bool bound_pruning = true);
+                                  uint32_t subfp_len, const SlideScan& scan, uint32_t n_query, uint32_t range,
+                                  uint64_t index_base, unsigned int* d_score_bits, hipStream_t stream, bool bound_pruning = true,
+                                  float prune_from = 0.7f);
+// limits of a ragged corpus (the key carries a 32-bit index, the scan's claim cursor and its record offsets want a little slack)
+constexpr uint64_t kMaxRaggedEntries = 0xFFFF0000ull;
+constexpr uint64_t kMaxRaggedRecords = 0xFFFFFF00ull;
 constexpr uint32_t kRecordSlack = 8;   // records allocated behind a ragged corpus' capacity (zero: over-read + the zero record)
 
 // measurement: ticks of the shader clock and of the constant 100 MHz clock over ~usec microseconds (2 words)
@@ -431,9 +450,9 @@ struct LBAudioDetectiveCorpus {
     uint32_t* d_plan = nullptr;
     uint32_t plan_nq = 0, plan_grid = 0;
     bool bound_pruning = true;     // top-1 scans of a ragged corpus may drop passes that cannot reach the best match so far (exact)
+    float prune_from = 0.7f;       // ... once a match of at least this score is known (LBAudioDetectiveCorpusSetBoundPruningThreshold)
     uint64_t plan_count = 0;
     hipEvent_t plan_built = nullptr;             // behind the plan's kernels, on plan_stream
-    hipEvent_t plan_used = nullptr;              // behind the latest scan that read the plan
     hipStream_t plan_stream = nullptr;
     // key block of the sharded query (api_rccl.cpp), made with the corpus so that the collective call never allocates
     unsigned long long* d_shard_keys = nullptr;
@@ -441,5 +460,11 @@ struct LBAudioDetectiveCorpus {
     // ring of query slots in h_query / d_query (ragged scan): slot size in words, one event per slot, queries so far
     size_t query_slot_words = 0;
     hipEvent_t query_ev[8] = {};
+    // per ring slot: the scan's running maxima (8 words) and its ticket, ZERO between scans -- the scan's last workgroup
+    // leaves them so (k_sliding.hip: ScanOut); 16 words per slot
+    unsigned long long* d_scan_out = nullptr;
+    std::mutex shard_lock;                       // the sharded query's key block is one per corpus (api_rccl.cpp)
+    bool shard_stale = false;                    // a sharded query timed out: work may still be queued behind the key block
+    hipStream_t shard_stale_stream = nullptr;
     uint64_t query_seq = 0;
 };

@@ -76,7 +76,15 @@ constexpr uint32_t kSlots = 128;      // queue slots per wave (at most 63 left o
 #define LBAD_CLAIM_PASSES 2u       // ... but at least this many passes' worth of entries
 #define LBAD_CLAIM_MIN 8u
 #endif
-constexpr float kPruneFrom = 0.7f;    // top-1 scans: matches from this score on are published and bound the passes that follow
+// Bound pruning of top-1 scans.  A pass is given up once, for every lane, T = fl(top + n) < stop_below = fl(fl(bs nq) kPruneMargin),
+// top = the lane's largest sum so far, n = steps still to come, bs = the best score published.  Why nothing that could win
+// or tie is lost: with u = 2^-24, n more float additions of terms <= 1 end at S <= (top + n) (1 + u)^n <= T (1 + (n + 2) u),
+// and an entry matters only if fl(S / nq) >= bs, i.e. S >= bs nq (1 - u).  T < bs nq kPruneMargin (1 + 2 u) therefore
+// drops nothing as long as kPruneMargin (1 + 2 u) (1 + (n + 2) u) <= 1 - u, which 0.999 satisfies for (n + 5) u <= 0.001:
+// queries of up to 16 000 sub-fingerprints (the launcher switches the pruning off beyond kPruneMaxQuery).
+constexpr uint32_t kPassSpan = 1u << 26;      // records an "A" pass may span: 32-bit byte offsets inside it stay below 2^31
+constexpr float kPruneMargin = 0.999f;
+constexpr uint32_t kPruneMaxQuery = 8192;
 
 __device__ __forceinline__ unsigned long long sl_key(float score, uint64_t global_index) {
     return ((unsigned long long)__float_as_uint(score) << 32) |
@@ -100,6 +108,24 @@ struct SlideArgs {                // the scalars of a scan (the pointers are ker
     uint32_t rm[4];               // RANGE over pair bits
     uint32_t dense_a, dense_b;    // entries that hold about 128 tasks of a kind (two passes): the least a wave claims
     uint32_t prune;               // 1: a top-1 scan (no per-entry scores wanted) may drop passes that cannot reach the best match so far
+    float prune_from;             // ... once a match of at least this score has been published (CorpusSetBoundPruningThreshold)
+    uint32_t q_in_args;           // 1: the query block travels in the kernel's argument segment (QueryArg), not through d_query
+};
+
+// A query of up to kSlideQueryArgSubs sub-fingerprints fits the kernel's argument segment (4 KB): no copy to the device, one
+// node less on the stream in front of every scan.
+struct QueryArg {
+    uint32_t w[(kSlideQueryArgSubs + 1) * 16];
+};
+
+// Where a scan leaves its result.  acc: n_keys words that are ZERO between scans (the scan's running maxima, also what a
+// strong match is published through while the scan runs); ticket: workgroups that have finished; the last one moves acc to
+// keys and clears both -- no memset in front of the scan.
+struct ScanOut {
+    unsigned long long* acc;
+    unsigned int* ticket;
+    unsigned long long* keys;
+    uint32_t pos[8];              // query i's key goes to keys[pos[i]]
 };
 
 struct SlidePtrs {
@@ -307,6 +333,10 @@ __device__ __forceinline__ void fill_windows(const uint4* __restrict__ recs, con
 #define LBAD_SLIDE_RING 6
 #endif
 constexpr int kRing = LBAD_SLIDE_RING;        // record slots per lane: the 4 of the window + kRing - 4 fetched ahead
+#ifndef LBAD_SLIDE_RING_MULTI
+#define LBAD_SLIDE_RING_MULTI 5
+#endif
+constexpr int kRingMulti = LBAD_SLIDE_RING_MULTI;   // the same for passes of several queries (their steps are longer)
 
 // One pass: 64 tasks, nq steps.  R is the lane's ring of S = kRing record slots.
 //   A: slot n % S holds the record of relative index n (records o0 + n of the entry); step i uses n = i + k for the
@@ -321,14 +351,19 @@ constexpr int kRing = LBAD_SLIDE_RING;        // record slots per lane: the 4 of
 // The step's query sub-fingerprint comes from LDS (QLDS: two ds_read_b128 per step, the same address in every lane)
 // rather than from scalar registers: a vector instruction with a scalar operand issues at the slow rate on this chip
 // (v_bitop3_b32 1.85 ns against 1.13 ns per SIMD, tools/ubench/slide_rates.hip), and the step has 32 of them.
-template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
+// QN queries of ONE length in a pass (round 5): the records travel, are fetched and have their table row extracted once;
+// a step compares the four window records with sub-fingerprint i of every query (LDS: query qi at s_q + qi (nq + 1)
+// kQWords) and a lane keeps 4 QN sums.  QN = 1 is the single scan with its one-step-late table adds; for QN > 1 the
+// other queries' arithmetic covers the look-ups.
+template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS, int QN>
 // stop_below (A passes of a top-1 scan, else 0): once every lane's best sum so far plus one whole point per step still to
 // come stays under it, nothing in this pass can reach the best match known -- the pass ends and returns false (its sums
 // are then meaningless).
 __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __restrict__ recs, const uint32_t* __restrict__ q,
-                                         const uint32_t* s_q, const Task& t, const float* s_tri, float (&acc)[4],
+                                         const uint32_t* s_q, const Task& t, const float* s_tri, float (&acc)[QN][4],
                                          const float stop_below, uint4* s_stage) {
-    constexpr int S = kRing;
+    static_assert(QN == 1 || QLDS, "several queries in a pass are read from LDS");
+    constexpr int S = QN > 1 ? kRingMulti : kRing;
     constexpr int D = S - 4;
     static_assert(S >= 5 && S <= 8, "ring of 5..8 slots");
     Slot R[S];
@@ -394,9 +429,11 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
 #pragma unroll
         for (int n = 1; n <= D; ++n) slot_load_masked(recs, rec_index(n), feeders, R[mod(n)]);
     }
-    float pend[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // the previous step's quotients: added one step late, their LDS latency hidden
+    float pend[4] = {0.0f, 0.0f, 0.0f, 0.0f};   // (QN = 1) the previous step's quotients: added one step late, their LDS latency hidden
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = 0.0f;
+    for (int qi = 0; qi < QN; ++qi)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[qi][k] = 0.0f;
     // every slot is "used" here, in front of the loop: the compiler places the waits for the loads above HERE and not
     // at their first use inside the loop (where a wait would drain the step loop's own loads every S steps)
 #pragma unroll
@@ -407,15 +444,17 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
     struct QStep {
         uint32_t v[8], nz[4], row;
     };
-    auto fetch_q = [&](uint32_t i, QStep& o) {
+    const uint32_t q_stride = (nq + 1u) * kQWords;            // words from a query to the next one
+    auto fetch_q = [&](uint32_t i, QStep& o, int qi = 0) {
         if (QLDS) {
-            const uint4* ql = reinterpret_cast<const uint4*>(s_q + (size_t)i * kQWords);
+            const uint32_t* sq = s_q + (size_t)qi * q_stride + (size_t)i * kQWords;
+            const uint4* ql = reinterpret_cast<const uint4*>(sq);
             const uint4 q0 = ql[0], q1 = ql[1];
             o.v[0] = q0.x; o.v[1] = q0.y; o.v[2] = q0.z; o.v[3] = q0.w; o.v[4] = q1.x; o.v[5] = q1.y; o.v[6] = q1.z; o.v[7] = q1.w;
             if (MODE_B) {
                 const uint4 q2 = ql[2];
                 o.nz[0] = q2.x; o.nz[1] = q2.y; o.nz[2] = q2.z; o.nz[3] = q2.w;
-                o.row = s_q[(size_t)i * kQWords + 12];
+                o.row = sq[12];
             }
         } else {
             const uint32_t* __restrict__ qa = q + (size_t)i * kQWords;
@@ -442,33 +481,53 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
 #pragma unroll
     for (int w = 0; w < 4; ++w) qn.nz[w] = 0;
     qn.row = 0;
-    fetch_q(0, qn);
+    if (QN == 1) fetch_q(0, qn);
     // one step; u = i % S is a compile-time constant (the ring's slots are registers)
     auto step = [&](const int u, const uint32_t i) {
-        const QStep qc = qn;
-#ifndef LBAD_EXP_SLIDE_NOQ
-        fetch_q(i + 1u, qn);                                    // (one sub-fingerprint of slack behind the query)
-#endif
         if (!MODE_B) {
             uint32_t w[8];
             slot_words(R[(u + 3) % S], w);
             row[(u + 3) % S] = record_row<FULL>(w, rm);
         }
-        uint32_t h[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t w[8];
-            slot_words(R[MODE_B ? mod(u - k) : (u + k) % S], w);
-            h[k] = pair_index<MODE_B, FULL>(w, qc.v, qc.nz, MODE_B ? qc.row : row[(u + k) % S], rm);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[k] = __fadd_rn(acc[k], pend[k]);                // step i - 1's term (0.0 in front of the first)
-#ifdef LBAD_EXP_SLIDE_NOTRI
-            pend[k] = __uint_as_float(h[k]);
-#else
-            pend[k] = s_tri[h[k]];
+        if constexpr (QN == 1) {
+            const QStep qc = qn;
+#ifndef LBAD_EXP_SLIDE_NOQ
+            fetch_q(i + 1u, qn);                                // (one sub-fingerprint of slack behind the query)
 #endif
+            uint32_t h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t w[8];
+                slot_words(R[MODE_B ? mod(u - k) : (u + k) % S], w);
+                h[k] = pair_index<MODE_B, FULL>(w, qc.v, qc.nz, MODE_B ? qc.row : row[(u + k) % S], rm);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc[0][k] = __fadd_rn(acc[0][k], pend[k]);      // step i - 1's term (0.0 in front of the first)
+#ifdef LBAD_EXP_SLIDE_NOTRI
+                pend[k] = __uint_as_float(h[k]);
+#else
+                pend[k] = s_tri[h[k]];
+#endif
+            }
+        } else {
+#pragma unroll
+            for (int qi = 0; qi < QN; ++qi) {
+                QStep qc;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) qc.nz[w] = 0;
+                qc.row = 0;
+                fetch_q(i, qc, qi);
+                uint32_t h[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t w[8];
+                    slot_words(R[MODE_B ? mod(u - k) : (u + k) % S], w);
+                    h[k] = pair_index<MODE_B, FULL>(w, qc.v, qc.nz, MODE_B ? qc.row : row[(u + k) % S], rm);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[qi][k] = __fadd_rn(acc[qi][k], s_tri[h[k]]);    // in step order (Fp.m:139-142)
+            }
         }
         // the window moves on: the record fetched D steps ago has landed by now
 #ifdef LBAD_SLIDE_PROF_STEP
@@ -509,8 +568,8 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
     for (; i0 + (uint32_t)S <= nq; i0 += (uint32_t)S) {
 #pragma unroll
         for (int u = 0; u < S; ++u) step(u, i0 + (uint32_t)u);
-        if (!MODE_B && stop_below > 0.0f) {                     // (uniform) a ratio is at most 1: an upper bound of every sum
-            const float top = fmaxf(fmaxf(acc[0] + pend[0], acc[1] + pend[1]), fmaxf(acc[2] + pend[2], acc[3] + pend[3]));
+        if (QN == 1 && !MODE_B && stop_below > 0.0f) {          // (uniform) a ratio is at most 1: an upper bound of every sum
+            const float top = fmaxf(fmaxf(acc[0][0] + pend[0], acc[0][1] + pend[1]), fmaxf(acc[0][2] + pend[2], acc[0][3] + pend[3]));
             if (!__any(t.active && top + (float)(nq - (i0 + (uint32_t)S)) >= stop_below)) { alive = false; break; }
         }
     }
@@ -519,8 +578,10 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
         for (int u = 0; u < S - 1; ++u)
             if (i0 + (uint32_t)u < nq) step(u, i0 + (uint32_t)u);   // uniform
     }
+    if (QN == 1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = __fadd_rn(acc[k], pend[k]);
+        for (int k = 0; k < 4; ++k) acc[0][k] = __fadd_rn(acc[0][k], pend[k]);
+    }
     // Nothing of this pass may still be in flight when the ring's registers are reused.  The wait NAMES every slot:
     // the compiler does not know that loads are on their way into them, sees the ring dead after the last step and
     // would otherwise hand its registers to the code that follows (scheduled in front of a wait without operands) --
@@ -548,10 +609,10 @@ __device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v, uint32_t lane
 // (16 k same-address atomics per scan: a fifth of a wave's time went into waiting for them, plus the tail of whoever
 // claimed last) and fully static shares per wave (no atomics at all, but waves that share a SIMD do not run at one
 // speed: the slowest needed 1.37 x the average and the rest of its SIMD idled meanwhile).
-template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS>
-__device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, const SlidePtrs& p, const float* s_tri, const uint32_t* s_q,
-                                                        uint32_t* s_cursor, uint32_t* s_start, uint32_t* s_off, uint32_t* s_ne,
-                                                        uint32_t* s_ent, uint4* s_stage, unsigned long long best) {
+template <bool MODE_B, bool FULL, bool ALL_FEED, bool QLDS, int QN, int WAVES>
+__device__ __forceinline__ void scan_mode(const SlideArgs& a, const SlidePtrs& p, const float* s_tri, const uint32_t* s_q,
+                                          uint32_t* s_cursor, uint32_t* s_start, uint32_t* s_off, uint32_t* s_ne,
+                                          uint32_t* s_ent, uint4* s_stage, unsigned long long (&best)[QN]) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nq = a.nq;
     const uint32_t run_end = s_cursor[1];
@@ -572,7 +633,7 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
                     const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(s_cursor);
                     const uint32_t left = seen < run_end ? run_end - seen : 0u;
                     const uint32_t least = MODE_B ? a.dense_b : a.dense_a;
-                    size = left / (LBAD_CLAIM_DIV * kScanWaves);
+                    size = left / (LBAD_CLAIM_DIV * (uint32_t)WAVES);
                     size = size < least ? least : size;
                     size = size < LBAD_CLAIM_MIN ? LBAD_CLAIM_MIN : (size > 4096u ? 4096u : size);
                     c0 = atomicAdd(s_cursor, size);
@@ -647,9 +708,9 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         const uint32_t tid = done + lane;
 #ifdef LBAD_EXP_SLIDE_PARTIAL
         // (experiment) every pass takes at most LBAD_EXP_SLIDE_PARTIAL tasks: are partly filled passes slow by themselves?
-        const uint32_t pass_tasks = total - done < LBAD_EXP_SLIDE_PARTIAL ? total - done : LBAD_EXP_SLIDE_PARTIAL;
+        uint32_t pass_tasks = total - done < LBAD_EXP_SLIDE_PARTIAL ? total - done : LBAD_EXP_SLIDE_PARTIAL;
 #else
-        const uint32_t pass_tasks = total - done < 64u ? total - done : 64u;
+        uint32_t pass_tasks = total - done < 64u ? total - done : 64u;
 #endif
         t.active = lane < pass_tasks;
         const uint32_t key_t = t.active ? tid : done + pass_tasks - 1u;
@@ -668,12 +729,25 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         t.n_off = MODE_B ? nq - t.ne + 1u : t.ne - nq + 1u;
         const uint32_t e_first = s_off[lo];
         t.rec0 = MODE_B ? e_first : e_first + t.o0;
+        if (!MODE_B) {
+            // run_pass addresses a lane's records as a wave-uniform base + a 32-bit byte offset.  The lanes of a pass are in
+            // entry order, but entries WITHOUT tasks of this kind (and entries other waves claimed) may lie between two of
+            // them -- in a corpus of more than 4 GiB a wave's left-over tasks and its next claim can be 2^27 records apart
+            // (round-4 advice).  A pass therefore takes only the leading tasks within kPassSpan records of its first one;
+            // the others stay queued and open the next pass.
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.rec0);
+            const uint32_t near = (uint32_t)__popcll(__ballot(t.active && t.rec0 - first < kPassSpan));
+            if (near < pass_tasks) {                         // (uniform; a prefix: the records ascend with the lanes)
+                pass_tasks = near;
+                t.active = lane < pass_tasks;
+            }
+        }
         // who reads memory: the lane whose neighbour cannot hand it the next record -- the entry's last (A) / first (B)
-        // task and the wave's edge lanes (an entry whose tasks lie in two passes)
+        // task and the pass's edge lanes (an entry whose tasks lie in two passes)
         if (ALL_FEED) t.feeder = t.active;
         else if (MODE_B) t.feeder = t.active && (tl == 0u || lane == 0u);
-        else t.feeder = t.active && (t.o0 + 4u >= t.n_off || lane == 63u);
-        float acc[4];
+        else t.feeder = t.active && (t.o0 + 4u >= t.n_off || lane + 1u == pass_tasks);
+        float acc[QN][4];
 #ifdef LBAD_SLIDE_PROBE
         {   // (profiling build) one timed load of a line nobody has touched lately: the memory latency at this moment
             const uint32_t far_rec = (uint32_t)(((uint64_t)t.rec0 * 2654435761ull + 12345ull) % (uint64_t)p.off[a.n_entries]);
@@ -703,13 +777,13 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
         // every wave looks at that word before a pass and lets run_pass give up a pass that cannot reach it (an upper bound:
         // exact -- nothing that could win or tie is dropped; per-entry scores are never asked for together with this).
         float stop_below = 0.0f;
-        if (!MODE_B && a.prune) {
+        if (QN == 1 && !MODE_B && a.prune) {
             const unsigned long long seen = __hip_atomic_load(p.key_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            best = seen > best ? seen : best;
-            const float bs = __uint_as_float((uint32_t)(best >> 32));
-            if (bs >= kPruneFrom) stop_below = bs * (float)nq * 0.999f;
+            best[0] = seen > best[0] ? seen : best[0];
+            const float bs = __uint_as_float((uint32_t)(best[0] >> 32));
+            if (bs >= a.prune_from) stop_below = bs * (float)nq * kPruneMargin;
         }
-        const bool alive = run_pass<MODE_B, FULL, ALL_FEED, QLDS>(a, p.recs, p.q, s_q, t, s_tri, acc, stop_below, s_stage);
+        const bool alive = run_pass<MODE_B, FULL, ALL_FEED, QLDS, QN>(a, p.recs, p.q, s_q, t, s_tri, acc, stop_below, s_stage);
         LBAD_PROF_T(p3);
         LBAD_PROF_ADD(2, p2, p3);
 #ifdef LBAD_SLIDE_PROF
@@ -734,30 +808,32 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
 #ifdef LBAD_SLIDE_DEBUG
         if (t.active)
             printf("wg %u wave %u mode %d lane %u ent %u ne %u o0 %u n_off %u rec0 %u feeder %d acc %g %g %g %g total %u n_slots %u\n",
-                   blockIdx.x, threadIdx.x >> 6, (int)MODE_B, lane, t.ent, t.ne, t.o0, t.n_off, t.rec0, (int)t.feeder, acc[0], acc[1],
-                   acc[2], acc[3], total, n_slots);
+                   blockIdx.x, threadIdx.x >> 6, (int)MODE_B, lane, t.ent, t.ne, t.o0, t.n_off, t.rec0, (int)t.feeder, acc[0][0], acc[0][1],
+                   acc[0][2], acc[0][3], total, n_slots);
 #endif
 
         // max over the task's offsets first, ONE exact division where the sum can still matter (Fp.m:144)
-        int m = -1;                                          // sums are >= 0: as integers their bits order like the floats
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (alive && t.active && t.o0 + (uint32_t)k < t.n_off) m = max(m, __float_as_int(acc[k]));
         const float n2f = (float)(MODE_B ? t.ne : nq);
-        const float thr = __uint_as_float((uint32_t)(best >> 32)) * 0.99999f;
-        const bool need = m >= 0 && (p.score_bits != nullptr || __int_as_float(m) >= thr * n2f);
-        if (need) {
-            const float cand = __fdiv_rn(__int_as_float(m), n2f);
-            const float match = (0.0f < cand) ? cand : 0.0f;                 // MAX(match, cand) from match = 0
-            if (p.score_bits) atomicMax(&p.score_bits[t.ent], __float_as_uint(match));
-            const unsigned long long key = sl_key(match, a.index_base + t.ent);
-            best = key > best ? key : best;
-            if (!MODE_B && a.prune && match >= kPruneFrom) atomicMax(p.key_out, key);      // (rare: only a real match gets here)
+#pragma unroll
+        for (int qi = 0; qi < QN; ++qi) {
+            int m = -1;                                      // sums are >= 0: as integers their bits order like the floats
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (alive && t.active && t.o0 + (uint32_t)k < t.n_off) m = max(m, __float_as_int(acc[qi][k]));
+            const float thr = __uint_as_float((uint32_t)(best[qi] >> 32)) * 0.99999f;
+            const bool need = m >= 0 && ((QN == 1 && p.score_bits != nullptr) || __int_as_float(m) >= thr * n2f);
+            if (need) {
+                const float cand = __fdiv_rn(__int_as_float(m), n2f);
+                const float match = (0.0f < cand) ? cand : 0.0f;             // MAX(match, cand) from match = 0
+                if (QN == 1 && p.score_bits) atomicMax(&p.score_bits[t.ent], __float_as_uint(match));
+                const unsigned long long key = sl_key(match, a.index_base + t.ent);
+                best[qi] = key > best[qi] ? key : best[qi];
+                if (QN == 1 && !MODE_B && a.prune && match >= a.prune_from) atomicMax(p.key_out, key);   // (rare: only a real match gets here)
+            }
         }
         LBAD_PROF_T(p4);
         LBAD_PROF_ADD(3, p3, p4);
     }
-    return best;
 }
 
 // the query in LDS (dynamic, 64 bytes per sub-fingerprint): up to kQueryLds sub-fingerprints; longer queries are read
@@ -765,20 +841,30 @@ __device__ __forceinline__ unsigned long long scan_mode(const SlideArgs& a, cons
 constexpr uint32_t kQueryLds = 480;
 
 // starts_a / starts_b: grid + 1 entry indices: workgroup g owns the entries [starts[g], starts[g + 1])
-template <bool FULL, bool ALL_FEED, bool QLDS>
-__global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kernel(
+// QN queries of one length per launch (1: the single scan, 1024 threads; 2, 4: 768 threads -- twelve waves leave a lane
+// the registers for 4 QN sums); q: QN blocks of (nq + 1) kQWords words (QN = 1: or qa, the same block as an argument).
+template <bool FULL, bool ALL_FEED, bool QLDS, int QN, int THREADS>
+__global__ __launch_bounds__(THREADS, 1) void compare_sliding_kernel(
     const uint4* __restrict__ recs, const uint32_t* __restrict__ off, const uint32_t* __restrict__ q,
     const uint32_t* __restrict__ starts_a, const uint32_t* __restrict__ starts_b, const float* __restrict__ tri_tbl,
-    unsigned int* score_bits, unsigned long long* key_out, const SlideArgs a) {
+    unsigned int* score_bits, const ScanOut out, const SlideArgs a, const QueryArg qa) {
+    constexpr int WAVES = THREADS / 64;
+    static_assert(WAVES <= kScanWaves, "the profiling arrays are sized for sixteen waves");
     __shared__ float s_tri[kTriSize];
-    __shared__ uint32_t s_queue[kScanWaves][4 * kSlots + 4];
-    __shared__ unsigned long long s_k[kScanWaves];
+    __shared__ uint32_t s_queue[WAVES][4 * kSlots + 4];
+    __shared__ unsigned long long s_k[WAVES][QN];
     __shared__ uint32_t s_cursor[2][2];                                    // per mode: next entry to claim, end of the run
-    __shared__ __attribute__((aligned(16))) uint4 s_stage_all[kScanWaves][kStageWords];   // fill_windows' staging block, per wave
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_qbuf[];      // QLDS: nq * kQWords words
-    for (uint32_t i = threadIdx.x; i < kTriSize; i += kScanThreads) s_tri[i] = tri_tbl[i];
-    if (QLDS)
-        for (uint32_t i = threadIdx.x; i < (a.nq + 1u) * kQWords; i += kScanThreads) s_qbuf[i] = q[i];
+    __shared__ __attribute__((aligned(16))) uint4 s_stage_all[WAVES][kStageWords];   // fill_windows' staging block, per wave
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_qbuf[];      // QLDS: QN * (nq + 1) * kQWords words
+    for (uint32_t i = threadIdx.x; i < kTriSize; i += THREADS) s_tri[i] = tri_tbl[i];
+    if (QLDS) {
+        const uint32_t words = (uint32_t)QN * (a.nq + 1u) * kQWords;
+        if (QN == 1 && a.q_in_args) {
+            for (uint32_t i = threadIdx.x; i < words; i += THREADS) s_qbuf[i] = qa.w[i];
+        } else {
+            for (uint32_t i = threadIdx.x; i < words; i += THREADS) s_qbuf[i] = q[i];
+        }
+    }
     if (threadIdx.x == 0) {
         s_cursor[0][0] = starts_a[blockIdx.x]; s_cursor[0][1] = starts_a[blockIdx.x + 1];
         s_cursor[1][0] = starts_b[blockIdx.x]; s_cursor[1][1] = starts_b[blockIdx.x + 1];
@@ -790,9 +876,11 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
     uint32_t* s_ne = s_off + kSlots;
     uint32_t* s_ent = s_ne + kSlots;
     SlidePtrs p;
-    p.recs = recs; p.off = off; p.q = q; p.score_bits = score_bits; p.key_out = key_out;
+    p.recs = recs; p.off = off; p.q = q; p.score_bits = score_bits; p.key_out = out.acc;
     const uint32_t* s_q = QLDS ? s_qbuf : nullptr;
-    unsigned long long best = 0ull;
+    unsigned long long best[QN];
+#pragma unroll
+    for (int qi = 0; qi < QN; ++qi) best[qi] = 0ull;
 #ifdef LBAD_SLIDE_PROF
     if (lane < 16) s_slide_prof[wave][lane] = 0ull;
 #endif
@@ -800,16 +888,16 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
 #if defined(LBAD_SLIDE_PROF) || defined(LBAD_SLIDE_STAMPS)
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // Two of the sixteen waves take the B entries first, the others the A entries; whoever runs out moves on to the
+    // Two of the waves take the B entries first, the others the A entries; whoever runs out moves on to the
     // other kind.  Where B entries are rare (a short query: the few entries not longer than it) finding them is a walk
     // over the whole run's offsets -- latency, not arithmetic -- and hides behind the others' A passes this way.
-    const bool b_first = wave >= kScanWaves - 2;
-    if (b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
-    best = scan_mode<false, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[0], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
+    const bool b_first = wave >= (uint32_t)WAVES - 2u;
+    if (b_first) scan_mode<true, FULL, ALL_FEED, QLDS, QN, WAVES>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
+    scan_mode<false, FULL, ALL_FEED, QLDS, QN, WAVES>(a, p, s_tri, s_q, s_cursor[0], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     LBAD_PROF_T(k1);
     LBAD_STAMP(0, rt0);
     LBAD_STAMP(2, __builtin_amdgcn_s_memrealtime());
-    if (!b_first) best = scan_mode<true, FULL, ALL_FEED, QLDS>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
+    if (!b_first) scan_mode<true, FULL, ALL_FEED, QLDS, QN, WAVES>(a, p, s_tri, s_q, s_cursor[1], s_start, s_off, s_ne, s_ent, s_stage_all[wave], best);
     LBAD_PROF_T(k2);
     LBAD_PROF_ADD(6, k0, k1);
     LBAD_PROF_ADD(7, k1, k2);
@@ -825,33 +913,31 @@ __global__ __launch_bounds__(kScanThreads, kScanPerCu) void compare_sliding_kern
 #endif
     LBAD_STAMP(3, __builtin_amdgcn_s_memrealtime());
 #pragma unroll
-    for (int off2 = 32; off2 > 0; off2 >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off2, 64);
-        best = o > best ? o : best;
-    }
-#ifdef LBAD_EXP_SLIDE_KEEPWARM
-    // (experiment) waves that are done keep the CU's memory path busy with loads that hit until the whole workgroup is done
-    if (lane == 0) atomicAdd(&s_cursor[0][1], 0x10000u);            // (the run's end is no longer needed: a counter of finished waves above it)
-    {
-        uint32_t spin = 0, sink = 0;
-        while ((*reinterpret_cast<volatile uint32_t*>(&s_cursor[0][1]) >> 16) - (starts_a[blockIdx.x + 1] >> 16) < (uint32_t)kScanWaves && spin < 200000u) {
-            sink += *reinterpret_cast<const volatile uint32_t*>(off + ((spin * 64u + lane) & 1023u));
-            ++spin;
+    for (int qi = 0; qi < QN; ++qi) {
+#pragma unroll
+        for (int off2 = 32; off2 > 0; off2 >>= 1) {
+            const unsigned long long o = __shfl_xor(best[qi], off2, 64);
+            best[qi] = o > best[qi] ? o : best[qi];
         }
-        if (sink == 0x12345u) best ^= 1ull;
+        if (lane == 0) s_k[wave][qi] = best[qi];
     }
-#endif
-#ifdef LBAD_EXP_SLIDE_NOBARRIER
-    if (lane == 0 && best) atomicMax(key_out, best);
-#else
-    if (lane == 0) s_k[wave] = best;
     __syncthreads();
+    // The workgroup's maxima join the scan's running ones; the LAST workgroup to get here hands the results over and
+    // leaves the running words and the ticket at zero for the next scan (no memset node in front of a scan).
     if (threadIdx.x == 0) {
-        unsigned long long m = s_k[0];
-        for (int i = 1; i < kScanWaves; ++i) m = s_k[i] > m ? s_k[i] : m;
-        if (m) atomicMax(key_out, m);
+        for (int qi = 0; qi < QN; ++qi) {
+            unsigned long long m = s_k[0][qi];
+            for (int i = 1; i < WAVES; ++i) m = s_k[i][qi] > m ? s_k[i][qi] : m;
+            if (m) atomicMax(&out.acc[qi], m);
+        }
+        __threadfence();
+        if (atomicAdd(out.ticket, 1u) == gridDim.x - 1u) {
+            __threadfence();
+            for (int qi = 0; qi < QN; ++qi) out.keys[out.pos[qi]] = atomicExch(&out.acc[qi], 0ull);
+            *out.ticket = 0u;
+            __threadfence();
+        }
     }
-#endif
 }
 
 // ---- the plan of a query length: where every workgroup's run of entries starts ---------------------------------------
@@ -1057,13 +1143,15 @@ __device__ __forceinline__ void short_steps(const uint32_t (&P)[K][4], const uin
     }
 }
 
-template <int K>
-__global__ __launch_bounds__(kSlThreads) void compare_short_kernel(
+// QN queries of one length per launch (round 5): a chunk's records are fetched and unpacked once, the steps run per query
+// (q: QN blocks of (nq + 1) kQWords words).
+template <int K, int QN>
+__global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compare_short_kernel(     // (four waves per SIMD: 128 registers, as round 4's)
     const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
     uint64_t n_chunks, uint4 range_mask, const float* __restrict__ tri_tbl, uint64_t index_base,
-    unsigned int* __restrict__ score_bits, unsigned long long* __restrict__ key_out) {
+    unsigned int* __restrict__ score_bits, const ScanOut out) {
     __shared__ float s_tri[kTriSize];
-    __shared__ unsigned long long s_k[kSlThreads / 64];
+    __shared__ unsigned long long s_k[kSlThreads / 64][QN];
     for (uint32_t i = threadIdx.x; i < kTriSize; i += kSlThreads) s_tri[i] = tri_tbl[i];
     __syncthreads();
 
@@ -1071,7 +1159,10 @@ __global__ __launch_bounds__(kSlThreads) void compare_short_kernel(
     const uint64_t wave = (uint64_t)blockIdx.x * (kSlThreads / 64) + (threadIdx.x >> 6);
     const uint64_t n_waves = (uint64_t)gridDim.x * (kSlThreads / 64);
     const uint32_t rm[4] = {range_mask.x, range_mask.y, range_mask.z, range_mask.w};
-    unsigned long long best = 0ull;
+    unsigned long long best[QN];
+#pragma unroll
+    for (int qi = 0; qi < QN; ++qi) best[qi] = 0ull;
+    const uint32_t q_stride = (nq + 1u) * kQWords;
 
     for (uint64_t c = wave; c < n_chunks; c += n_waves) {
         const uint64_t p0 = c * chunk_step + (uint64_t)lane * K;
@@ -1106,44 +1197,56 @@ __global__ __launch_bounds__(kSlThreads) void compare_short_kernel(
         }
         const bool any_a = __ballot(some_a) != 0ull, any_b = __ballot(some_b) != 0ull;
 
-        float acc[K];
-        int smax[K];
-        if (!any_b) short_steps<K, 0>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
-        else if (!any_a) short_steps<K, 1>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
-        else short_steps<K, 2>(P, N, nz, tri, case_a, start_b, q, nq, s_tri, acc, smax);
-
-        // a record closes a window iff the window lies inside its entry AND inside this chunk.  The exact
-        // division (Fp.m:144) runs only where the sum can reach the lane's best so far.
-        const float thr = __uint_as_float((uint32_t)(best >> 32)) * 0.99999f;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const bool closes = case_a[k] ? (isat[k] >= nq - 1u) : (rem[k] == 0u);
-            const bool valid = inb[k] && closes && lane * K + k >= n2[k] - 1u;
-            const float s = case_a[k] ? acc[k] : __int_as_float(smax[k]);
-            const float n2f = (float)n2[k];
-            const bool need = valid && (score_bits != nullptr || s >= thr * n2f);
-            if (__ballot(need) != 0ull) {
-                if (need) {
-                    const float cand = __fdiv_rn(s, n2f);
-                    const float match = (0.0f < cand) ? cand : 0.0f;         // MAX(match, cand) from match = 0
-                    if (score_bits) atomicMax(&score_bits[idx[k]], __float_as_uint(match));
-                    const unsigned long long key = sl_key(match, index_base + idx[k]);
-                    best = key > best ? key : best;
+        for (int qi = 0; qi < QN; ++qi) {
+            const uint32_t* __restrict__ qq = q + (size_t)qi * q_stride;
+            float acc[K];
+            int smax[K];
+            if (!any_b) short_steps<K, 0>(P, N, nz, tri, case_a, start_b, qq, nq, s_tri, acc, smax);
+            else if (!any_a) short_steps<K, 1>(P, N, nz, tri, case_a, start_b, qq, nq, s_tri, acc, smax);
+            else short_steps<K, 2>(P, N, nz, tri, case_a, start_b, qq, nq, s_tri, acc, smax);
+
+            // a record closes a window iff the window lies inside its entry AND inside this chunk.  The exact
+            // division (Fp.m:144) runs only where the sum can reach the lane's best so far.
+            const float thr = __uint_as_float((uint32_t)(best[qi] >> 32)) * 0.99999f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const bool closes = case_a[k] ? (isat[k] >= nq - 1u) : (rem[k] == 0u);
+                const bool valid = inb[k] && closes && lane * K + k >= n2[k] - 1u;
+                const float s = case_a[k] ? acc[k] : __int_as_float(smax[k]);
+                const float n2f = (float)n2[k];
+                const bool need = valid && ((QN == 1 && score_bits != nullptr) || s >= thr * n2f);
+                if (__ballot(need) != 0ull) {
+                    if (need) {
+                        const float cand = __fdiv_rn(s, n2f);
+                        const float match = (0.0f < cand) ? cand : 0.0f;     // MAX(match, cand) from match = 0
+                        if (QN == 1 && score_bits) atomicMax(&score_bits[idx[k]], __float_as_uint(match));
+                        const unsigned long long key = sl_key(match, index_base + idx[k]);
+                        best[qi] = key > best[qi] ? key : best[qi];
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(best, off, 64);
-        best = o > best ? o : best;
+    for (int qi = 0; qi < QN; ++qi) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best[qi], off, 64);
+            best[qi] = o > best[qi] ? o : best[qi];
+        }
+        if (lane == 0) s_k[threadIdx.x >> 6][qi] = best[qi];
     }
-    if (lane == 0) s_k[threadIdx.x >> 6] = best;
     __syncthreads();
+    // The keys are max-ed in place (the host clears them in front of the launch): this scan runs six workgroups per CU,
+    // and a ticket on top of the maximum -- two contended atomics and two fences for each of 1536 workgroups -- cost a
+    // fifth of the HBM-bound scan's time (0.261 -> 0.309 ms at a query of 5) where the memset node costs 5 us.
     if (threadIdx.x == 0) {
-        unsigned long long m = s_k[0];
-        for (int i = 1; i < kSlThreads / 64; ++i) m = s_k[i] > m ? s_k[i] : m;
-        if (m) atomicMax(key_out, m);
+        for (int qi = 0; qi < QN; ++qi) {
+            unsigned long long m = s_k[0][qi];
+            for (int i = 1; i < kSlThreads / 64; ++i) m = s_k[i][qi] > m ? s_k[i][qi] : m;
+            if (m) atomicMax(&out.keys[out.pos[qi]], m);
+        }
     }
 }
 
@@ -1382,20 +1485,36 @@ hipError_t launch_synth_ragged(uint32_t seed, uint64_t first_entry, uint64_t n_e
 #endif
 bool sliding_short(uint32_t n_query, uint32_t ne_max) { return (n_query < ne_max ? n_query : ne_max) <= LBAD_SHORT_LOOK + 1u; }
 
-static void sliding_variant(uint32_t subfp_len, uint32_t n_query, uint32_t range, bool& full, bool& all_feed, bool& qlds, uint32_t& dyn_lds) {
+static void sliding_variant(uint32_t subfp_len, uint32_t n_query, uint32_t range, uint32_t n_q, bool& full, bool& qlds, uint32_t& dyn_lds) {
     const uint4 rm = sliding_range_mask(subfp_len, range);
     const uint4 all = pair_mask(subfp_len);
     full = rm.x == all.x && rm.y == all.y && rm.z == all.z && rm.w == all.w;
-    all_feed = n_query <= 6u;     // short queries: every lane reads its own records, nothing travels
-    qlds = n_query <= kQueryLds;
-    dyn_lds = qlds ? (n_query + 1u) * kQWords * 4u : 0u;
+    qlds = n_q > 1 || n_query <= kQueryLds;
+    dyn_lds = qlds ? n_q * (n_query + 1u) * kQWords * 4u : 0u;
+}
+
+#ifndef LBAD_MULTI_THREADS
+#define LBAD_MULTI_THREADS 768
+#endif
+constexpr int kMultiThreads = LBAD_MULTI_THREADS;  // several queries per pass: twelve waves, 168 registers per lane
+constexpr uint32_t kMultiLdsWords = 14000;          // dynamic LDS a launch of several queries may ask for (56 KB of the CU's 160)
+
+// How many of `n_left` queries of n_query sub-fingerprints ONE launch takes: the systolic scan of short queries up to
+// eight, the task scan four or two while their blocks fit the LDS next to the tables.
+uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t n_left) {
+    if (n_left <= 1) return n_left;
+    if (sliding_short(n_query, ne_max)) return n_left >= 8 ? 8u : (n_left >= 4 ? 4u : 2u);
+    uint32_t g = n_left >= 4 ? 4u : 2u;
+    while (g > 1 && (uint64_t)g * (n_query + 1u) * kQWords > kMultiLdsWords) g >>= 1;
+    return g;
 }
 
 // Shape of a scan: one workgroup per CU, each with 1 / grid of the tasks of either kind (whole entries).
-SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b) {
+SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b, uint32_t n_q) {
     SlideShape sh;
+    const uint64_t waves = n_q > 1 ? kMultiThreads / 64 : kScanWaves;
     const uint64_t passes = (tasks_a + 63) / 64 + (tasks_b + 63) / 64;
-    const uint64_t want = (passes + kScanWaves - 1) / kScanWaves;
+    const uint64_t want = (passes + waves - 1) / waves;
     uint64_t cap = (uint64_t)device_cu_count() * kScanPerCu;
     if (cap > kSlideMaxGrid) cap = kSlideMaxGrid;
     sh.grid = (uint32_t)(want < cap ? (want ? want : 1) : cap);
@@ -1435,22 +1554,28 @@ hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32
 }
 
 // tasks_a / tasks_b: groups of four sliding offsets over the entries longer than / not longer than the query (from the
-// host's histogram of entry lengths).  d_query: what build_sliding_query made.  zero_rec: index of an all-zero record
-// behind the stored ones.  d_score_bits (optional, n_entries words) must be zero on entry and receives the float bits of
-// every entry's match; *d_key is max-ed.
+// host's histogram of entry lengths).  zero_rec: index of an all-zero record behind the stored ones.  d_score_bits
+// (optional, one query only; n_entries words) must be zero on entry and receives the float bits of every entry's match.
+// scan: the queries (build_sliding_query blocks without their header, one after the other) and where the keys go.
 hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uint32_t* d_off, uint64_t n_entries, uint32_t ne_max,
                                   uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
-                                  uint32_t subfp_len, const uint32_t* d_query, uint32_t n_query, uint32_t range,
-                                  uint64_t index_base, unsigned int* d_score_bits, unsigned long long* d_key,
-                                  hipStream_t stream, bool bound_pruning) {
-    if (n_entries == 0 || n_query == 0 || tasks_a + tasks_b == 0) return hipSuccess;
+                                  uint32_t subfp_len, const SlideScan& scan, uint32_t n_query, uint32_t range,
+                                  uint64_t index_base, unsigned int* d_score_bits, hipStream_t stream, bool bound_pruning,
+                                  float prune_from) {
+    const uint32_t n_q = scan.n_q;
+    if (n_entries == 0 || n_query == 0 || tasks_a + tasks_b == 0 || n_q == 0) return hipErrorInvalidValue;   // (the caller clears the keys itself)
     if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return hipErrorInvalidValue;    // the plan counts in 32 bits
     if (n_query >= (1u << 20)) return hipErrorInvalidValue;                                  // (run_pass: 32-bit lane offsets)
+    if (n_q > 1 && d_score_bits) return hipErrorInvalidValue;
     const float* tri = sliding_tri_table();
     if (!tri) return hipErrorOutOfMemory;
+    ScanOut out;
+    out.acc = scan.d_acc; out.ticket = scan.d_ticket; out.keys = scan.d_keys;
+    for (int i = 0; i < 8; ++i) out.pos[i] = scan.key_pos[i];
     if (sliding_short(n_query, ne_max)) {
         // the systolic scan: 64 K records per wave and chunk (K = 4 records per lane once a window reaches back more than six
         // records: the overlap of consecutive chunks stays a small part of a chunk)
+        if (!scan.d_queries) return hipErrorInvalidValue;
         const uint32_t look = (n_query < ne_max ? n_query : ne_max) - 1u;
         const uint32_t K = look <= 6u ? 1u : 4u;
         const uint32_t step = 64u * K - look;
@@ -1460,12 +1585,17 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         const uint64_t cap = (uint64_t)device_cu_count() * 6u;                   // 21 KB of LDS per workgroup
         const uint32_t grid = (uint32_t)(want < cap ? want : cap);
         const uint4 rm4 = sliding_range_mask(subfp_len, range);
-        if (K == 1)
-            hipLaunchKernelGGL(compare_short_kernel<1>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_query + kQHeader,
-                               n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, d_key);
-        else
-            hipLaunchKernelGGL(compare_short_kernel<4>, dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, d_query + kQHeader,
-                               n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, d_key);
+#define LBAD_SHORT(KK, QQ)                                                                                                    \
+    hipLaunchKernelGGL((compare_short_kernel<KK, QQ>), dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
+                       n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, out)
+        if (K == 1) {
+            if (n_q == 1) LBAD_SHORT(1, 1); else if (n_q == 2) LBAD_SHORT(1, 2); else if (n_q == 4) LBAD_SHORT(1, 4);
+            else if (n_q == 8) LBAD_SHORT(1, 8); else return hipErrorInvalidValue;
+        } else {
+            if (n_q == 1) LBAD_SHORT(4, 1); else if (n_q == 2) LBAD_SHORT(4, 2); else if (n_q == 4) LBAD_SHORT(4, 4);
+            else if (n_q == 8) LBAD_SHORT(4, 8); else return hipErrorInvalidValue;
+        }
+#undef LBAD_SHORT
         return hipGetLastError();
     }
     SlideArgs a;
@@ -1479,22 +1609,37 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     };
     a.dense_a = dense(tasks_a);
     a.dense_b = dense(tasks_b);
-    a.prune = (bound_pruning && d_score_bits == nullptr) ? 1u : 0u;
-    bool full, all_feed, qlds;
+    a.prune = (bound_pruning && d_score_bits == nullptr && n_q == 1 && n_query <= kPruneMaxQuery) ? 1u : 0u;
+    a.prune_from = prune_from;
+    bool full, qlds;
     uint32_t dyn_lds;
-    sliding_variant(subfp_len, n_query, range, full, all_feed, qlds, dyn_lds);
+    sliding_variant(subfp_len, n_query, range, n_q, full, qlds, dyn_lds);
+    static QueryArg qa_zero = {};
+    const QueryArg* qa = &qa_zero;
+    QueryArg qa_local;
+    a.q_in_args = 0;
+    if (n_q == 1 && qlds && scan.h_query && n_query <= kSlideQueryArgSubs) {
+        std::memcpy(qa_local.w, scan.h_query, (size_t)(n_query + 1u) * kQWords * 4u);
+        qa = &qa_local;
+        a.q_in_args = 1;
+    } else if (!scan.d_queries) {
+        return hipErrorInvalidValue;
+    }
     const uint32_t* starts_a = d_plan;
     const uint32_t* starts_b = starts_a + (kSlideMaxGrid + 1);
-    const uint32_t* q = d_query + kQHeader;
-#define LBAD_SLIDE(FULL, FEED, QL)                                                                                         \
-    hipLaunchKernelGGL((compare_sliding_kernel<FULL, FEED, QL>), dim3(sh.grid), dim3(kScanThreads), dyn_lds, stream, d_recs, \
-                       d_off, q, starts_a, starts_b, tri, d_score_bits, d_key, a)
-    if (full) {
-        if (all_feed) { if (qlds) LBAD_SLIDE(true, true, true); else LBAD_SLIDE(true, true, false); }
-        else { if (qlds) LBAD_SLIDE(true, false, true); else LBAD_SLIDE(true, false, false); }
+    const uint32_t* q = scan.d_queries;
+#define LBAD_SLIDE(FULL, QL, QQ, TT)                                                                                          \
+    hipLaunchKernelGGL((compare_sliding_kernel<FULL, false, QL, QQ, TT>), dim3(sh.grid), dim3(TT), dyn_lds, stream, d_recs, d_off, \
+                       q, starts_a, starts_b, tri, d_score_bits, out, a, *qa)
+    if (n_q == 1) {
+        if (full) { if (qlds) LBAD_SLIDE(true, true, 1, kScanThreads); else LBAD_SLIDE(true, false, 1, kScanThreads); }
+        else { if (qlds) LBAD_SLIDE(false, true, 1, kScanThreads); else LBAD_SLIDE(false, false, 1, kScanThreads); }
+    } else if (n_q == 2) {
+        if (full) LBAD_SLIDE(true, true, 2, kMultiThreads); else LBAD_SLIDE(false, true, 2, kMultiThreads);
+    } else if (n_q == 4) {
+        if (full) LBAD_SLIDE(true, true, 4, kMultiThreads); else LBAD_SLIDE(false, true, 4, kMultiThreads);
     } else {
-        if (all_feed) { if (qlds) LBAD_SLIDE(false, true, true); else LBAD_SLIDE(false, true, false); }
-        else { if (qlds) LBAD_SLIDE(false, false, true); else LBAD_SLIDE(false, false, false); }
+        return hipErrorInvalidValue;
     }
 #undef LBAD_SLIDE
     return hipGetLastError();

@@ -470,3 +470,143 @@ def test_bench_collective_paths_on_nccl_at_one_rank(gpu):
     assert c["collective_fallback"] is False and c["found_planted"] is True and c["allreduce_ms"] is not None
     assert r["parity"]["bit_exact"] is True if "parity" in r else True
     assert r["self_check"]["ok"]
+
+
+def _bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+@pytest.mark.parametrize("L,seed", [(200, 1), (199, 2), (64, 3)])
+def test_ragged_batches_equal_single_queries(lb, gpu, oracle, L, seed):
+    """Round 5: several queries of ONE length share their passes over the records (four per launch of the task scan, eight of
+    the systolic scan of short queries); a batch of mixed lengths runs a group per length.  Upstream's caller is Q x N
+    (LBAudioDetectiveTests.m:57-91: ten originals against ten candidates).  Every (index, score bits) of a batch equals the
+    single query's and the oracle's, whatever the order and the group sizes (1, 2, 4, 8 and what is left over)."""
+    rng = np.random.default_rng(4200 + seed)
+    n_entries = 400
+    lens = rng.integers(1, 71, n_entries)
+    lens[:6] = [70, 21, 22, 20, 48, 1]
+    entries = [_rand_fp(rng, int(n), L, p_zero=0.05, p_both=0.02) for n in lens]
+    corpus, _ = _ragged_corpus(lb, gpu, entries, L)
+
+    def make(nq):
+        q = _rand_fp(rng, nq, L, p_zero=0.05, p_both=0.02)
+        src = entries[int(rng.integers(0, n_entries))]
+        k = min(nq, src.shape[0])
+        q[:k] = src[:k]
+        q[::3, : max(1, L // 7)] ^= 1
+        return q
+
+    for lengths in ([21] * 4, [21] * 8, [48] * 7, [5] * 8, [5] * 3 + [12] * 9, [21, 48, 21, 5, 48, 21, 21, 64, 21, 2, 70, 21, 48],
+                    [30, 30], [16] * 5, [33] * 11):
+        qs = [make(nq) for nq in lengths]
+        fps = [lb.Fingerprint.from_bools(q) for q in qs]
+        for rg in (0, max(1, L // 2), 7):
+            got = corpus.query_batch(fps, rg)
+            for q, fq, g in zip(qs, fps, got):
+                bi, bs = oracle.corpus_best_ragged(q, entries, rg if rg else L)
+                one = corpus.query(fq, rg)
+                assert (g[0], _bits(g[1])) == (one[0], _bits(one[1])) == (bi, _bits(bs)), (lengths, rg, q.shape, g, one, bi, bs)
+    # the same through the device form, with an index base, on a stream of its own
+    s = gpu.cuda.Stream()
+    keys = gpu.zeros(8, dtype=gpu.int64, device="cuda")
+    qs = [make(21) for _ in range(8)]
+    fps = [lb.Fingerprint.from_bools(q) for q in qs]
+    with gpu.cuda.stream(s):
+        corpus.query_batch_keys_device(fps, keys, 0, index_base=1000, stream=s)
+    s.synchronize()
+    for q, k in zip(qs, keys.tolist()):
+        bi, bs = oracle.corpus_best_ragged(q, entries, L)
+        idx, sc = lb.Corpus.decode_key(k)
+        assert (idx, _bits(sc)) == (bi + 1000, _bits(bs))
+
+
+@pytest.mark.parametrize("nq", [21, 200, 2000])
+def test_bound_pruning_against_adversarial_layouts(lb, gpu, oracle, nq):
+    """The bound that lets a top-1 scan give up groups of offsets (k_sliding.hip: kPruneMargin) against the layouts that
+    could break it: a strong match is published early, and LATER entries trail it by a hair for most of the query and then
+    collect ratios of exactly 1.0 to the end -- one ends in an exact TIE (the lower index must keep the result, strict '<' of
+    LBAudioDetectiveTests.m:80), one strictly BETTER by a single sign pair (it must win), others a little inside and a little
+    outside the 0.1 % margin.  Pruned scan == full scan == oracle, at queries of 21, 200 and 2000 sub-fingerprints, with the
+    threshold at its default and moved."""
+    L = 200
+    rng = np.random.default_rng(900 + nq)
+    q = _rand_fp(rng, nq, L, p_zero=0.0)                      # every pair set: possible = 100 in every sub-fingerprint
+
+    def variant(flips):
+        """an entry of nq + 9 sub-fingerprints that holds the query at offset 4 with flips[j] sign pairs of sub-fingerprint j reversed"""
+        e = _rand_fp(rng, nq + 9, L, p_zero=0.0)
+        w = q.copy()
+        for j, k in flips.items():
+            for p in range(k):
+                w[j, 2 * p], w[j, 2 * p + 1] = w[j, 2 * p + 1], w[j, 2 * p]
+        e[4:4 + nq] = w
+        return e
+
+    lead = {0: 9, 1: 17, 2: 4, 3: 11}                         # mismatches in the FIRST steps only: the rest of the query scores 1.0
+    published = variant(lead)
+    tie = variant(lead)                                        # the same ratios in the same order: the same float32 sum
+    better = variant({0: 9, 1: 17, 2: 4, 3: 10})              # one pair fewer
+    inside = variant({0: 9, 1: 17, 2: 4, 3: 11, 4: max(1, nq // 1250)})                  # trails by < 0.1 %
+    outside = variant({0: 30, 1: 30, 2: 30, 3: 30, 4: 30})                             # trails by more
+    noise = [_rand_fp(rng, int(n), L, p_zero=0.02) for n in rng.integers(20, 71, 300)]
+    for layout, winner in (([published] + noise[:100] + [tie] + noise[100:], "published"),
+                           ([tie] + noise[:50] + [published] + noise[50:] + [inside, outside], "first of the tie"),
+                           (noise[:10] + [published] + noise[10:200] + [inside, tie, outside] + noise[200:] + [better], "better"),
+                           ([outside, inside] + noise[:150] + [better, published, tie] + noise[150:], "better")):
+        corpus, _ = _ragged_corpus(lb, gpu, layout, L)
+        fq = lb.Fingerprint.from_bools(q)
+        bi, bs = oracle.corpus_best_ragged(q, layout, L, nthreads=8)
+        assert bs > 0.9
+        corpus.set_bound_pruning(False)
+        full = corpus.query(fq)
+        results = []
+        for thr in (0.7, 0.5, 0.95):
+            corpus.set_bound_pruning(True).set_bound_pruning_threshold(thr)
+            assert abs(corpus.bound_pruning_threshold - thr) < 1e-6
+            for _ in range(3):                                 # (which wave publishes first is a race: the result must not be)
+                results.append(corpus.query(fq))
+        for r in [full] + results:
+            assert (r[0], _bits(r[1])) == (bi, _bits(bs)), (nq, winner, r, bi, bs)
+        corpus.dispose()
+    with pytest.raises(lb.LBAudioDetectiveError):
+        corpus2, _ = _ragged_corpus(lb, gpu, noise[:3], L)
+        corpus2.set_bound_pruning_threshold(0.0)
+
+
+def test_pass_of_a_scan_never_spans_more_than_its_offsets_can_address(lb, gpu, oracle):
+    """Round-4 advice: the lanes of an "A" pass address their records as a wave-uniform base + a 32-bit byte offset, and in
+    a corpus of more than 4 GiB a wave's left-over tasks and its next claim can lie 2^27 records apart (entries without
+    tasks of that kind in between).  The corpus here has exactly that shape: a few hundred entries longer than the query,
+    then 2^27 + records in 6.9 M entries NOT longer than it, then a few hundred longer ones with the match planted in the last.
+    Whichever wave holds tasks of both sides, the pass is cut at the gap (k_sliding.hip: kPassSpan) -- ten queries, every
+    one must find the planted entry with the oracle's score."""
+    L, nq = 200, 21
+    rng = np.random.default_rng(31)
+    n_a = 300
+    a_entries = [_rand_fp(rng, 30, L, p_zero=0.02) for _ in range(2 * n_a)]          # 30 > 21: three tasks of four offsets each
+    q = _rand_fp(rng, nq, L, p_zero=0.0)
+    a_entries[-1][5:5 + nq] = q
+    a_entries[-1][7, :40] ^= 1
+    gap_entries = (1 << 27) // 20 + 1000
+    counts = np.concatenate([np.full(n_a, 30, np.uint32), np.full(gap_entries, 20, np.uint32), np.full(n_a, 30, np.uint32)])
+    total = int(counts.sum(dtype=np.uint64))
+    assert total * 32 > (1 << 32)
+    packed = gpu.zeros((total, 32), dtype=gpu.uint8, device="cuda")                  # the gap: all-zero records (they score 0)
+    def pack(es):
+        return np.stack([lb.pack_subfingerprint(r) for e in es for r in e]).view(np.uint8).reshape(-1, 32)
+    packed[: n_a * 30] = gpu.from_numpy(pack(a_entries[:n_a])).cuda()
+    packed[total - n_a * 30:] = gpu.from_numpy(pack(a_entries[n_a:])).cuda()
+    corpus = lb.Corpus.ragged(L, len(counts), total)
+    corpus.append_ragged_packed_device(packed, counts)
+    del packed
+    bi, bs = oracle.corpus_best_ragged(q, a_entries, L)
+    assert bi == 2 * n_a - 1 and bs > 0.9
+    want_index = len(counts) - 1
+    fq = lb.Fingerprint.from_bools(q)
+    for pruning in (False, True):
+        corpus.set_bound_pruning(pruning)
+        for _ in range(5):
+            idx, score = corpus.query(fq)
+            assert (idx, _bits(score)) == (want_index, _bits(bs)), (pruning, idx, score, want_index, bs)
+    corpus.dispose()
