@@ -69,10 +69,34 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+# Float operations a stage-1 kernel EXECUTES per window, as a fraction of SURVEY 8(d)'s canonical count (2.5 W log2 W of a
+# real radix-2 FFT): static counts from the kernels' own headers.  The canonical figure is what the metric is priced in;
+# the executed one is what the vector ALU actually did -- both are reported, neither as the other.
+EXECUTED_OVER_CANONICAL = {
+    # k_rows_pruned.hip header: ~10.3 k operations per window instead of 25.6 k (only the outputs that feed bins 0..21)
+    (44100, 1024): (10.3e3 / 25.6e3, "k_rows_pruned.hip: 10.3 k of 25.6 k operations per window survive the output pruning"),
+    # k_rows_stream2.hip header: 4.1 k of 5.1 k butterflies (stages 1-4 shared by consecutive windows), split pass and
+    # band sums in full: (4.1 k x 10 + 1024 x 12 + 2.3 k) / 56.3 k
+    (5512, 2048): ((4.1e3 * 10 + 1024 * 12 + 2.3e3) / (2.5 * 2048 * 11), "k_rows_stream2.hip: 4.1 k of 5.1 k butterflies per window, split pass and bands in full"),
+    # k_rows_stream.hip: 32 new 32-point transforms (2560 butterflies), 1024 of stage 6, 64 cross transforms pruned to 12
+    # of 32 outputs (~50 of 80 butterflies), split pass over 384 bins: (6.8 k x 10 + 384 x 12 + 1 k) / 122.9 k
+    (48000, 4096): ((6.8e3 * 10 + 384 * 12 + 1.0e3) / (2.5 * 4096 * 12), "k_rows_stream.hip: ~6.8 k of 11.3 k butterflies per window (five shared stages, cross transform pruned to 12 of 32 outputs)"),
+}
+
+
 def algorithmic_bytes_per_clip(n_samples: int, window: int, stride: int) -> int:
     """4 L input + 25 bytes of information per sub-fingerprint."""
     per = ((n_samples - window) // stride) // 128
     return 4 * n_samples + 25 * per
+
+
+def executed_fields(rate: int, window: int, canonical_tflops: float, variant: int) -> dict:
+    """fp32_executed_tflops / fp32_frac_executed beside the canonical figures (the specialised kernels only)."""
+    f = EXECUTED_OVER_CANONICAL.get((rate, window)) if variant != 1 else None
+    if f is None:
+        return {"fp32_executed_tflops": None, "fp32_frac_executed": None}
+    return {"fp32_executed_tflops": round(canonical_tflops * f[0], 3), "fp32_frac_executed": round(canonical_tflops * f[0] / FP32_PEAK_TFLOPS, 4),
+            "executed_over_canonical": round(f[0], 3), "executed_count_source": f[1]}
 
 
 def per_call_stage_times(stage1_ms_sum: float, stage2_ms_sum: float, launches: int, calls: int):
@@ -409,8 +433,9 @@ def sliding_leg(args, torch, np):
                                "same_result_no_match": bool(best_stranger == best_stranger_full),
                                "best_score_no_match": best_stranger[1]},
         "subfingerprint_compares_per_s": round(nq * total / (ms * 1e-3), 1),
-        "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel (k_sliding.hip, round 4: only the sliding offsets that "
-                     "exist; 2 v_bitop3 + 1 v_bcnt per 32 sign pairs, 8 DPP moves per step of 4 pairs): integer VALU issue, not HBM",
+        "roofline": {"bound": "valu", "kernel": "compare_sliding_kernel<FULL, false, QLDS, 1, 1024> (k_sliding.hip: only the sliding "
+                     "offsets that exist; 2 v_bitop3 + 1 v_bcnt per 32 sign pairs, 8 DPP moves per step of 4 pairs; round 5: a pass's "
+                     "windows fetched as whole lines through LDS, query in the kernel arguments, no memset node): integer VALU issue, not HBM",
                      "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes": alg, "layout_GBps": round(32 * total / (ms * 1e-3) / 1e9, 1)},
@@ -427,6 +452,38 @@ def sliding_leg(args, torch, np):
         others[f"query_of_{n_other}"] = {"scan_ms": round(mo, 4), "algorithmic_GBps": round(alg / (mo * 1e-3) / 1e9, 1),
                                          "layout_GBps": round(32 * total / (mo * 1e-3) / 1e9, 1)}
     out["other_query_lengths"] = others
+    # Q x N, the shape of the reference's own test (LBAudioDetectiveTests.m:57-91: ten originals against ten candidates):
+    # eight queries of one length in ONE call (four per pass of the task scan, eight of the systolic scan of short queries)
+    # against eight single calls; every key of the batch must equal the single query's
+    corpus.set_bound_pruning(False)
+    batches = {}
+    for n_b in (21, 5):
+        fps = []
+        for k in range(8):
+            e = 100_000 * (k + 1) + 777
+            fps.append(lb.Fingerprint.from_bools(O.synth_entry(CSEED, e, max(int(counts[e]), n_b), 200)[:n_b]))
+        keys8, single8 = torch.zeros(8, dtype=torch.int64, device="cuda"), torch.zeros(8, dtype=torch.int64, device="cuda")
+        t_single = 0.0
+        for i, f in enumerate(fps):
+            mo, _ = timed_scan(f, 5)
+            t_single += mo
+            corpus.query_key_device(f, single8[i:i + 1])
+        for _ in range(2):
+            corpus.query_batch_keys_device(fps, keys8)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            corpus.query_batch_keys_device(fps, keys8)
+        e1.record()
+        torch.cuda.synchronize()
+        mb = e0.elapsed_time(e1) / 10
+        batches[f"eight_queries_of_{n_b}"] = {
+            "one_call_ms": round(mb, 4), "eight_single_calls_ms": round(t_single, 4), "speedup": round(t_single / mb, 2),
+            "times_one_query": round(mb / (t_single / 8), 2), "same_keys": bool(torch.equal(keys8, single8)),
+            "algorithmic_GBps_all_queries": round(8 * alg / (mb * 1e-3) / 1e9, 1)}
+    corpus.set_bound_pruning(True)
+    out["query_batches"] = batches
     if not args.no_cpu_baseline:
         # the oracle's Boolean-per-byte loop (the reference's layout) on a bounded sample of the same corpus;
         # also the parity check of the scores the GPU produced for those entries
@@ -533,17 +590,28 @@ def files_leg(args, torch, np):
         "without_the_pipeline_ms": round(dtb_off * 1e3, 2), "pipeline_gain": round(dtb_off / dtb, 3),
     }
     if not args.no_cpu_baseline:
+        # the independent oracle end to end (own container reader, IMA4 / LPCM decoder, converter, upstream's file loop), ONE
+        # FILE PER THREAD on every usable core (round-4 review: a baseline that runs its files one after the other is a
+        # straw man), and one file on one thread
         cfg = O.Config()
-        sample = paths[:12]
+        threads = usable_cores()
+        sample = (paths * (1 + (2 * threads) // len(paths)))[: max(len(paths), 2 * threads)]       # at least two files per thread
+        O.fingerprint_files(paths[:2], cfg, 1, O.TAIL_NOTHING, 0, 2)
         t1 = time.perf_counter()
-        got = [O.fingerprint_file(p, cfg, 1, O.TAIL_NOTHING, 0) for p in sample]
-        dt1 = time.perf_counter() - t1
-        same = all(np.array_equal(g, fps[paths.index(p)].to_bools()) for g, p in zip(got, sample))
+        got = O.fingerprint_files(sample, cfg, 1, O.TAIL_NOTHING, 0, threads)
+        dt_all = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        O.fingerprint_files(paths[:3], cfg, 1, O.TAIL_NOTHING, 0, 1)
+        dt1 = (time.perf_counter() - t1) / 3
+        same = all(np.array_equal(got[i], fps[i % len(paths)].to_bools()) for i in range(len(sample)))
         out["cpu_baseline"] = {
-            "value": round(len(sample) / dt1, 2), "unit": "files/s", "cores": usable_cores(), "kind": "port", "cpu_model": cpu_model(),
-            "sample": f"the independent oracle end to end (oracle/lbad_file_oracle.c: own container reader, IMA4 / LPCM decoder "
-                      f"and converter -- the converter's loops in OpenMP over {usable_cores()} threads, everything else one thread; "
-                      f"then lbo_fingerprint_file_loop) on the first {len(sample)} fixtures one after the other, {dt1:.1f} s",
+            "value": round(len(sample) / dt_all, 2), "unit": "files/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "per_core": round(len(sample) / dt_all / threads, 3),
+            "single_thread": {"value": round(1.0 / dt1, 3), "unit": "files/s", "cores": 1, "sample": "the first three fixtures, one after the other"},
+            "sample": f"the independent oracle end to end (oracle/lbad_file_oracle.c:lbo_fingerprint_files: own container reader, IMA4 / "
+                      f"LPCM decoder, converter, then upstream's file loop), {len(sample)} files, one file per OpenMP thread on {threads} "
+                      f"threads, {dt_all:.1f} s.  What a file costs a CPU is the reference's own loop: a 2048-point FFT every 8 samples "
+                      f"(6 200 of them for nine seconds of audio, 0.6 GFLOP) in front of 385 converter taps per sample",
         }
         out["parity"] = {"files_checked": len(sample), "bit_exact": bool(same)}
     return out
@@ -728,6 +796,7 @@ def run_rank(args) -> int:
                     "fp32_canonical_tflops": round(canon_flops * clips_per_launch / (rows_ms * 1e-3) / 1e12, 3),
                     "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                     "fp32_frac_canonical": round(canon_flops * clips_per_launch / (rows_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                    **executed_fields(RATE, WINDOW, canon_flops * clips_per_launch / (rows_ms * 1e-3) / 1e12, args.variant),
                     "whole_pass_achieved_GBps": round(alg_bytes * n_clips / (kern_avg_ms * 1e-3) / 1e9, 2),
                 },
             })
@@ -802,6 +871,7 @@ def run_rank(args) -> int:
                         "fp32_canonical_tflops": round(canon * clips_per_launch_o / (k1 * 1e-3) / 1e12, 2),
                         "fp32_peak_tflops": FP32_PEAK_TFLOPS,
                         "fp32_frac_canonical": round(canon * clips_per_launch_o / (k1 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                        **executed_fields(rate, window, canon * clips_per_launch_o / (k1 * 1e-3) / 1e12, 0),
                     },
                     "parity": {"clips_checked": 4, "bit_exact": bool(np.array_equal(got, want))},
                 }
@@ -931,7 +1001,10 @@ def run_rank(args) -> int:
                     "entries_per_s": round(total / ((api_lat_ms if api_lat_ms is not None else lat_ms) * 1e-3), 1),
                     "scan_entries_per_s": round(total / (scan_ms * 1e-3), 1),
                     "achieved_GBps_algorithmic_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9, 2),
-                    "hbm_frac_algorithmic_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "scan_frac_of_hbm_peak_per_gpu": round(25 * per * n_local_max / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "scan_reads_from": (f"the Infinity Cache, not HBM: a shard's planes ({sc.local.entry_stride_bytes * n_local_max / 1e6:.0f} MB) fit its "
+                                        "256 MB -- the HBM-resident figure is compare_hbm.roofline"
+                                        if sc.local.entry_stride_bytes * n_local_max < 256e6 else "HBM"),
                 }
                 if world == 1 and not args.no_cpu_baseline:
                     # the same query over the same corpus through the oracle's Boolean-per-byte loop

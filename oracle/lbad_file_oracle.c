@@ -469,3 +469,26 @@ int lbo_fingerprint_file(const char* path, const lbo_config* cfg, int hop_mode, 
     *out_count = count;
     return 0;
 }
+
+/* n files, one per thread (nthreads OpenMP threads, files handed out dynamically; the converter's own parallel loops run
+ * on one thread inside: nested regions are off) -- the CPU baseline of a catalogue build.  out_bools[i] / out_counts[i] as
+ * lbo_fingerprint_file's; returns the first non-zero status. */
+int lbo_fingerprint_files(const char* const* paths, uint64_t n, const lbo_config* cfg, int hop_mode, int tail_mode, int resampler,
+                          int nthreads, uint8_t** out_bools, uint64_t* out_counts) {
+    int first = 0;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        const int rc = lbo_fingerprint_file(paths[i], cfg, hop_mode, tail_mode, resampler, &out_bools[i], &out_counts[i]);
+        if (rc != 0) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            { if (first == 0) first = rc; }
+        }
+    }
+    return first;
+}
+

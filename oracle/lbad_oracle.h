@@ -179,6 +179,10 @@ int lbo_resample(const float* in, uint64_t n_in, double rate_in, double rate_out
 int lbo_fingerprint_file(const char* path, const lbo_config* cfg, int hop_mode, int tail_mode, int resampler,
                          uint8_t** out_bools, uint64_t* out_count);
 
+/* the same for n files, one per OpenMP thread (the CPU baseline of a catalogue build) */
+int lbo_fingerprint_files(const char* const* paths, uint64_t n, const lbo_config* cfg, int hop_mode, int tail_mode, int resampler,
+                          int nthreads, uint8_t** out_bools, uint64_t* out_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,6 +97,8 @@ def lib():
     sig("lbo_resample", C.c_int, [f32p, C.c_uint64, C.c_double, C.c_double, C.c_int, f32p])
     sig("lbo_fingerprint_file", C.c_int, [C.c_char_p, cfgp, C.c_int, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8)),
                                           C.POINTER(C.c_uint64)])
+    sig("lbo_fingerprint_files", C.c_int, [C.POINTER(C.c_char_p), C.c_uint64, cfgp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint64)])
     sig("lbo_synth_sine_table", None, [i16p])
     sig("lbo_synth_clip", None, [C.c_uint32, C.c_uint64, C.c_double, C.c_uint32, C.c_int, f32p])
     sig("lbo_synth_entry", None, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, u8p])
@@ -389,6 +391,28 @@ def fingerprint_file(path: str, cfg: Config, hop_mode: int = 1, tail_mode: int =
             if n.value else np.zeros((0, cfg.subfp_len), np.uint8)
     finally:
         C.CDLL(None).free(buf)
+    return out
+
+
+def fingerprint_files(paths, cfg: Config, hop_mode: int = 1, tail_mode: int = TAIL_NOTHING, resampler: int = 0, nthreads: int = 1):
+    """fingerprint_file over many files, one file per OpenMP thread (lbo_fingerprint_files): list of [count, subfp_len] arrays."""
+    n = len(paths)
+    arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+    bufs = (C.POINTER(C.c_uint8) * n)()
+    counts = (C.c_uint64 * n)()
+    rc = lib().lbo_fingerprint_files(arr, n, C.byref(cfg), hop_mode, tail_mode, resampler, nthreads, bufs, counts)
+    out = []
+    try:
+        if rc != 0:
+            raise ValueError(f"oracle status {rc}")
+        for i in range(n):
+            k = int(counts[i])
+            out.append(np.ctypeslib.as_array(bufs[i], shape=(k * cfg.subfp_len,)).copy().reshape(k, cfg.subfp_len)
+                       if k else np.zeros((0, cfg.subfp_len), np.uint8))
+    finally:
+        for i in range(n):
+            if bufs[i]:
+                C.CDLL(None).free(bufs[i])
     return out
 
 

@@ -349,3 +349,15 @@ def test_fft_rounding_order_hardly_moves_a_fingerprint(oracle):
     full = json.load(open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "r02_vdsp_gap.json")))
     assert max(v["total"]["flip_rate"] for v in full["variants"].values()) < 1e-4
     assert all(v["birds"]["subfingerprints_touched"] == 0 for v in full["variants"].values())
+
+
+def test_files_in_parallel_equal_files_one_by_one():
+    """lbo_fingerprint_files (one file per OpenMP thread: bench.py's CPU baseline of the file leg) against lbo_fingerprint_file."""
+    import glob
+    from oracle import oracle as O
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "birds", "*.caf")))[:6]
+    cfg = O.Config()
+    many = O.fingerprint_files(paths, cfg, 1, O.TAIL_NOTHING, 0, 4)
+    for p, got in zip(paths[:3], many[:3]):
+        assert np.array_equal(got, O.fingerprint_file(p, cfg, 1, O.TAIL_NOTHING, 0))
+    assert all(m.shape[1] == cfg.subfp_len for m in many)
