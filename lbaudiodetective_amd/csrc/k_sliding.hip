@@ -52,6 +52,8 @@
 #include "internal.hpp"
 
 #include <cmath>
+#include <type_traits>
+#include <utility>
 #include <cstring>
 #include <mutex>
 
@@ -263,6 +265,17 @@ __device__ __forceinline__ void slot_from_left(Slot& d, const Slot& s) {
 
 // the loads of the steps after the awaited one may still be in flight (2 per step, IN_FLIGHT of them), everything
 // older has landed: memory reads return in order
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a step's ring slots are registers, i.e.
+// compile-time constants
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void for_each_slot_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void for_each_slot(F&& f) {
+    for_each_slot_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
 template <int IN_FLIGHT>
 __device__ __forceinline__ void slot_wait_n(Slot& s) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(s.lo), "+v"(s.hi) : "n"(IN_FLIGHT));
@@ -483,7 +496,8 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
     qn.row = 0;
     if (QN == 1) fetch_q(0, qn);
     // one step; u = i % S is a compile-time constant (the ring's slots are registers)
-    auto step = [&](const int u, const uint32_t i) {
+    auto step = [&](auto u_c, const uint32_t i) {
+        constexpr int u = decltype(u_c)::value;
         if (!MODE_B) {
             uint32_t w[8];
             slot_words(R[(u + 3) % S], w);
@@ -566,17 +580,16 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
     uint32_t i0 = 0;
     bool alive = true;
     for (; i0 + (uint32_t)S <= nq; i0 += (uint32_t)S) {
-#pragma unroll
-        for (int u = 0; u < S; ++u) step(u, i0 + (uint32_t)u);
+        for_each_slot<S>([&](auto u_c) { step(u_c, i0 + (uint32_t)decltype(u_c)::value); });
         if (QN == 1 && !MODE_B && stop_below > 0.0f) {          // (uniform) a ratio is at most 1: an upper bound of every sum
             const float top = fmaxf(fmaxf(acc[0][0] + pend[0], acc[0][1] + pend[1]), fmaxf(acc[0][2] + pend[2], acc[0][3] + pend[3]));
             if (!__any(t.active && top + (float)(nq - (i0 + (uint32_t)S)) >= stop_below)) { alive = false; break; }
         }
     }
     if (alive) {
-#pragma unroll
-        for (int u = 0; u < S - 1; ++u)
-            if (i0 + (uint32_t)u < nq) step(u, i0 + (uint32_t)u);   // uniform
+        for_each_slot<S - 1>([&](auto u_c) {
+            if (i0 + (uint32_t)decltype(u_c)::value < nq) step(u_c, i0 + (uint32_t)decltype(u_c)::value);   // uniform
+        });
     }
     if (QN == 1) {
 #pragma unroll
@@ -1494,17 +1507,24 @@ static void sliding_variant(uint32_t subfp_len, uint32_t n_query, uint32_t range
 }
 
 #ifndef LBAD_MULTI_THREADS
-#define LBAD_MULTI_THREADS 768
+#define LBAD_MULTI_THREADS 1024
 #endif
-constexpr int kMultiThreads = LBAD_MULTI_THREADS;  // several queries per pass: twelve waves, 168 registers per lane
-constexpr uint32_t kMultiLdsWords = 14000;          // dynamic LDS a launch of several queries may ask for (56 KB of the CU's 160)
+#ifndef LBAD_MULTI_THREADS8
+#define LBAD_MULTI_THREADS8 768
+#endif
+#ifndef LBAD_MULTI_MAX
+#define LBAD_MULTI_MAX 4u
+#endif
+constexpr int kMultiThreads = LBAD_MULTI_THREADS;  // two or four queries per pass: sixteen waves like the single scan (126 registers)
+constexpr int kMultiThreads8 = LBAD_MULTI_THREADS8; // eight queries per pass: twelve waves, 168 registers per lane
+constexpr uint32_t kMultiLdsWords = 7000;           // dynamic LDS a launch of several queries may ask for (28 KB next to 131 KB of tables and queues)
 
 // How many of `n_left` queries of n_query sub-fingerprints ONE launch takes: the systolic scan of short queries up to
 // eight, the task scan four or two while their blocks fit the LDS next to the tables.
 uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t n_left) {
     if (n_left <= 1) return n_left;
     if (sliding_short(n_query, ne_max)) return n_left >= 8 ? 8u : (n_left >= 4 ? 4u : 2u);
-    uint32_t g = n_left >= 4 ? 4u : 2u;
+    uint32_t g = n_left >= LBAD_MULTI_MAX ? LBAD_MULTI_MAX : (n_left >= 4 ? 4u : 2u);
     while (g > 1 && (uint64_t)g * (n_query + 1u) * kQWords > kMultiLdsWords) g >>= 1;
     return g;
 }
@@ -1512,7 +1532,7 @@ uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t 
 // Shape of a scan: one workgroup per CU, each with 1 / grid of the tasks of either kind (whole entries).
 SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b, uint32_t n_q) {
     SlideShape sh;
-    const uint64_t waves = n_q > 1 ? kMultiThreads / 64 : kScanWaves;
+    const uint64_t waves = n_q == 8 ? kMultiThreads8 / 64 : (n_q > 1 ? kMultiThreads / 64 : kScanWaves);
     const uint64_t passes = (tasks_a + 63) / 64 + (tasks_b + 63) / 64;
     const uint64_t want = (passes + waves - 1) / waves;
     uint64_t cap = (uint64_t)device_cu_count() * kScanPerCu;
@@ -1638,6 +1658,10 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         if (full) LBAD_SLIDE(true, true, 2, kMultiThreads); else LBAD_SLIDE(false, true, 2, kMultiThreads);
     } else if (n_q == 4) {
         if (full) LBAD_SLIDE(true, true, 4, kMultiThreads); else LBAD_SLIDE(false, true, 4, kMultiThreads);
+#if LBAD_MULTI_MAX >= 8
+    } else if (n_q == 8) {
+        if (full) LBAD_SLIDE(true, true, 8, kMultiThreads8); else LBAD_SLIDE(false, true, 8, kMultiThreads8);
+#endif
     } else {
         return hipErrorInvalidValue;
     }
