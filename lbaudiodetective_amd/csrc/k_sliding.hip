@@ -1100,58 +1100,66 @@ constexpr int kNegInf = (int)0xFF800000u;   // -inf; as a signed integer it sort
 // One chunk = 64 K consecutive records; lane l holds records K l .. K l + K - 1, so a diagonal moves from register
 // set k - 1 to set k inside the lane and crosses to the next lane only from set K - 1 to set 0.
 // MODE 0: every entry in the chunk is longer than the query; 1: none is; 2: mixed.
-template <int K, int MODE>
+// QN queries of one length (round 5): step a of ALL queries before step a + 1 -- their sums travel side by side, a query's
+// chain of dependent adds and look-ups is covered by the others' bit operations (query qi at q + qi q_stride).
+template <int K, int MODE, int QN>
 __device__ __forceinline__ void short_steps(const uint32_t (&P)[K][4], const uint32_t (&N)[K][4], const uint32_t (&nz)[K][4],
                                           const uint32_t (&tri)[K], const bool (&case_a)[K], const bool (&start_b)[K],
-                                          const uint32_t* __restrict__ q, uint32_t nq, const float* s_tri,
-                                          float (&acc)[K], int (&smax)[K]) {
+                                          const uint32_t* __restrict__ q, uint32_t q_stride, uint32_t nq, const float* s_tri,
+                                          float (&acc)[QN][K], int (&smax)[QN][K]) {
     // MODE 2: the mask of a cell is the entry's NZ in A lanes and the query's in B lanes:
     //   m = sel_e & (nz_q | sel_a)   with sel_e = A ? nz_e : ~0,  sel_a = A ? ~0 : 0     (one v_bitop3)
     uint32_t sel_e[K][4], sel_a[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        acc[k] = MODE == 0 ? 0.0f : __int_as_float(kNegInf);   // MODE 0: step 0 adds to the zeros, no reset needed
-        smax[k] = kNegInf;
+#pragma unroll
+        for (int qi = 0; qi < QN; ++qi) {
+            acc[qi][k] = MODE == 0 ? 0.0f : __int_as_float(kNegInf);   // MODE 0: step 0 adds to the zeros, no reset needed
+            smax[qi][k] = kNegInf;
+        }
         sel_a[k] = case_a[k] ? 0xFFFFFFFFu : 0u;
 #pragma unroll
         for (int w = 0; w < 4; ++w) sel_e[k][w] = case_a[k] ? nz[k][w] : 0xFFFFFFFFu;
     }
     for (uint32_t a = 0; a < nq; ++a) {
-        const uint32_t* __restrict__ qa = q + (size_t)a * kQWords;
-        uint32_t nzq[4] = {0, 0, 0, 0}, triq = 0;
-        if (MODE != 0) {
-            // the query's mask and table row in vector registers, once per step for the K cells (a VALU
-            // instruction reads one scalar operand only)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) asm("v_mov_b32 %0, %1" : "=v"(nzq[w]) : "s"(qa[8 + w]));
-            asm("v_mov_b32 %0, %1" : "=v"(triq) : "s"(qa[12]));
-        }
-        float ratio[K];
+        for (int qi = 0; qi < QN; ++qi) {
+            const uint32_t* __restrict__ qa = q + (size_t)qi * q_stride + (size_t)a * kQWords;
+            uint32_t nzq[4] = {0, 0, 0, 0}, triq = 0;
+            if (MODE != 0) {
+                // the query's mask and table row in vector registers, once per step for the K cells (a VALU
+                // instruction reads one scalar operand only)
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint32_t h0 = MODE == 0 ? tri[k] : MODE == 1 ? triq : (case_a[k] ? tri[k] : triq);
-            uint32_t h = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                // a & ~(b ^ c), twice: two v_bitop3_b32 per word (left to itself the compiler builds xor, xor, bitop3)
-                uint32_t m = MODE == 0 ? nz[k][w] : nzq[w];
-                if (MODE == 2) m = __builtin_amdgcn_bitop3_b32(sel_e[k][w], nzq[w], sel_a[k], 0xE0);   // a & (b | c)
-                const uint32_t u = __builtin_amdgcn_bitop3_b32(m, P[k][w], qa[w], 0x90);
-                const uint32_t v = __builtin_amdgcn_bitop3_b32(u, N[k][w], qa[4 + w], 0x90);
-                // h += popc(v) as ONE accumulating v_bcnt (the compiler distributes the table's * 4 over the sum)
-                if (w == 0) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(v), "v"(h0));   // starts at the table row
-                else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(v));
+                for (int w = 0; w < 4; ++w) asm("v_mov_b32 %0, %1" : "=v"(nzq[w]) : "s"(qa[8 + w]));
+                asm("v_mov_b32 %0, %1" : "=v"(triq) : "s"(qa[12]));
             }
-            ratio[k] = s_tri[h];
-        }
-        const float in0 = __uint_as_float(from_left_lane(__float_as_uint(acc[K - 1])));
+            float ratio[K];
 #pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            float sh = k ? acc[k - 1] : in0;
-            if (MODE == 1) sh = start_b[k] ? 0.0f : sh;
-            if (MODE == 2) sh = (start_b[k] || (a == 0 && case_a[k])) ? 0.0f : sh;
-            acc[k] = __fadd_rn(sh, ratio[k]);
-            if (MODE != 0) smax[k] = max(smax[k], __float_as_int(acc[k]));
+            for (int k = 0; k < K; ++k) {
+                const uint32_t h0 = MODE == 0 ? tri[k] : MODE == 1 ? triq : (case_a[k] ? tri[k] : triq);
+                uint32_t h = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    // a & ~(b ^ c), twice: two v_bitop3_b32 per word (left to itself the compiler builds xor, xor, bitop3)
+                    uint32_t m = MODE == 0 ? nz[k][w] : nzq[w];
+                    if (MODE == 2) m = __builtin_amdgcn_bitop3_b32(sel_e[k][w], nzq[w], sel_a[k], 0xE0);   // a & (b | c)
+                    const uint32_t u = __builtin_amdgcn_bitop3_b32(m, P[k][w], qa[w], 0x90);
+                    const uint32_t v = __builtin_amdgcn_bitop3_b32(u, N[k][w], qa[4 + w], 0x90);
+                    // h += popc(v) as ONE accumulating v_bcnt (the compiler distributes the table's * 4 over the sum)
+                    if (w == 0) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(v), "v"(h0));   // starts at the table row
+                    else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(v));
+                }
+                ratio[k] = s_tri[h];
+            }
+            const float in0 = __uint_as_float(from_left_lane(__float_as_uint(acc[qi][K - 1])));
+#pragma unroll
+            for (int k = K - 1; k >= 0; --k) {
+                float sh = k ? acc[qi][k - 1] : in0;
+                if (MODE == 1) sh = start_b[k] ? 0.0f : sh;
+                if (MODE == 2) sh = (start_b[k] || (a == 0 && case_a[k])) ? 0.0f : sh;
+                acc[qi][k] = __fadd_rn(sh, ratio[k]);
+                if (MODE != 0) smax[qi][k] = max(smax[qi][k], __float_as_int(acc[qi][k]));
+            }
         }
     }
 }
@@ -1210,14 +1218,13 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
         }
         const bool any_a = __ballot(some_a) != 0ull, any_b = __ballot(some_b) != 0ull;
 
+        float acc[QN][K];
+        int smax[QN][K];
+        if (!any_b) short_steps<K, 0, QN>(P, N, nz, tri, case_a, start_b, q, q_stride, nq, s_tri, acc, smax);
+        else if (!any_a) short_steps<K, 1, QN>(P, N, nz, tri, case_a, start_b, q, q_stride, nq, s_tri, acc, smax);
+        else short_steps<K, 2, QN>(P, N, nz, tri, case_a, start_b, q, q_stride, nq, s_tri, acc, smax);
 #pragma unroll
         for (int qi = 0; qi < QN; ++qi) {
-            const uint32_t* __restrict__ qq = q + (size_t)qi * q_stride;
-            float acc[K];
-            int smax[K];
-            if (!any_b) short_steps<K, 0>(P, N, nz, tri, case_a, start_b, qq, nq, s_tri, acc, smax);
-            else if (!any_a) short_steps<K, 1>(P, N, nz, tri, case_a, start_b, qq, nq, s_tri, acc, smax);
-            else short_steps<K, 2>(P, N, nz, tri, case_a, start_b, qq, nq, s_tri, acc, smax);
 
             // a record closes a window iff the window lies inside its entry AND inside this chunk.  The exact
             // division (Fp.m:144) runs only where the sum can reach the lane's best so far.
@@ -1226,7 +1233,7 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
             for (int k = 0; k < K; ++k) {
                 const bool closes = case_a[k] ? (isat[k] >= nq - 1u) : (rem[k] == 0u);
                 const bool valid = inb[k] && closes && lane * K + k >= n2[k] - 1u;
-                const float s = case_a[k] ? acc[k] : __int_as_float(smax[k]);
+                const float s = case_a[k] ? acc[qi][k] : __int_as_float(smax[qi][k]);
                 const float n2f = (float)n2[k];
                 const bool need = valid && ((QN == 1 && score_bits != nullptr) || s >= thr * n2f);
                 if (__ballot(need) != 0ull) {
@@ -1523,7 +1530,13 @@ constexpr uint32_t kMultiLdsWords = 7000;           // dynamic LDS a launch of s
 // eight, the task scan four or two while their blocks fit the LDS next to the tables.
 uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t n_left) {
     if (n_left <= 1) return n_left;
-    if (sliding_short(n_query, ne_max)) return n_left >= 8 ? 8u : (n_left >= 4 ? 4u : 2u);
+    if (sliding_short(n_query, ne_max)) {
+        // one record per lane (windows of up to seven records): eight queries side by side; four records per lane: four (eight
+        // would need 213 registers -- two waves per SIMD -- and gain nothing over two launches of four)
+        const uint32_t look = (n_query < ne_max ? n_query : ne_max) - 1u;
+        const uint32_t most = look <= 6u ? 8u : 4u;
+        return n_left >= most ? most : (n_left >= 4 ? 4u : 2u);
+    }
     uint32_t g = n_left >= LBAD_MULTI_MAX ? LBAD_MULTI_MAX : (n_left >= 4 ? 4u : 2u);
     while (g > 1 && (uint64_t)g * (n_query + 1u) * kQWords > kMultiLdsWords) g >>= 1;
     return g;

@@ -5,7 +5,8 @@ a few very long ones past the record's saturating position fields), sub-fingerpr
 1..130 sub-fingerprints (shorter than, equal to and longer than the entries: the systolic kernel for short windows, the
 task kernel's "A" and "B" passes and corpora that need both), every range, planted windows, duplicated entries (lowest index wins), empty
 sub-fingerprints, 11 pairs; the per-entry scores (float bit patterns) and the top-1 against
-oracle/lbad_oracle.c:lbo_corpus_best_ragged; every fifth trial also through save / load and the sharded entry point."""
+oracle/lbad_oracle.c:lbo_corpus_best_ragged; every second trial also a batch of 2..11 queries of one or two lengths in one
+call (round 5), every fifth through save / load and the sharded entry point."""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,6 +17,7 @@ from oracle import oracle as O
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+batches = 0
 t0 = time.time()
 comm = lb.make_comm(0, 1)
 tmp = tempfile.mkdtemp()
@@ -84,6 +86,28 @@ for t in range(trials):
     top = corpus.query(fq, rg)
     ok = np.array_equal(got.view(np.uint32), want.view(np.uint32)) and top[0] == bi and \
         np.float32(top[1]).view(np.uint32) == np.float32(bs).view(np.uint32)
+    if ok and t % 2 == 0:
+        # round 5: a batch of 2..11 queries, one or two lengths mixed, in one call (groups of four / eight share a pass) --
+        # every (index, score bits) against the oracle
+        nb = int(rng.integers(2, 12))
+        nq2 = int(rng.choice([1, 4, 8, 16, 21, 33, 48, 70]))
+        qs = []
+        for b in range(nb):
+            m = nq if (b % 3 or rng.integers(0, 2)) else nq2
+            qq = rand_fp(m, L, p_zero, p_both)
+            s2 = entries[int(rng.integers(0, n))]
+            k2 = min(m, s2.shape[0])
+            o2 = int(rng.integers(0, s2.shape[0] - k2 + 1))
+            qq[:k2] = s2[o2:o2 + k2]
+            qq ^= (rng.random(qq.shape) < 0.03).astype(np.uint8)
+            qs.append(qq)
+        batches = batches + 1
+        gotb = corpus.query_batch([lb.Fingerprint.from_bools(x) for x in qs], rg)
+        for x, g in zip(qs, gotb):
+            wi, ws = O.corpus_best_ragged(x, (flat, counts), rg if rg else L, nthreads=8)
+            if g[0] != wi or np.float32(g[1]).view(np.uint32) != np.float32(ws).view(np.uint32):
+                ok = False
+                print("BATCH MISMATCH", t, L, n, x.shape[0], rg, g, (wi, ws), flush=True)
     if ok and t % 5 == 0:
         p = os.path.join(tmp, "c.lbad")
         corpus.save(p)
@@ -95,5 +119,5 @@ for t in range(trials):
         bad += 1
         wrong = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
         print("RAGGED MISMATCH", t, L, n, shape, nq, rg, look, top, (bi, bs), wrong[:5], lens[wrong[:5]], flush=True)
-print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.1f} s; corpora by kernel path {modes}")
+print(f"{trials} trials, {bad} mismatches, {time.time() - t0:.1f} s; corpora by kernel path {modes}; {batches} batches of 2..11 queries")
 sys.exit(1 if bad else 0)
