@@ -14,6 +14,10 @@ if [ "$R" != "r02" ]; then
   if [ "$R" != "r03" ]; then      # round 4: the long query and the 6000-file call
     PROF_DRIVER=tools/prof_sliding.py PROF_SETS=short tools/prof_run.sh ${R}_sliding_q48 1000000 48 20 70 5
     PROF_DRIVER=tools/exp/files_time.py PROF_SETS=short tools/prof_run.sh ${R}_files6000 100 2
+    if [ "$R" != "r04" ]; then    # round 5: eight queries of one length in one call
+      PROF_DRIVER=tools/prof_sliding_batch.py PROF_SETS=short tools/prof_run.sh ${R}_sliding_batch8_q21 1000000 21 8 5
+      PROF_DRIVER=tools/prof_sliding_batch.py PROF_SETS=short tools/prof_run.sh ${R}_sliding_batch8_q5 1000000 5 8 5
+    fi
   fi
   exit 0
 fi
