@@ -68,7 +68,15 @@ OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerpr
     }
     if (!c->d_scan_out) {
         LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scan_out), (size_t)kQuerySlots * kScanOutWords * 8));
+        c->scan_out_dirty = true;
+    }
+    if (c->scan_out_dirty) {
+        // the result words must be zero between scans: the scans themselves leave them so, but a launch that failed may not
+        // have -- nothing is trusted after one: everything that may still touch the words finishes, then they are cleared
+        for (hipEvent_t e : c->query_ev)
+            if (e) (void)hipEventSynchronize(e);
         LBAD_HIP(hipMemset(c->d_scan_out, 0, (size_t)kQuerySlots * kScanOutWords * 8));
+        c->scan_out_dirty = false;
     }
     const uint32_t slot = (uint32_t)(c->query_seq++ % kQuerySlots);
     if (!c->query_ev[slot]) LBAD_HIP(hipEventCreateWithFlags(&c->query_ev[slot], hipEventDisableTiming));
@@ -105,9 +113,14 @@ OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerpr
     scan.d_ticket = reinterpret_cast<unsigned int*>(scan.d_acc + 8);
     scan.d_keys = keys;
     for (uint32_t i = 0; i < 8; ++i) scan.key_pos[i] = i < n_q ? pos[i] : 0u;
-    LBAD_HIP(launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max, (uint32_t)(c->rec_capacity + kRecordSlack / 2),
-                                    tasks_a, tasks_b, sh, c->d_plan, c->subfp_len, scan, nq, range, index_base,
-                                    reinterpret_cast<unsigned int*>(d_scores), stream, c->bound_pruning, c->prune_from));
+    {
+        const hipError_t launched = launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max,
+                                                           (uint32_t)(c->rec_capacity + kRecordSlack / 2), tasks_a, tasks_b, sh, c->d_plan,
+                                                           c->subfp_len, scan, nq, range, index_base,
+                                                           reinterpret_cast<unsigned int*>(d_scores), stream, c->bound_pruning, c->prune_from);
+        if (launched != hipSuccess) c->scan_out_dirty = true;
+        LBAD_HIP(launched);
+    }
     // behind the SCAN, not just the copy: the slot's device half and its result words are the kernel's, and the launch
     // that reuses the slot eight launches later may arrive on another stream
     LBAD_HIP(hipEventRecord(c->query_ev[slot], stream));

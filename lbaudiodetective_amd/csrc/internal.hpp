@@ -463,6 +463,7 @@ struct LBAudioDetectiveCorpus {
     // per ring slot: the scan's running maxima (8 words) and its ticket, ZERO between scans -- the scan's last workgroup
     // leaves them so (k_sliding.hip: ScanOut); 16 words per slot
     unsigned long long* d_scan_out = nullptr;
+    bool scan_out_dirty = false;                 // a scan's launch failed: clear the words before the next one
     std::mutex shard_lock;                       // the sharded query's key block is one per corpus (api_rccl.cpp)
     bool shard_stale = false;                    // a sharded query timed out: work may still be queued behind the key block
     hipStream_t shard_stale_stream = nullptr;

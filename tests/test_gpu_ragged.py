@@ -16,6 +16,10 @@ CSEED = 0x4C424145
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
 def _rand_fp(rng, n, L, p_zero=0.03, p_both=0.0):
     """n sub-fingerprints of L Booleans: sign pairs 10 / 01, some 00, optionally the 11 no extraction produces."""
     pairs = (L + 1) // 2
@@ -79,13 +83,23 @@ def test_ragged_long_query_against_long_entries(lb, gpu, oracle):
     lens = [5000, 90, 64, 65, 4096, 200, 1, 130]
     entries = [_rand_fp(rng, n, 200) for n in lens]
     corpus, _ = _ragged_corpus(lb, gpu, entries, 200)
-    for nq in (64, 65, 100, 130, 300, 5, 48):
+    # (480 / 481: the longest query whose block lives in LDS next to 131 KB of tables, queues and staging blocks, and the
+    # first that is read through the scalar cache; 108 / 109 and 217 / 218: where batches go from four to two to one query per pass)
+    for nq in (64, 65, 100, 130, 300, 5, 48, 480, 481):
         q = _rand_fp(rng, nq, 200)
         src = entries[0]
         k = min(nq, 60)
         q[:k] = src[4500:4500 + k]
         for rg in (0, 64):
             _check_query(lb, oracle, corpus, entries, q, rg)
+    for nq in (108, 109, 217, 218):
+        qs = [_rand_fp(rng, nq, 200) for _ in range(5)]
+        for i, q in enumerate(qs):
+            q[:50] = entries[0][700 * i + 3:700 * i + 53]
+        got = corpus.query_batch([lb.Fingerprint.from_bools(q) for q in qs])
+        for q, g in zip(qs, got):
+            bi, bs = oracle.corpus_best_ragged(q, entries, 200)
+            assert (g[0], _bits(g[1])) == (bi, _bits(bs)), (nq, g, bi, bs)
 
 
 def test_ragged_ties_zero_and_append(lb, gpu, oracle):
@@ -470,10 +484,6 @@ def test_bench_collective_paths_on_nccl_at_one_rank(gpu):
     assert c["collective_fallback"] is False and c["found_planted"] is True and c["allreduce_ms"] is not None
     assert r["parity"]["bit_exact"] is True if "parity" in r else True
     assert r["self_check"]["ok"]
-
-
-def _bits(x):
-    return int(np.float32(x).view(np.uint32))
 
 
 @pytest.mark.parametrize("L,seed", [(200, 1), (199, 2), (64, 3)])
