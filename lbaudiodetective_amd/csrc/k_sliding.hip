@@ -49,6 +49,13 @@
 //
 // max over offsets commutes with the division by n2 (a correctly rounded division by a positive constant is
 // monotonic), so there is ONE division per task, and only where the sum can still reach the wave's best (Fp.m:144).
+//
+// Round 5: the windows of an "A" pass are fetched as whole lines and dealt out through LDS (fill_windows: lane by lane the
+// eight loads touched 64 lines each -- a quarter of the scan); feeder loads stop at the last record a pass uses; a pass
+// never spans more than 2^26 records (32-bit byte offsets inside it); up to FOUR queries of one length share a pass
+// (QN: LBAudioDetectiveTests.m:57-91 is Q originals against N candidates), eight in the systolic scan of short queries;
+// a single query travels as a kernel argument and the scan clears its own result words (ScanOut: no copy, no memset on
+// the stream in front of a scan).
 #include "internal.hpp"
 
 #include <cmath>
