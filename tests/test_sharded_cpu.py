@@ -69,3 +69,43 @@ def test_allreduce_top1_two_ranks(oracle, planted):
     assert ret[0] == ret[1] == want
     if planted:
         assert want == (min(planted), 1.0)
+
+
+def _lone_worker(rank, world, port, q, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lbaudiodetective_amd as lb
+    calls = []
+    real = dist.all_reduce
+
+    def counting(*a, **k):
+        calls.append("all_reduce")
+        return real(*a, **k)
+
+    dist.all_reduce = counting
+    key = torch.tensor([41], dtype=torch.int64)
+    sharded.FORCE_COLLECTIVES = False
+    sharded.allreduce_best(key)                       # a lone rank skips the collective ...
+    skipped = list(calls)
+    sharded.FORCE_COLLECTIVES = True                  # ... unless told to take every collective branch (bench.py --force-dist)
+    sharded.allreduce_best(key)
+    fq = lb.broadcast_fingerprint(lb.Fingerprint.from_bools(q), src=0)
+    mine = torch.full((4, 5, 32), 7, dtype=torch.uint8)
+    allp = sharded.gather_packed(mine)
+    ret[0] = (skipped, list(calls), int(key.item()), bool(np.array_equal(fq.to_bools(), q)), tuple(allp.shape), bool((allp == 7).all()))
+    dist.all_reduce = real
+    sharded.FORCE_COLLECTIVES = False
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_at_one_rank(oracle):
+    """sharded.FORCE_COLLECTIVES (bench.py --force-dist): in a group of ONE rank the helpers really call the backend -- the
+    N > 1 branches executed without a second rank -- and leave their data unchanged."""
+    q = oracle.synth_entry(5, 99, 5, 200)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_lone_worker, args=(1, port, q, ret), nprocs=1, join=True)
+    skipped, calls, key, same_fp, shape, same_packed = ret[0]
+    assert skipped == [] and calls == ["all_reduce"] and key == 41 and same_fp and shape == (4, 5, 32) and same_packed
