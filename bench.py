@@ -352,7 +352,7 @@ def profile_traffic(variant: int, clips_per_launch: float):
             return None, None
         return (round(tj[key]["hbm_bytes_per_clip"] * clips_per_launch),
                 {"file": "profiles/traffic.json", "sha256": hashlib.sha256(raw).hexdigest()[:16], "entry": key,
-                 "round": tj.get("round"), "measured_by": "committed rocprofv3 --pmc passes, not this run"})
+                 "round": tj[key].get("round", tj.get("round")), "measured_by": "committed rocprofv3 --pmc passes, not this run"})
     except (OSError, ValueError, KeyError):
         return None, None
 
