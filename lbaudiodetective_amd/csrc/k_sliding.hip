@@ -1505,12 +1505,20 @@ hipError_t launch_synth_ragged(uint32_t seed, uint64_t first_entry, uint64_t n_e
 }
 
 // ---- the plan and the scan ---------------------------------------------------------------------------------------------
-// a query (or a corpus) so short that a sliding window reaches back at most kShortLook records: the systolic scan (the
-// records' place fields saturate at 15, which bounds it at 14; measured cross-over with the task kernel: see DESIGN.md)
-#ifndef LBAD_SHORT_LOOK
-#define LBAD_SHORT_LOOK 14
+// The systolic scan (compare_short_kernel) takes
+//   * queries of up to LBAD_SHORT_QUERY = 7 sub-fingerprints: one record per lane, HBM-bound (0.26 ms at 5 against 0.31 of the
+//     task kernel), and
+//   * corpora whose LONGEST entry has at most 15 records (the records' place fields saturate at 15, which bounds the reach
+//     of a window at 14), whatever the query: "B" work on short entries costs the task kernel a window fill per n steps
+//     (4 M entries of 8..15 against a query of 100: 2.1 ms systolic, 15.5 ms task kernel).
+// Queries of 8..15 against longer entries went to the systolic scan's four-records-per-lane form until round 5; with the
+// whole-line window fill the task kernel is 12-15 % faster there (1 M entries of 20..70: 0.315 / 0.336 / 0.352 ms at
+// 8 / 12 / 15 against 0.370 / 0.382 / 0.404) and its batches of eight 13-30 %.
+#ifndef LBAD_SHORT_QUERY
+#define LBAD_SHORT_QUERY 7
 #endif
-bool sliding_short(uint32_t n_query, uint32_t ne_max) { return (n_query < ne_max ? n_query : ne_max) <= LBAD_SHORT_LOOK + 1u; }
+constexpr uint32_t kShortEntries = 15;
+bool sliding_short(uint32_t n_query, uint32_t ne_max) { return n_query <= LBAD_SHORT_QUERY || ne_max <= kShortEntries; }
 
 static void sliding_variant(uint32_t subfp_len, uint32_t n_query, uint32_t range, uint32_t n_q, bool& full, bool& qlds, uint32_t& dyn_lds) {
     const uint4 rm = sliding_range_mask(subfp_len, range);

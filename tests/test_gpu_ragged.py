@@ -66,7 +66,8 @@ def test_ragged_random_shapes(lb, gpu, oracle, L):
     entries[10][1::2] = 0
     corpus, _ = _ragged_corpus(lb, gpu, entries, L)
     assert len(corpus) == n_entries and corpus.subfingerprint_total == int(lens.sum())
-    for nq in (1, 2, 5, 21, 48, 64, 70):
+    # (7 / 8: where the systolic scan of short queries hands over to the task kernel)
+    for nq in (1, 2, 5, 7, 8, 12, 15, 16, 21, 48, 64, 70):
         q = _rand_fp(rng, nq, L, p_zero=0.05, p_both=0.02)
         src = entries[int(rng.integers(0, n_entries))]
         k = min(nq, src.shape[0])
@@ -74,6 +75,31 @@ def test_ragged_random_shapes(lb, gpu, oracle, L):
         q[::2, : max(1, L // 5)] ^= 1
         for rg in sorted({0, L, max(1, L // 2), 1, 7, L + 50, max(1, L - 1)}):
             _check_query(lb, oracle, corpus, entries, q, rg)
+
+
+@pytest.mark.parametrize("longest", [7, 15, 16])
+def test_ragged_short_entries_against_any_query(lb, gpu, oracle, longest):
+    """A corpus whose longest entry has at most 15 sub-fingerprints goes through the systolic scan whatever the query's
+    length (one record per lane up to 7, four above); with a longest entry of 16 the task kernel takes over."""
+    rng = np.random.default_rng(4000 + longest)
+    lens = rng.integers(1, longest + 1, 500)
+    lens[:3] = [longest, 1, max(1, longest - 1)]
+    entries = [_rand_fp(rng, int(n), 200, p_zero=0.03, p_both=0.01) for n in lens]
+    corpus, _ = _ragged_corpus(lb, gpu, entries, 200)
+    for nq in (1, 6, 7, 8, 12, 15, 16, 17, 40, 100):
+        q = _rand_fp(rng, nq, 200, p_zero=0.03, p_both=0.01)
+        src = entries[int(rng.integers(0, len(entries)))]
+        at = int(rng.integers(0, max(1, nq - src.shape[0] + 1)))
+        k = min(nq - at, src.shape[0])
+        q[at:at + k] = src[:k]
+        q[::3, :20] ^= 1
+        for rg in (0, 64, 1):
+            _check_query(lb, oracle, corpus, entries, q, rg)
+    qs = [_rand_fp(rng, 12, 200) for _ in range(9)]
+    got = corpus.query_batch([lb.Fingerprint.from_bools(q) for q in qs])
+    for q, g in zip(qs, got):
+        bi, bs = oracle.corpus_best_ragged(q, entries, 200)
+        assert (g[0], _bits(g[1])) == (bi, _bits(bs)), (longest, g, bi, bs)
 
 
 def test_ragged_long_query_against_long_entries(lb, gpu, oracle):

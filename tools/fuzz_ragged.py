@@ -69,7 +69,7 @@ for t in range(trials):
         q ^= flip.astype(np.uint8)
     rg = int(rng.choice([0, 1, 2, L // 2 + 1, L, L + 7]))
     look = min(nq, int(counts.max())) - 1
-    modes["short (systolic kernel)" if look <= 14 else "A only" if counts.min() > nq else "B only" if counts.max() <= nq else "A and B"] += 1
+    modes["short (systolic kernel)" if (nq <= 7 or counts.max() <= 15) else "A only" if counts.min() > nq else "B only" if counts.max() <= nq else "A and B"] += 1
     corpus = lb.Corpus.ragged(L, n + 1, int(counts.sum()) + 200)
     flat = np.concatenate(entries, axis=0)
     packed = np.stack([lb.pack_subfingerprint(r) for r in flat]).view(np.uint8).reshape(-1, 32)
