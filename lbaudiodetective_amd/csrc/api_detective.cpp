@@ -84,8 +84,9 @@ OSStatus ensure_plan(LBAudioDetective* d) {
     plan_sparse(p);
     // [bands] lo, [bands] hi, [bands] divisor as float bits; then where the band's mean of row w goes inside a frame, as
     // multiplier and offset (w * mult + off): for rows of `bands` floats, and for the compact frame of plan.sparse
-    // (off 0xFFFFFFFF: not stored)
-    std::vector<uint32_t> tbl(7 * (size_t)p.bands);
+    // (off 0xFFFFFFFF: not stored); then the first word of the band's power terms in LDS (BandTable::term_at) and, one word,
+    // the end of the last band's
+    std::vector<uint32_t> tbl(8 * (size_t)p.bands + 1);
     for (uint32_t b = 0; b < p.bands; ++b) {
         tbl[b] = p.table.lo[b];
         tbl[p.bands + b] = p.table.hi[b];
@@ -100,7 +101,9 @@ OSStatus ensure_plan(LBAudioDetective* d) {
         }
         tbl[5 * p.bands + b] = mult;
         tbl[6 * p.bands + b] = off;
+        tbl[7 * p.bands + b] = p.table.term_at[b];
     }
+    tbl[8 * (size_t)p.bands] = p.table.term_end;
     LBAD_HIP(hipMalloc(reinterpret_cast<void**>(&p.d_bands), tbl.size() * sizeof(uint32_t)));
     LBAD_HIP(hipMemcpy(p.d_bands, tbl.data(), tbl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     OSStatus st = plan_kernels(p);

@@ -60,6 +60,14 @@ struct BandTable {
     std::vector<uint32_t> indices;  // bands + 1
     std::vector<uint32_t> lo, hi;   // bin bounds per band
     uint32_t kmin = 0, kmax = 0;    // union of [lo, hi) over non-empty bands (kmin == kmax: nothing read)
+    // Where a window's power terms lie in LDS (k_rows_full.hip, k_rows_stream2.hip): band b's terms in bin order from word
+    // term_at[b], the bands one after the other with a gap in front of a band where its first term would share a bank
+    // (word mod 32) with an earlier band's -- the lanes that add the bands' terms side by side then never meet on a bank.
+    // term_end: first word behind the last band.  ordered == false (a table whose bands overlap or are not in bin order;
+    // make_band_table never makes one): terms by bin number, term_at[b] = lo[b] - kmin.
+    std::vector<uint32_t> term_at;
+    uint32_t term_end = 0;
+    bool ordered = true;
 };
 
 // host-side, double precision; mirrors LBAudioDetective.m:361-371,382-383
@@ -79,7 +87,7 @@ struct Plan {
     BandTable table;
     // device copies
     float* d_tw = nullptr;        // [W/2] re then [W/2] im
-    uint32_t* d_bands = nullptr;  // [bands] lo, [bands] hi, then [bands] divisor as float bits
+    uint32_t* d_bands = nullptr;  // [bands] lo, [bands] hi, [bands] divisor as float bits, ... (api_detective.cpp: eight rows + 1 word)
     float* d_bin_const = nullptr; // per-bin twiddles of the pruned kernel (only when pruned_ok)
     bool pruned_ok = false;
     bool full_ok = false;         // k_rows_full.hip applies

@@ -49,10 +49,27 @@ template <int LOG2L> struct Shape {
         return s64 ? (uint32_t)kSpanDw : ((span_len(stride) + 63u) & ~63u);
     }
     static constexpr int kRowDw = 2 * L + 4;           // transpose row: L values of 8 B, padded by 16 B
-    // one pass of one window; the windows a 32-lane group writes together must start 2 L banks apart
-    static constexpr int kWinDw = L * kRowDw + (L == 8 ? 16 : 32);
-    static constexpr int kTwRowDw = 2 * L + 2;         // cross-lane twiddles of one row: (L - 1) x 8 B, padded
+    // one pass of one window.  L = 16: a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31},
+    // ... (MI355X_MICROARCH.md, LDS) -- half of one window's rows and half of the next one's; with the windows a whole
+    // number of 256-byte bank rows apart the two halves fall on different 16-byte slots (rows r and r + 8 of ONE window
+    // do: 9 r mod 16).  Until round 5 the windows lay 32 words further apart and every such read met a 2-way conflict.
+    static constexpr int kWinDw = L == 16 ? L * kRowDw : L * kRowDw + (L == 8 ? 16 : 32);
+    static_assert(L != 16 || (L * kRowDw) % 64 == 0, "windows a whole number of bank rows apart");
+    // cross-lane twiddles of one row: (L - 1) x 8 B; the 16 rows 2 r + Q a half-wave reads together lie 4 banks apart either
+    // way (L = 16: 60 r mod 64 without padding, 68 r with the two words the smaller shapes keep)
+    static constexpr int kTwRowDw = L == 16 ? 2 * L - 2 : 2 * L + 2;
 };
+
+// words between the power terms of two windows of a wave: the terms, a dump word per lane of the window (the six words a
+// band's last partial batch reads past its end lie in them too), odd (see the kernel)
+__host__ __device__ constexpr uint32_t term_pitch(uint32_t term_end) { return (term_end + 16u) | 1u; }
+// words of a wave's LDS area: the transpose of a pass, later the power terms of its windows (16-byte granules: the transpose
+// is read as float4)
+template <int LOG2L> __host__ __device__ constexpr uint32_t wave_words(uint32_t term_end) {
+    using S = Shape<LOG2L>;
+    const uint32_t a = (uint32_t)(S::WPW * S::kWinDw), b = (uint32_t)S::WPW * term_pitch(term_end);
+    return ((a > b ? a : b) + 3u) & ~3u;
+}
 
 // L-point DIT over the lanes' values of one row.  v[] is in bit-reversed lane order on entry (slot i
 // holds lane brev(i)) and in natural order of u on exit: v[u] = X[k64 + 64 u].  tw[] holds the row's
@@ -174,17 +191,25 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
+    // A window's power terms (round 5): band after band, every band starting on a bank of its own (BandTable::term_at) --
+    // the lanes that add the bands' terms in bin order, one band per lane, never meet on a bank (by bin number they did four
+    // at a time: most of the 35.6 % SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of round 4).  Where each of a lane's 64 bins
+    // goes is a table in LDS (bins no band reads: the lane's dump word behind the last band); the windows of a wave lie an
+    // ODD number of words apart: the 16 lanes of a window store bins two apart, the neighbour window fills the banks between.
+    const uint32_t term_end = band_tbl[8 * nbands];
+    const uint32_t pitch = term_pitch(term_end);
     const uint32_t stride = S64 ? (uint32_t)kStride : stride_arg;
-    // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][claim slot][per wave: transpose pass / power terms]
+    // LDS: [span][cross-lane twiddles: 64 rows][split-pass twiddles][claim slot][where the bins go][per wave: transpose pass / power terms]
     float* span = smem;
     float* ctw = smem + S::span_dw(stride, S64);
     // split-pass twiddles in consumption order: entry e = (slot q, pair u, half) of lane r at [e * L + r]
+    // split-pass twiddles: W^ka of pair p = (slot q, pair u) of lane r at [p * L + r]; the partner bin's W^(N - ka) is
+    // (-re, im) of it, exactly (make_twiddles builds the table by that symmetry) -- until round 5 it had its own entry
     float2* split_tw = reinterpret_cast<float2*>(ctw + 64 * S::kTwRowDw);
-    uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + 64 * L);
-    // (+ 64: one scratch word per lane behind the power terms, the target of stores for bins no band reads)
-    const uint32_t wave_dw = ((uint32_t)(WPW * S::kWinDw) > WPW * nread ? (uint32_t)(WPW * S::kWinDw) : WPW * nread) + 64u;
-    float* tbuf = reinterpret_cast<float*>(claim_slot + 4) + wave * wave_dw;
+    uint32_t* claim_slot = reinterpret_cast<uint32_t*>(split_tw + 32 * L);
+    uint16_t* term_at = reinterpret_cast<uint16_t*>(claim_slot + 4);          // entry e of lane r at [e * L + r], as split_tw
+    const uint32_t wave_dw = wave_words<LOG2L>(term_end);
+    float* tbuf = reinterpret_cast<float*>(term_at + 64 * L) + wave * wave_dw;
     float* vbuf = tbuf;   // the power terms reuse the wave's transpose area after the last pass
 
     // workgroup b runs on XCD b % 8 (observed dispatch order; speed only, see k_rows_pruned.hip)
@@ -219,41 +244,46 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     }
     // every lane meets the same 64 bins in every unit: W^k of each, laid out the way the lanes read them
     // (conflict-free, no index arithmetic in the loop).  Bin numbering as in the split pass below.
-    for (int i = threadIdx.x; i < 64 * L; i += kThreads) {
-        const int rr = i % L, e = i / L, half = e & 1, u = (e >> 1) % L, q = (e >> 1) / L;
+    for (int i = threadIdx.x; i < 32 * L; i += kThreads) {
+        const int rr = i % L, u = (i / L) % L, q = (i / L) / L;
         const int slot = rr * (R / 2) + q;
         int ka = slot + 64 * u;
         if (slot == 0 && u >= L / 2) ka = 32 + 64 * (u - L / 2);
-        int k = half ? N - ka : ka;
-        if (slot == 0 && u == 0 && half) k = N / 2;
-        k &= N - 1;                                    // (bin N of slot 0 never occurs; keeps the index in the table)
-        split_tw[i] = make_float2(tw[k], tw[N + k]);
+        split_tw[i] = make_float2(tw[ka], tw[N + ka]);
+        // pair 0 of slot 0 is (bin 0, bin N / 2): bin 0 takes no twiddle (DC and Nyquist, `dc` below), so the entry holds what
+        // gives its partner W^(N/2) after the change of sign
+        if (slot == 0 && u == 0) split_tw[i] = make_float2(-tw[N / 2], tw[N + N / 2]);
+    }
+    {
+        // where the same 64 bins' power terms go; the bands' edges and first words pass through the (still unused) wave areas
+        uint32_t* edge = reinterpret_cast<uint32_t*>(term_at + 64 * L);        // [lo | hi | first word][nbands]
+        for (uint32_t i = threadIdx.x; i < nbands; i += kThreads) {
+            edge[i] = band_tbl[i];
+            edge[nbands + i] = band_tbl[nbands + i];
+            edge[2 * nbands + i] = band_tbl[7 * nbands + i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * L; i += kThreads) {
+            const int rr = i % L, e = i / L, half = e & 1, u = (e >> 1) % L, q = (e >> 1) / L;
+            const int slot = rr * (R / 2) + q;
+            int ka = slot + 64 * u;
+            if (slot == 0 && u >= L / 2) ka = 32 + 64 * (u - L / 2);
+            int kb = N - ka;
+            if (slot == 0 && u == 0) kb = N / 2;
+            const uint32_t k = (uint32_t)(half ? kb : ka);
+            uint32_t at = term_end + (uint32_t)rr;                             // the lane's dump word
+            if (!(half && kb == ka))
+                for (uint32_t b = 0; b < nbands; ++b)
+                    if (k >= edge[b] && k < edge[nbands + b]) at = edge[2 * nbands + b] + (k - edge[b]);
+            term_at[i] = (uint16_t)at;
+        }
+        // (the loop below starts with a barrier: nobody writes a wave area before every thread is through here)
     }
 
     const int wl = lane / L, r = lane % L;          // window of the wave, lane of the window
     const float inv_norm = 1.0f / (float)(S::W / 4);
     float* tcol = tbuf + wl * S::kWinDw + 2 * r;                 // this lane's column of its window's pass
     const float* trow = tbuf + wl * S::kWinDw + r * S::kRowDw;   // the row this lane receives
-
-    // which of this lane's 64 bins a band reads (bit (q L + u) 2 + half), fixed for the life of the workgroup
-    uint32_t need[2] = {0u, 0u};
-#pragma unroll
-    for (int q = 0; q < R / 2; ++q) {
-        const int slot = r * (R / 2) + q;
-#pragma unroll
-        for (int u = 0; u < L; ++u) {
-            uint32_t ka = (uint32_t)(slot + 64 * u);
-            if (q == 0 && slot == 0 && u >= L / 2) ka = (uint32_t)(32 + 64 * (u - L / 2));
-            uint32_t kb = (uint32_t)N - ka;
-            if (q == 0 && slot == 0 && u == 0) kb = (uint32_t)(N / 2);
-            const int bit = (q * L + u) * 2;
-            if (ka >= kmin && ka < kmax) need[bit >> 5] |= 1u << (bit & 31);
-            if (kb >= kmin && kb < kmax && kb != ka) need[(bit + 1) >> 5] |= 1u << ((bit + 1) & 31);
-        }
-    }
-    // per-lane corrections of the bin numbers of slot 0 (rows 0 and 32 pair with themselves)
-    const int adj_a = r == 0 ? 32 - 32 * L : 0;      // pairs u >= L/2 of slot 0 are bins 32 + 64 (u - L/2)
-    const int adj_b = r == 0 ? N / 2 : 0;            // pair 0 of slot 0: partner bin N/2 instead of N
 
     for (;;) {
     // ---- A: this unit's span has landed (own loads: vmcnt, the other waves': barrier) -------------------
@@ -301,9 +331,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         cross_fft<L>(y, ctw + row * S::kTwRowDw);
     };
     // power term of bin k from A = Z[k], B = Z[N - k] (LBAudioDetective.m:373-396 after the vDSP packing)
-    const float2* my_tw = split_tw + r;
-    auto power = [&](cplx a, cplx b, int e, bool dc) -> float {
-        const float2 wk = my_tw[e * L];                                 // bins outside the bands: computed, never stored
+    const float2* my_tw = split_tw + r_now;
+    auto power = [&](cplx a, cplx b, int p, bool partner, bool dc) -> float {   // (bins outside the bands: computed, never read)
+        float2 wk = my_tw[p * L];
+        if (partner) wk.x = -wk.x;                                      // W^(N - k) = (-re, im) of W^k
         const float sr = a.x + b.x, si = a.y - b.y;
         const float dr = a.x - b.x, di = a.y + b.y;
         float re = __fmaf_rn(wk.x, di, __fmaf_rn(wk.y, dr, sr));
@@ -345,8 +376,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
             if (Q == 0 && u == 0) {
                 if (slot == 0) { a2 = b; b2 = b; b = a; dc = true; }     // (bin 0 from Z[0] alone, bin N/2 from Z[N/2] alone)
             }
-            pw[Q][2 * u] = power(a, b, (Q * L + u) * 2, dc);
-            pw[Q][2 * u + 1] = power(a2, b2, (Q * L + u) * 2 + 1, false);
+            pw[Q][2 * u] = power(a, b, Q * L + u, false, dc);
+            pw[Q][2 * u + 1] = power(a2, b2, Q * L + u, true, false);
         }
         // pin the order: without this the scheduler sinks every split pass below the last transpose and
         // keeps the outputs of all passes alive at once (several hundred bytes of scratch)
@@ -368,24 +399,16 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // ---- D: power terms -> LDS (every read of the last pass has returned: the values are in
     //         registers), band means in bin order -----------------------------------------------------
     {
-        // a power term goes to vbuf[window][bin - kmin] when a band reads the bin, to the lane's scratch
-        // word otherwise: no bin arithmetic, predicates or divergent stores in the loop
-        float* vwin = vbuf + wl * nread - kmin;
-        float* dummy = vbuf + WPW * nread + lane;
+        // a power term goes where the table says: no bin arithmetic, predicates or divergent stores in the loop
+        float* vwin = vbuf + wl * pitch;
+        const uint16_t* my_at = term_at + r_now;
 #pragma unroll
         for (int q = 0; q < R / 2; ++q) {
-            const int slot = r_now * (R / 2) + q;
 #pragma unroll
             for (int u = 0; u < L; ++u) {
-                int ka = slot + 64 * u;
-                if (q == 0 && u >= L / 2) ka += adj_a;
-                int kb = N - ka;
-                if (q == 0 && u == 0) kb -= adj_b;
-                const int bit = (q * L + u) * 2;
-                float* pa = (need[bit >> 5] >> (bit & 31)) & 1u ? vwin + ka : dummy;
-                float* pb = (need[(bit + 1) >> 5] >> ((bit + 1) & 31)) & 1u ? vwin + kb : dummy;
-                *pa = pw[q][2 * u];
-                *pb = pw[q][2 * u + 1];
+                const int e = (q * L + u) * 2;
+                vwin[my_at[e * L]] = pw[q][2 * u];
+                vwin[my_at[(e + 1) * L]] = pw[q][2 * u + 1];
             }
         }
     }
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
             // the last w % 8 terms are read from the lane's own offset -- what lies behind a band (another band's
             // terms, padding, the scratch words) is read and selected away, never added
             const uint32_t width = hi > lo ? hi - lo : 0;
-            const float* vb = vbuf + ww * nread + (lo - kmin);
+            const float* vb = vbuf + ww * pitch + band_tbl[7 * nbands + band];
             const uint32_t full = width >> 3, rem = width & 7;
             for (uint32_t b = 0; b < full; ++b) {
                 float v[8];
@@ -431,19 +454,17 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     }
 }
 
-template <int LOG2L> size_t lds_bytes(uint32_t kmin, uint32_t kmax, uint32_t stride) {
+template <int LOG2L> size_t lds_bytes(uint32_t term_end, uint32_t stride) {
     using S = Shape<LOG2L>;
-    const uint32_t nread = (kmax - kmin + 63u) & ~63u;
-    const uint32_t wave_dw = ((uint32_t)(S::WPW * S::kWinDw) > S::WPW * nread ? (uint32_t)(S::WPW * S::kWinDw) : S::WPW * nread) + 64u;
-    return ((size_t)S::span_dw(stride, stride == (uint32_t)kStride) + 64 * S::kTwRowDw + 2 * 64 * (size_t)S::L + 4 +
-            (size_t)kWaves * wave_dw) * sizeof(float);
+    return ((size_t)S::span_dw(stride, stride == (uint32_t)kStride) + 64 * S::kTwRowDw + 2 * 32 * (size_t)S::L + 4 +
+            (size_t)kWaves * wave_words<LOG2L>(term_end)) * sizeof(float) + 64 * (size_t)S::L * sizeof(uint16_t);
 }
 
 template <int LOG2L, int FMT, bool S64>
 hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frames, uint64_t samples_per_clip,
                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     using S = Shape<LOG2L>;
-    const size_t lds = lds_bytes<LOG2L>(plan.table.kmin, plan.table.kmax, plan.stride);
+    const size_t lds = lds_bytes<LOG2L>(plan.table.term_end, plan.stride);
     static PerDevice attr;
     if (attr.changed(lds)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT, S64>),
@@ -493,10 +514,10 @@ bool rows_full_supported(const Plan& p) {
     const uint32_t step = p.window / 64;
     for (int t = 0; t < 32; ++t)
         if (re[step * t] != kTw64Re[t] || im[step * t] != kTw64Im[t]) return false;
-    const size_t lds = p.window == 256    ? lds_bytes<1>(p.table.kmin, p.table.kmax, p.stride)
-                       : p.window == 512  ? lds_bytes<2>(p.table.kmin, p.table.kmax, p.stride)
-                       : p.window == 1024 ? lds_bytes<3>(p.table.kmin, p.table.kmax, p.stride)
-                                          : lds_bytes<4>(p.table.kmin, p.table.kmax, p.stride);
+    const size_t lds = p.window == 256    ? lds_bytes<1>(p.table.term_end, p.stride)
+                       : p.window == 512  ? lds_bytes<2>(p.table.term_end, p.stride)
+                       : p.window == 1024 ? lds_bytes<3>(p.table.term_end, p.stride)
+                                          : lds_bytes<4>(p.table.term_end, p.stride);
     return lds <= 80 * 1024;
 }
 

@@ -38,12 +38,22 @@ constexpr int kChunksPerFrame = 128 / kChunk;
 constexpr int kRowDw = 68;                    // 32 complex + 16 B: conflict-free ds_read_b128 across lanes
 constexpr int kTDw = 64 * kRowDw;             // two windows x 32 rows
 constexpr int kCrossTw = 31;                  // 1 + 2 + 4 + 8 + 16 twiddles of a row's cross transform
+constexpr int kCtwDw = 66;                    // pitch of a row's twiddles: 32 lanes x ds_read_b64 land on 64 different banks
+                                              // (round 5; at the transpose's pitch of 68 lanes n and n + 16 shared theirs)
 constexpr int kMaxTerms = 56;                 // bins of the widest band (the band sums are unrolled this far)
-constexpr int kPowerDw = kN + kMaxTerms;      // power terms of a window by bin number, read overrun of the last band
-constexpr int kLdsDw = kWaves * kTDw + 32 * kRowDw + 32 * 32 * 2;
-constexpr int kLdsBytes = kLdsDw * 4;         // 156 160 B: one workgroup per CU
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-static_assert(2 * kPowerDw <= kTDw, "the power terms of two windows reuse the transpose area");
+// Power terms of a window (round 5): NOT by bin number -- lane b of a half-wave adds band b's terms in bin order, and with
+// the bands' first bins anywhere the 32 lanes of a ds_read_b32 met on the same banks four at a time (189 extra LDS cycles
+// on 63 reads per window with the default table: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 45.7 %, most of it here).  The
+// bands' terms now lie one band after the other, every band starting on a bank (word mod 32) of its own (BandTable::
+// term_at, made by the host: 58 words of gaps for the default table): term j of every band is on a different bank.  The
+// lanes that PRODUCE the terms (row lane n: bins row + 32 q) take each bin's word from a table in LDS; a store of 32
+// consecutive bins then conflicts only where a band ends (11 extra cycles on 22 stores); bins no band reads go to a dump
+// word per lane behind the last band.
+constexpr int kPowerDw = kTDw / 2;            // one window's area: <= 1024 terms + 32 x 31 gap words + the read overrun
+static_assert(kN + 32 * 31 + kMaxTerms + 7 <= kPowerDw, "skewed power terms of a window fit its half of the transpose area");
+constexpr int kLdsDw = kWaves * kTDw + 32 * kCtwDw + 32 * 32 * 2 + 32 * 32;
+constexpr int kLdsBytes = kLdsDw * 4;         // 159 744 B (+ 384 B static): one workgroup per CU
+static_assert(kLdsBytes + 512 <= 160 * 1024, "LDS budget");
 
 // row of lane l (within its window): lanes 2 p, 2 p + 1 hold the partner rows (p, 32 - p); pair 0 is (0, 16)
 __device__ __forceinline__ int row_of_lane(int l) {
@@ -92,8 +102,10 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     float* tbuf = smem + wave * kTDw;                       // this wave's transpose / power terms
-    float* ctw = smem + kWaves * kTDw;                      // [row lane 0..31][31 complex], pitch kRowDw
-    float2* stw = reinterpret_cast<float2*>(ctw + 32 * kRowDw);   // [q][row lane]
+    float* ctw = smem + kWaves * kTDw;                      // [row lane 0..31][31 complex], pitch kCtwDw
+    float2* stw = reinterpret_cast<float2*>(ctw + 32 * kCtwDw);   // [q][row lane]
+    uint32_t* term_at = reinterpret_cast<uint32_t*>(stw + 32 * 32);   // [q][row lane]: word of bin row + 32 q in the window's area
+    __shared__ uint32_t s_edge[3][32];                      // the bands' first bins, ends and first words
 
     // ---- once per workgroup: tables --------------------------------------------------------------------
     for (int i = threadIdx.x; i < 32 * kCrossTw; i += kThreads) {
@@ -103,8 +115,24 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
         while ((1 << s) - 1 <= e) ++s;                      // cross stage s = 1..5 (overall stage 5 + s)
         const int jj = e - ((1 << (s - 1)) - 1);
         const uint32_t ti = (uint32_t)(a + 32 * jj) << (6 - s);     // W_(32 * 2^s)^(a + 32 jj)
-        ctw[l * kRowDw + 2 * e] = tw[ti];
-        ctw[l * kRowDw + 2 * e + 1] = tw[kN + ti];
+        ctw[l * kCtwDw + 2 * e] = tw[ti];
+        ctw[l * kCtwDw + 2 * e + 1] = tw[kN + ti];
+    }
+    if (threadIdx.x < 32) {
+        const bool live = threadIdx.x < nbands;
+        s_edge[0][threadIdx.x] = live ? band_tbl[threadIdx.x] : 0u;
+        s_edge[1][threadIdx.x] = live ? band_tbl[nbands + threadIdx.x] : 0u;
+        s_edge[2][threadIdx.x] = live ? band_tbl[7 * nbands + threadIdx.x] : 0u;
+    }
+    const uint32_t term_end = band_tbl[8 * nbands];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32; i += kThreads) {
+        const int l = i % 32;
+        const uint32_t k = (uint32_t)(row_of_lane(l) + 32 * (i / 32));
+        uint32_t at = term_end + (uint32_t)l;               // no band reads the bin: the lane's dump word
+        for (uint32_t b = 0; b < 32; ++b)
+            if (k >= s_edge[0][b] && k < s_edge[1][b]) at = s_edge[2][b] + (k - s_edge[0][b]);
+        term_at[i] = at;
     }
     for (int i = threadIdx.x; i < 32 * 32; i += kThreads) {
         const int q = i / 32, l = i % 32;
@@ -114,18 +142,18 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
     __syncthreads();
 
     const int n = lane & 31, s = lane >> 5;                  // phase 1: residue and run; phase 2: row lane and window
-    const int my_row = row_of_lane(n);
     const bool special = n < 2;                              // rows 0 and 16 pair with themselves
     const float inv_norm = 1.0f / (float)(kW / 4);
     float* my_col = tbuf + 32 * s * kRowDw + 2 * n;          // column n of this run's 32 rows
     const float* my_trow = tbuf + lane * kRowDw;             // the row this lane transforms
-    const float* my_ctw = ctw + n * kRowDw;
-    float* vbuf = tbuf + s * kPowerDw;                       // power terms of this lane's window, indexed by bin
-    float* my_bins = vbuf + my_row;                          // this lane's bins row + 32 q (all stored, the bands pick)
-    uint32_t b_lo = 0, b_full = 0, b_rem = 0;
+    const float* my_ctw = ctw + n * kCtwDw;
+    float* vbuf = tbuf + s * kPowerDw;                       // power terms of this lane's window, band after band
+    const uint32_t* my_term_at = term_at + n;                // where this lane's bins row + 32 q go
+    uint32_t b_at = 0, b_full = 0, b_rem = 0;
     float b_div = 1.0f;
     if ((uint32_t)n < nbands) {
-        b_lo = band_tbl[n];
+        const uint32_t b_lo = band_tbl[n];
+        b_at = s_edge[2][n];
         const uint32_t b_hi = band_tbl[nbands + n];
         const uint32_t b_width = b_hi > b_lo ? b_hi - b_lo : 0;
         b_full = b_width >> 3;                               // whole batches of 8 terms
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
 #pragma unroll
             for (int q = QLO; q < QHI; ++q) {
 #ifdef LBAD_EXP_NOSPLIT
-                my_bins[32 * q] = y[q].x + y[31 - q].y;
+                vbuf[my_term_at[32 * q]] = y[q].x + y[31 - q].y;
 #else
                 {
                     const int j = 31 - q;
@@ -234,7 +262,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                     const cplx zn = mk(fminf(zs.x, z.x), fminf(zs.y, z.y));
                     const cplx sq = zn * zn;
                     const float t = __fadd_rn(sq.x, sq.y);
-                    my_bins[32 * q] = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;   // LBAudioDetective.m:398-401, at the source
+                    vbuf[my_term_at[32 * q]] = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;   // LBAudioDetective.m:398-401, at the source
                 }
 #endif
             }
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
             {
                 // A band of width w is w / 8 whole batches of 8 terms -- added under a lane mask, no per-term
                 // select -- and one partial batch of w % 8 terms read from the lane's own offset.
-                const float* vb = vbuf + b_lo;
+                const float* vb = vbuf + b_at;
                 float v[kMaxTerms], vt[7];
 #pragma unroll
                 for (uint32_t b = 0; b < kMaxTerms / 8; ++b) {
@@ -283,6 +311,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
 bool rows_stream2_supported(const Plan& p) {
     if (p.window != (uint32_t)kW || p.stride != (uint32_t)kStride || p.bands == 0 || p.bands > 32) return false;
     if (p.table.kmax <= p.table.kmin || p.table.kmin < 1 || p.table.kmax > (uint32_t)kN) return false;
+    if (!p.table.ordered) return false;                        // (bands in bin order, no bin in two of them: the terms' layout)
     for (uint32_t b = 0; b < p.bands; ++b)
         if (p.table.hi[b] > p.table.lo[b] && p.table.hi[b] - p.table.lo[b] > (uint32_t)kMaxTerms) return false;
     std::vector<float> re, im;

@@ -75,6 +75,29 @@ void make_band_table(double sample_rate, uint32_t window, uint32_t bands, BandTa
     if (kmin > kmax) kmin = kmax = 0;
     out.kmin = kmin;
     out.kmax = kmax;
+    // the terms' layout (internal.hpp): greedy, every band on the first bank none of the (up to 32) bands before it started on
+    out.term_at.assign(bands, 0);
+    out.ordered = true;
+    uint32_t last_hi = 0;
+    for (uint32_t i = 0; i < bands; ++i) {
+        if (out.hi[i] <= out.lo[i]) continue;
+        if (out.lo[i] < last_hi) out.ordered = false;
+        last_hi = out.hi[i];
+    }
+    if (out.ordered) {
+        uint32_t used = 0, at = 0;
+        for (uint32_t i = 0; i < bands; ++i) {
+            if (used == 0xFFFFFFFFu) used = 0;
+            while ((used >> (at & 31u)) & 1u) ++at;
+            used |= 1u << (at & 31u);
+            out.term_at[i] = at;
+            at += out.hi[i] > out.lo[i] ? out.hi[i] - out.lo[i] : 0u;
+        }
+        out.term_end = at;
+    } else {
+        for (uint32_t i = 0; i < bands; ++i) out.term_at[i] = out.hi[i] > out.lo[i] ? out.lo[i] - kmin : 0u;
+        out.term_end = kmax - kmin;
+    }
 }
 
 void make_band_bounds(double sample_rate, uint32_t window, uint32_t n_frames, const BandTable& table, uint32_t* lo,
