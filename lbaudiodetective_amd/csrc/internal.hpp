@@ -68,6 +68,9 @@ struct BandTable {
     std::vector<uint32_t> term_at;
     uint32_t term_end = 0;
     bool ordered = true;
+    // 2048-sample windows on k_rows_full.hip: bit (q * 16 + u) * 2 + half is set when NO lane's bin of that place in the split
+    // pass (k_rows_full.hip: slot_work) is read by a band -- the kernel has an instance that leaves the default table's out
+    uint64_t unread_terms16 = 0;
 };
 
 // host-side, double precision; mirrors LBAudioDetective.m:361-371,382-383

@@ -60,6 +60,18 @@ template <int LOG2L> struct Shape {
     static constexpr int kTwRowDw = L == 16 ? 2 * L - 2 : 2 * L + 2;
 };
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int COUNT, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, COUNT>{}); }
+
+// The split-pass terms no band of the DEFAULT table (5512 Hz, 2048-sample windows, 32 bands: bins 86..758) reads from ANY
+// lane, as bits (q * 16 + u) * 2 + half (BandTable::unread_terms16): 14 of the 64 places -- the lanes' bins 0..31 and
+// 993..1024 and most of 768..992; lane 0's slot 0 pairs rows 0 and 32 with themselves and keeps six more alive.
+// rows_full_kernel<4, ...> has an instance that does not compute them (- 7 % vector instructions); any table whose
+// unread set contains this one may use it.
+constexpr uint64_t kDefaultUnread16 = 0xd50000ab000000a9ull;
+
 // words between the power terms of two windows of a wave: the terms, a dump word per lane of the window (the six words a
 // band's last partial batch reads past its end lie in them too), odd (see the kernel)
 __host__ __device__ constexpr uint32_t term_pitch(uint32_t term_end) { return (term_end + 16u) | 1u; }
@@ -176,7 +188,7 @@ __device__ __forceinline__ void span_to_lds(const void* __restrict__ pcm_raw, ui
 // frames, the first ones are static, the rest is claimed a frame at a time from a per-XCD counter; the
 // span of unit u + 1 streams into the span buffer as soon as every wave holds its points of unit u.  The
 // twiddle tables are built once per workgroup.
-template <int LOG2L, int FMT, bool S64>
+template <int LOG2L, int FMT, bool S64, uint64_t SKIP>
 __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __restrict__ pcm_raw, uint32_t stride_arg,
                                                                  uint64_t samples_per_clip,
                                                                  uint32_t frames_per_clip, uint64_t n_units,
@@ -332,23 +344,38 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     };
     // power term of bin k from A = Z[k], B = Z[N - k] (LBAudioDetective.m:373-396 after the vDSP packing)
     const float2* my_tw = split_tw + r_now;
-    auto power = [&](cplx a, cplx b, int p, bool partner, bool dc) -> float {   // (bins outside the bands: computed, never read)
-        float2 wk = my_tw[p * L];
-        if (partner) wk.x = -wk.x;                                      // W^(N - k) = (-re, im) of W^k
-        const float sr = a.x + b.x, si = a.y - b.y;
-        const float dr = a.x - b.x, di = a.y + b.y;
-        float re = __fmaf_rn(wk.x, di, __fmaf_rn(wk.y, dr, sr));
-        float im = __fmaf_rn(-wk.x, dr, __fmaf_rn(wk.y, di, si));
+    // Written on (re, im) pairs (round 5): a + conj(b) and a - conj(b) as one packed add each; the two nested fmas of re
+    // and of im as two v_pk_fma_f32 that take the twiddle pair as it comes from LDS -- op_sel picks wi for both halves
+    // in the first and wr in the second, where the second operand's halves swap (di, dr) and neg_hi / neg_lo puts the
+    // sign on wr: on the high half for W^k, on the low half for the partner's W^(N - k) = (-wr, wi).  Per half the same
+    // correctly rounded operations on the same operands as
+    //   re = fma(wr, di, fma(wi, dr, sr)),  im = fma(-wr, dr, fma(wi, di, si)).
+    const cplx inv2 = mk(inv_norm, inv_norm);
+    auto power = [&](cplx a, cplx b, int p, auto partner_tag, bool dc) -> float {   // (bins outside the bands: computed, never read)
+        constexpr bool PARTNER = decltype(partner_tag)::value;
+        const cplx wk = *reinterpret_cast<const cplx*>(my_tw + p * L);
+        cplx sm, df, z1, z;
+        asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(sm) : "v"(a), "v"(b));
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(df) : "v"(a), "v"(b));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(z1) : "v"(wk), "v"(df), "v"(sm));
+        if constexpr (PARTNER)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(z) : "v"(wk), "v"(df), "v"(z1));
+        else
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(z) : "v"(wk), "v"(df), "v"(z1));
         if (dc) {                                                       // DC and Nyquist share bin 0
-            const float sm = a.x + a.y, df = a.x - a.y;
-            re = sm + sm;
-            im = df + df;
+            const float s2 = a.x + a.y, d2 = a.x - a.y;
+            z = mk(s2 + s2, d2 + d2);
         }
         // "if (x > 0) x *= 1 / (W/4)" is min(x * 2^-n, x): the same single rounding for x > 0, x itself
         // otherwise (negative, zero of either sign, NaN)
-        re = fminf(__fmul_rn(re, inv_norm), re);
-        im = fminf(__fmul_rn(im, inv_norm), im);
-        const float t = __fadd_rn(__fmul_rn(re, re), __fmul_rn(im, im));
+        // (v_min_f32 by hand: behind inline assembly the compiler does not know that z is no signalling NaN and would
+        // put a v_max_f32 z, z in front of every fminf)
+        const cplx zs = z * inv2;
+        cplx zn;
+        asm("v_min_f32 %0, %1, %2" : "=v"(zn.x) : "v"(zs.x), "v"(z.x));
+        asm("v_min_f32 %0, %1, %2" : "=v"(zn.y) : "v"(zs.y), "v"(z.y));
+        const cplx sq = zn * zn;
+        const float t = __fadd_rn(sq.x, sq.y);
         return (t == t && fabsf(t) != INFINITY) ? t : 0.0f;             // LBAudioDetective.m:398-401, at the source
     };
     auto slot_work = [&](auto q_tag) {
@@ -361,8 +388,9 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         // Split pass by pairs: bin ka = row_a + 64 u and its partner kb = N - ka = row_b + 64 (L - 1 - u).
         // Slot 0 (rows 0 and 32 pair with themselves) re-indexes: pair 0 = (bin 0, bin N/2), pairs
         // 1..L/2-1 = (64 u, 64 (L - u)) of row 0, pairs L/2.. = (32 + 64 v, 32 + 64 (L - 1 - v)) of row 32.
-#pragma unroll
-        for (int u = 0; u < L; ++u) {
+        static_for<L>([&](auto u_tag) {
+            constexpr int u = decltype(u_tag)::value;
+            constexpr int e = (Q * L + u) * 2;
             cplx a = ya[u], b = yb[L - 1 - u];
             if constexpr (Q == 0) {
                 if (slot == 0) {
@@ -376,9 +404,11 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
             if (Q == 0 && u == 0) {
                 if (slot == 0) { a2 = b; b2 = b; b = a; dc = true; }     // (bin 0 from Z[0] alone, bin N/2 from Z[N/2] alone)
             }
-            pw[Q][2 * u] = power(a, b, Q * L + u, false, dc);
-            pw[Q][2 * u + 1] = power(a2, b2, Q * L + u, true, false);
-        }
+            pw[Q][2 * u] = 0.0f;
+            pw[Q][2 * u + 1] = 0.0f;
+            if constexpr (((SKIP >> e) & 1ull) == 0) pw[Q][2 * u] = power(a, b, Q * L + u, std::false_type{}, dc);
+            if constexpr (((SKIP >> (e + 1)) & 1ull) == 0) pw[Q][2 * u + 1] = power(a2, b2, Q * L + u, std::true_type{}, false);
+        });
         // pin the order: without this the scheduler sinks every split pass below the last transpose and
         // keeps the outputs of all passes alive at once (several hundred bytes of scratch)
 #pragma unroll
@@ -402,15 +432,11 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         // a power term goes where the table says: no bin arithmetic, predicates or divergent stores in the loop
         float* vwin = vbuf + wl * pitch;
         const uint16_t* my_at = term_at + r_now;
-#pragma unroll
-        for (int q = 0; q < R / 2; ++q) {
-#pragma unroll
-            for (int u = 0; u < L; ++u) {
-                const int e = (q * L + u) * 2;
-                vwin[my_at[e * L]] = pw[q][2 * u];
-                vwin[my_at[(e + 1) * L]] = pw[q][2 * u + 1];
-            }
-        }
+        static_for<(R / 2) * L>([&](auto p_tag) {
+            constexpr int e = decltype(p_tag)::value * 2, q = decltype(p_tag)::value / L, u = decltype(p_tag)::value % L;
+            if constexpr (((SKIP >> e) & 1ull) == 0) vwin[my_at[e * L]] = pw[q][2 * u];
+            if constexpr (((SKIP >> (e + 1)) & 1ull) == 0) vwin[my_at[(e + 1) * L]] = pw[q][2 * u + 1];
+        });
     }
     // (wave-local: LDS operations of one wave execute in order)
     // task t = lane + 64 i -> window t / nbands of the wave, band t % nbands; rows of a wave's windows are
@@ -460,14 +486,14 @@ template <int LOG2L> size_t lds_bytes(uint32_t term_end, uint32_t stride) {
             (size_t)kWaves * wave_words<LOG2L>(term_end)) * sizeof(float) + 64 * (size_t)S::L * sizeof(uint16_t);
 }
 
-template <int LOG2L, int FMT, bool S64>
+template <int LOG2L, int FMT, bool S64, uint64_t SKIP = 0>
 hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frames, uint64_t samples_per_clip,
                            uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
     using S = Shape<LOG2L>;
     const size_t lds = lds_bytes<LOG2L>(plan.table.term_end, plan.stride);
     static PerDevice attr;
     if (attr.changed(lds)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT, S64>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows_full_kernel<LOG2L, FMT, S64, SKIP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
@@ -480,7 +506,7 @@ hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frame
     if (wg_per_xcd > units_per_xcd / U) wg_per_xcd = units_per_xcd / U;
     hipError_t e = hipMemsetAsync(plan.d_claim, 0, 8 * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT, S64>), dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), lds, stream,
+    hipLaunchKernelGGL((rows_full_kernel<LOG2L, FMT, S64, SKIP>), dim3((uint32_t)(wg_per_xcd * 8)), dim3(kThreads), lds, stream,
                        d_pcm, plan.stride, samples_per_clip, frames_per_clip, n_units, units_per_xcd, plan.d_tw, plan.d_bands,
                        plan.bands, plan.table.kmin, plan.table.kmax, plan.d_claim, d_frames);
     return hipGetLastError();
@@ -489,9 +515,15 @@ hipError_t launch_full_fmt(const Plan& plan, const void* d_pcm, uint64_t n_frame
 template <int LOG2L>
 hipError_t launch_full(const Plan& plan, const void* d_pcm, uint32_t fmt, uint64_t n_frames, uint64_t samples_per_clip,
                        uint32_t frames_per_clip, float* d_frames, hipStream_t stream) {
-    if (plan.stride != (uint32_t)kStride)                  // any other stride: float32 input only (rows_full_supported_fmt)
-        return fmt == 0 ? launch_full_fmt<LOG2L, 0, false>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream)
-                        : hipErrorInvalidValue;
+    // 2048-sample windows, float32: the instance without the terms the default table never reads, when this table does not either
+    const bool lean = LOG2L == 4 && fmt == 0 && (plan.table.unread_terms16 & kDefaultUnread16) == kDefaultUnread16;
+    constexpr uint64_t kLean = LOG2L == 4 ? kDefaultUnread16 : 0ull;
+    if (plan.stride != (uint32_t)kStride) {                // any other stride: float32 input only (rows_full_supported_fmt)
+        if (fmt != 0) return hipErrorInvalidValue;
+        if (lean) return launch_full_fmt<LOG2L, 0, false, kLean>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+        return launch_full_fmt<LOG2L, 0, false>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
+    }
+    if (lean) return launch_full_fmt<LOG2L, 0, true, kLean>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
     switch (fmt) {
         case 0: return launch_full_fmt<LOG2L, 0, true>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);
         case 1: return launch_full_fmt<LOG2L, 1, true>(plan, d_pcm, n_frames, samples_per_clip, frames_per_clip, d_frames, stream);

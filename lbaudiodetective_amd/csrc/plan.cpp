@@ -98,6 +98,30 @@ void make_band_table(double sample_rate, uint32_t window, uint32_t bands, BandTa
         for (uint32_t i = 0; i < bands; ++i) out.term_at[i] = out.hi[i] > out.lo[i] ? out.lo[i] - kmin : 0u;
         out.term_end = kmax - kmin;
     }
+    out.unread_terms16 = 0;
+    if (window == 2048) {
+        // the bins of k_rows_full.hip's split pass at 16 lanes per window: lane r, slot 2 r + q, pair u -> bin slot + 64 u and
+        // its partner 1024 - bin (slot 0 pairs rows 0 and 32 with themselves: the same re-indexing as in the kernel)
+        std::vector<uint8_t> read(nyq + 1, 0);
+        for (uint32_t i = 0; i < bands; ++i)
+            for (uint32_t k = out.lo[i]; k < out.hi[i]; ++k) read[k] = 1;
+        const int L = 16, N = 1024;
+        for (int q = 0; q < 2; ++q)
+            for (int u = 0; u < L; ++u)
+                for (int half = 0; half < 2; ++half) {
+                    bool unread = true;
+                    for (int r = 0; r < L; ++r) {
+                        const int slot = 2 * r + q;
+                        int ka = slot + 64 * u;
+                        if (slot == 0 && u >= L / 2) ka = 32 + 64 * (u - L / 2);
+                        int kb = N - ka;
+                        if (slot == 0 && u == 0) kb = N / 2;
+                        if (half && kb == ka) continue;
+                        if (read[half ? kb : ka]) unread = false;
+                    }
+                    if (unread) out.unread_terms16 |= 1ull << ((q * L + u) * 2 + half);
+                }
+    }
 }
 
 void make_band_bounds(double sample_rate, uint32_t window, uint32_t n_frames, const BandTable& table, uint32_t* lo,
