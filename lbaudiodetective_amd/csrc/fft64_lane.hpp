@@ -71,5 +71,18 @@ static __device__ __forceinline__ cplx madd(cplx u, float wr, float wi, cplx v) 
     return fma2(mk(wr, wr), v, fma2(mk(-wi, wi), v.yx, u));
 }
 
+// u + w v and u - w v with the twiddle as the (wr, wi) pair it is read as (round 5): op_sel broadcasts wi, then wr, to both
+// halves, op_sel on v swaps (v.y, v.x), neg_lo / neg_hi carry the signs -- the nesting and the operands of madd() / msub(),
+// i.e. fma(wr, v, fma(-+wi, v.yx, u)) per half, without the two or three moves per twiddle the compiler spends on
+// building (-wi, wi) and (wi, -wi) in registers.
+// (the inner fmas of both results first: a packed fma that follows the one it depends on directly costs a wait state)
+static __device__ __forceinline__ void bfly_w(cplx u, cplx w, cplx v, cplx& plus, cplx& minus) {
+    cplx tp, tm;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(tp) : "v"(w), "v"(v), "v"(u));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(tm) : "v"(w), "v"(v), "v"(u));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(plus) : "v"(w), "v"(v), "v"(tp));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(minus) : "v"(w), "v"(v), "v"(tm));
+}
+
 }  // namespace lane64
 }  // namespace lbad

@@ -98,10 +98,9 @@ __device__ __forceinline__ void cross_fft(cplx (&v)[L], const float* tw) {
         for (int b = 0; b < L; b += 2 * half)
 #pragma unroll
             for (int jj = 0; jj < half; ++jj) {
-                const cplx a = v[b + jj], c = v[b + jj + half], cs = c.yx;
-                const float wr = w[jj].x, wi = w[jj].y;
-                v[b + jj] = fma2(mk(wr, wr), c, fma2(mk(-wi, wi), cs, a));
-                v[b + jj + half] = fma2(mk(-wr, -wr), c, fma2(mk(wi, -wi), cs, a));
+                // a + w c and a - w c: fma(wr, c, fma(-+wi, c.yx, a)) per half (fft64_lane.hpp: the twiddle pair as it is read)
+                const cplx a = v[b + jj], c = v[b + jj + half];
+                bfly_w(a, w[jj], c, v[b + jj], v[b + jj + half]);
             }
         t0 += half;
     }

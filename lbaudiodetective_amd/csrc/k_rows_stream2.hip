@@ -227,8 +227,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
 #pragma unroll
                         for (int b = 0; b < 32; b += 2 * half) {
                             const cplx u = y[b + jj], v = y[b + jj + half];
-                            y[b + jj] = madd(u, w.x, w.y, v);
-                            y[b + jj + half] = msub(u, w.x, w.y, v);
+                            bfly_w(u, w, v, y[b + jj], y[b + jj + half]);
                         }
                     }
                     e += half;
