@@ -84,5 +84,19 @@ static __device__ __forceinline__ void bfly_w(cplx u, cplx w, cplx v, cplx& plus
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(minus) : "v"(w), "v"(v), "v"(tm));
 }
 
+// the two results on their own (pruned stages need only one of them)
+static __device__ __forceinline__ cplx madd_w(cplx u, cplx w, cplx v) {
+    cplx t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(w), "v"(v), "v"(u));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(w), "v"(v), "v"(t));
+    return r;
+}
+static __device__ __forceinline__ cplx msub_w(cplx u, cplx w, cplx v) {
+    cplx t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(t) : "v"(w), "v"(v), "v"(u));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(v), "v"(t));
+    return r;
+}
+
 }  // namespace lane64
 }  // namespace lbad

@@ -181,8 +181,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
             const cplx u = x[j], v = x[8 + j];
 #endif
             const float2 w = wt[j];                                      // W_32^(8 h + j)
-            out[j] = madd(u, w.x, w.y, v);                               // D5[8 h + j]
-            out[8 + j] = msub(u, w.x, w.y, v);                           // D5[8 h + j + 16]
+            bfly_w(u, mk(w.x, w.y), v, out[j], out[8 + j]);              // D5[8 h + j], D5[8 h + j + 16]
         }
     };
 
@@ -226,8 +225,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) {
                 const float2 w = wt[8 + kk];                             // W_64^k
-                const cplx ep = madd(Pp[kk], w.x, w.y, Nn[kk]);
-                const cplx em = msub(Pp[kk], w.x, w.y, Nn[kk]);
+                cplx ep, em;
+                bfly_w(Pp[kk], mk(w.x, w.y), Nn[kk], ep, em);
                 *(lds_vf32x2*)((kk < 8 ? col_p0 : col_p1) + 2 * kk * kRowDw) = ep;
                 *(lds_vf32x2*)(kk == 0 ? col_m00 : (kk < 8 ? col_m0 + (14 - 2 * kk) * kRowDw : col_m1 + (30 - 2 * kk) * kRowDw)) = em;
             }
@@ -252,8 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
                 for (int b = 0; b < 32; b += 2) {
                     const cplx u = y[b], v = y[b + 1];
-                    y[b] = madd(u, w0.x, w0.y, v);
-                    y[b + 1] = msub(u, w0.x, w0.y, v);
+                    bfly_w(u, w0, v, y[b], y[b + 1]);
                 }
             }
 #pragma unroll
@@ -262,8 +260,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
                 for (int b = 0; b < 32; b += 4) {
                     const cplx u = y[b + jj], v = y[b + jj + 2];
-                    y[b + jj] = madd(u, w.x, w.y, v);
-                    y[b + jj + 2] = msub(u, w.x, w.y, v);
+                    bfly_w(u, w, v, y[b + jj], y[b + jj + 2]);
                 }
             }
 #pragma unroll
@@ -272,8 +269,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
                 for (int b = 0; b < 32; b += 8) {
                     const cplx u = y[b + jj], v = y[b + jj + 4];
-                    y[b + jj] = madd(u, w.x, w.y, v);
-                    y[b + jj + 4] = msub(u, w.x, w.y, v);
+                    bfly_w(u, w, v, y[b + jj], y[b + jj + 4]);
                 }
             }
             // cross stage 4, pruned: per 16-block the outputs p in {0..5} ("+") and {10..15} ("-")
@@ -283,8 +279,9 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
                 for (int b = 0; b < 32; b += 16) {
                     const cplx u = y[b + jj], v = y[b + jj + 8];
-                    if (jj < 6) y[b + jj] = madd(u, w.x, w.y, v);
-                    if (jj >= 2) y[b + jj + 8] = msub(u, w.x, w.y, v);
+                    if (jj >= 2 && jj < 6) bfly_w(u, w, v, y[b + jj], y[b + jj + 8]);
+                    else if (jj < 6) y[b + jj] = madd_w(u, w, v);
+                    else y[b + jj + 8] = msub_w(u, w, v);
                 }
             }
             // cross stage 5, pruned: outputs q in {0..5} ("+") and {26..31} ("-" of pairs 10..15).  The high
@@ -296,7 +293,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
                 for (int j = 0; j < kQ; ++j) {
                     const f32x2 wb = *reinterpret_cast<const f32x2*>(my_ctw + 2 * (21 + j));
-                    hi[j] = msub(y[10 + j], wb.x, wb.y, y[26 + j]);      // output 26 + j
+                    hi[j] = msub_w(y[10 + j], wb, y[26 + j]);            // output 26 + j
                 }
 #pragma unroll
                 for (int q = 0; q < kQ; ++q) {
@@ -313,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
                 const f32x2 wa = *reinterpret_cast<const f32x2*>(my_ctw + 2 * (15 + q));
-                const cplx a = madd(y[q], wa.x, wa.y, y[q + 16]);        // output q
+                const cplx a = madd_w(y[q], wa, y[q + 16]);              // output q
                 const cplx b = bsel[q];
                 const float2 wk = stw[q * 64 + lane];
                 cplx sm, df;                                             // a + conj(b) = (sr, si), a - conj(b) = (dr, di)
