@@ -350,6 +350,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // correctly rounded operations on the same operands as
     //   re = fma(wr, di, fma(wi, dr, sr)),  im = fma(-wr, dr, fma(wi, di, si)).
     const cplx inv2 = mk(inv_norm, inv_norm);
+    uint32_t worst = 0;
     auto power = [&](cplx a, cplx b, int p, auto partner_tag, bool dc) -> float {   // (bins outside the bands: computed, never read)
         constexpr bool PARTNER = decltype(partner_tag)::value;
         const cplx wk = *reinterpret_cast<const cplx*>(my_tw + p * L);
@@ -375,7 +376,11 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
         asm("v_min_f32 %0, %1, %2" : "=v"(zn.y) : "v"(zs.y), "v"(z.y));
         const cplx sq = zn * zn;
         const float t = __fadd_rn(sq.x, sq.y);
-        return (t == t && fabsf(t) != INFINITY) ? t : 0.0f;             // LBAudioDetective.m:398-401, at the source
+        // LBAudioDetective.m:398-401 skips NaN / inf terms: t >= +0.0 unless it is one of them, so as an unsigned integer every
+        // such t lies at or above the bits of +inf -- one v_max_u32 per term keeps watch, and the unit that has one puts its
+        // terms right in front of the stores below (was: a class test and a select per term)
+        worst = max(worst, __float_as_uint(t));
+        return t;
     };
     auto slot_work = [&](auto q_tag) {
         constexpr int Q = decltype(q_tag)::value;
@@ -428,6 +433,15 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // ---- D: power terms -> LDS (every read of the last pass has returned: the values are in
     //         registers), band means in bin order -----------------------------------------------------
     {
+        if (__builtin_expect(__any(worst >= 0x7F800000u), 0)) {
+#pragma unroll
+            for (int q = 0; q < R / 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 2 * L; ++i) {
+                    const float t = pw[q][i];
+                    pw[q][i] = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;
+                }
+        }
         // a power term goes where the table says: no bin arithmetic, predicates or divergent stores in the loop
         float* vwin = vbuf + wl * pitch;
         const uint16_t* my_at = term_at + r_now;

@@ -238,6 +238,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
             // ---- split pass: bin k = row + 32 q needs Z[N - k] = output 31 - q of the partner row (pair 0:
             //      output 31 - q of row 16 itself, output 32 - q of row 0 itself), for the q some band reads.
             //      Written on (re, im) pairs: packed instructions. -----------------------------------------------
+            uint32_t worst = 0;
 #pragma unroll
             for (int q = QLO; q < QHI; ++q) {
 #ifdef LBAD_EXP_NOSPLIT
@@ -261,9 +262,21 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream2_kernel(const void* _
                     const cplx zn = mk(fminf(zs.x, z.x), fminf(zs.y, z.y));
                     const cplx sq = zn * zn;
                     const float t = __fadd_rn(sq.x, sq.y);
-                    vbuf[my_term_at[32 * q]] = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;   // LBAudioDetective.m:398-401, at the source
+                    // LBAudioDetective.m:398-401 skips NaN / inf terms: t >= +0.0 unless it is one of them, so as an unsigned
+                    // integer every such t lies at or above the bits of +inf -- one v_max_u32 per term keeps watch and the
+                    // terms are put right below, in the rare window that has one (was: a class test and a select per term)
+                    vbuf[my_term_at[32 * q]] = t;
+                    worst = max(worst, __float_as_uint(t));
                 }
 #endif
+            }
+            if (__builtin_expect(__any(worst >= 0x7F800000u), 0)) {
+                wave_sync();                                              // (a wave's LDS operations execute in order)
+                for (int q = QLO; q < QHI; ++q) {
+                    float* at = vbuf + my_term_at[32 * q];
+                    const float t = *at;
+                    *at = (t == t && fabsf(t) != INFINITY) ? t : 0.0f;
+                }
             }
             wave_sync();
             // ---- band means in bin order (LBAudioDetective.m:379-405): lane = (band, window) -----------------
