@@ -495,7 +495,9 @@ OSStatus LBAudioDetectiveCorpusScoresDevice(LBAudioDetectiveCorpusRef inCorpus, 
  * entries and, for a ragged corpus, records in proportion. */
 OSStatus LBAudioDetectiveCorpusSave(LBAudioDetectiveCorpusRef inCorpus, const char* inPath);
 LBAudioDetectiveCorpusRef LBAudioDetectiveCorpusLoad(const char* inPath, UInt64 inCapacity);
-/* Kernel selection: 0 = automatic, 1 = generic kernel, 2 = specialised plane kernel. */
+/* Kernel selection: 0 = automatic, 1 = generic kernel, 2 = specialised plane kernel.  Ragged corpora only: 3 = always hand
+ * the entries of fewer than 16 sub-fingerprints that are not longer than the query to the systolic scan (a second launch;
+ * automatic: when their share of the work makes it pay), 4 = never. */
 OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef inCorpus, UInt32 inVariant);
 
 /* ---- synthetic inputs generated on the device (bench / tests) -------------------------- */

@@ -36,13 +36,33 @@ constexpr uint32_t kScanOutWords = 16;      // per slot: 8 running maxima, the t
 
 // tasks of either kind for queries of nq sub-fingerprints, from the histogram of entry lengths (Fp.m:123-136: an entry
 // longer than the query slides the query along itself, any other entry slides along the query)
-void ragged_tasks(const LBAudioDetectiveCorpus* c, uint64_t nq, uint64_t& tasks_a, uint64_t& tasks_b) {
+// (b_min: "B" entries shorter than this are left out -- they go through the systolic scan, ragged_split)
+void ragged_tasks(const LBAudioDetectiveCorpus* c, uint64_t nq, uint64_t b_min, uint64_t& tasks_a, uint64_t& tasks_b) {
     tasks_a = tasks_b = 0;
     for (const auto& kv : c->len_hist) {
         const uint64_t ne = kv.first;
         if (ne > nq) tasks_a += kv.second * ((ne - nq + 4) / 4);
-        else tasks_b += kv.second * ((nq - ne + 4) / 4);
+        else if (ne >= b_min) tasks_b += kv.second * ((nq - ne + 4) / 4);
     }
+}
+
+// Split the scan?  An entry of n <= 15 sub-fingerprints against a longer query of nq costs the task kernel a pass of nq steps
+// per four of its nq - n + 1 offsets, n of which meet the entry: measured 2 300 G (step, offset) slots per second whatever
+// n is.  The systolic scan spends nq steps on EVERY record of a chunk that holds such an entry (2 200 G record-steps per
+// second, and not less than reading the records once).  Worth a second launch when the short entries' slots are well above
+// the whole corpus' record-steps.  Kernel variant 3 forces the split (where one exists), 4 forbids it.
+uint32_t ragged_split(const LBAudioDetectiveCorpus* c, uint64_t nq) {
+    if (sliding_short((uint32_t)nq, c->ne_max) || nq < kSlideSplitBelow || c->variant == 4) return 0;
+    uint64_t slots = 0, entries = 0;
+    for (const auto& kv : c->len_hist) {
+        const uint64_t ne = kv.first;
+        if (ne >= kSlideSplitBelow || ne > nq) continue;
+        slots += kv.second * ((nq - ne + 4) / 4) * 4 * nq;
+        entries += kv.second;
+    }
+    if (entries == 0) return 0;
+    if (c->variant == 3) return kSlideSplitBelow;
+    return slots > 2 * c->n_pos * nq + 20000000ull ? kSlideSplitBelow : 0;     // (+ 10 us of slots: a second launch is not free)
 }
 
 // ONE launch: the n_q queries qs[0..n_q) (all of qs[0]->count sub-fingerprints), their keys to keys + pos[i]
@@ -56,7 +76,8 @@ OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerpr
         build_sliding_query(qs[i]->data.data(), nq, c->subfp_len, range, block);
         all.insert(all.end(), block.begin() + (block.size() - block_words), block.end());      // (without the header)
     }
-    const bool in_args = n_q == 1 && nq <= kSlideQueryArgSubs && !sliding_short(nq, c->ne_max);
+    const uint32_t b_min = ragged_split(c, nq);
+    const bool in_args = n_q == 1 && nq <= kSlideQueryArgSubs && !sliding_short(nq, c->ne_max) && b_min == 0;   // (the systolic scan reads d_query)
     const size_t slot_words = (all.size() + 63) & ~(size_t)63;
     if (c->query_slot_words < slot_words) {               // (re)size the ring: everything that used it must be done
         for (hipEvent_t e : c->query_ev)
@@ -87,21 +108,21 @@ OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerpr
     if (!in_args) LBAD_HIP(hipMemcpyAsync(dq, h, all.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     if (d_scores) LBAD_HIP(hipMemsetAsync(d_scores, 0, c->count * sizeof(float), stream));
     uint64_t tasks_a = 0, tasks_b = 0;
-    ragged_tasks(c, nq, tasks_a, tasks_b);
+    ragged_tasks(c, nq, b_min, tasks_a, tasks_b);
     if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return kLBAudioDetectiveArgumentInvalid;   // the plan counts in 32 bits
     const SlideShape sh = sliding_shape(tasks_a, tasks_b, n_q);
     // the plan of this query length: kept while the length and the entries stay (queries of one length are the rule)
-    if (!sliding_short(nq, c->ne_max) && (c->plan_nq != nq || c->plan_count != c->count || c->plan_grid != sh.grid)) {
+    if (!sliding_short(nq, c->ne_max) && (c->plan_nq != nq || c->plan_count != c->count || c->plan_grid != sh.grid || c->plan_bmin != b_min)) {
         // scans on other streams may still read the old plan: every scan leaves its slot's event behind, and a slot is
         // reused only after its event -- the eight events cover everything that can still be running
         for (hipEvent_t e : c->query_ev)
             if (e) LBAD_HIP(hipEventSynchronize(e));
         if (!c->plan_built) LBAD_HIP(hipEventCreateWithFlags(&c->plan_built, hipEventDisableTiming));
         c->plan_nq = 0;
-        LBAD_HIP(launch_sliding_plan(c->d_off, c->count, nq, sh, c->d_plan, stream));
+        LBAD_HIP(launch_sliding_plan(c->d_off, c->count, nq, b_min, sh, c->d_plan, stream));
         LBAD_HIP(hipEventRecord(c->plan_built, stream));
         c->plan_stream = stream;
-        c->plan_nq = nq; c->plan_count = c->count; c->plan_grid = sh.grid;
+        c->plan_nq = nq; c->plan_count = c->count; c->plan_grid = sh.grid; c->plan_bmin = b_min;
     } else if (c->plan_built && c->plan_stream != stream) {
         LBAD_HIP(hipStreamWaitEvent(stream, c->plan_built, 0));
     }
@@ -117,7 +138,7 @@ OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerpr
         const hipError_t launched = launch_compare_sliding(c->d_recs, c->n_pos, c->d_off, c->count, c->ne_max,
                                                            (uint32_t)(c->rec_capacity + kRecordSlack / 2), tasks_a, tasks_b, sh, c->d_plan,
                                                            c->subfp_len, scan, nq, range, index_base,
-                                                           reinterpret_cast<unsigned int*>(d_scores), stream, c->bound_pruning, c->prune_from);
+                                                           reinterpret_cast<unsigned int*>(d_scores), stream, c->bound_pruning, c->prune_from, b_min);
         if (launched != hipSuccess) c->scan_out_dirty = true;
         LBAD_HIP(launched);
     }
@@ -428,7 +449,7 @@ UInt32 LBAudioDetectiveCorpusGetEntryStrideBytes(LBAudioDetectiveCorpusRef c) {
 }
 
 OSStatus LBAudioDetectiveCorpusSetKernelVariant(LBAudioDetectiveCorpusRef c, UInt32 inVariant) {
-    if (!c || inVariant > 2) return kLBAudioDetectiveArgumentInvalid;
+    if (!c || inVariant > 4 || (inVariant > 2 && !c->ragged)) return kLBAudioDetectiveArgumentInvalid;
     c->variant = inVariant;
     return noErr;
 }

@@ -298,8 +298,8 @@ struct SlideScan {
 constexpr uint32_t kSlideQueryArgSubs = 47;   // longest query that travels as a kernel argument
 size_t sliding_plan_words(uint64_t capacity);
 // the plan of a query length (where every workgroup's run of entries starts) into d_plan
-hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, const SlideShape& sh, uint32_t* d_plan,
-                               hipStream_t stream);
+hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, uint32_t b_min, const SlideShape& sh,
+                               uint32_t* d_plan, hipStream_t stream);
 // tasks_a / tasks_b: groups of four sliding offsets over the entries longer / not longer than the query; d_query: the
 // block build_sliding_query made; zero_rec: index of an all-zero record
 bool sliding_short(uint32_t n_query, uint32_t ne_max);    // the systolic scan of short queries applies (no plan needed)
@@ -307,7 +307,11 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
                                   uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
                                   uint32_t subfp_len, const SlideScan& scan, uint32_t n_query, uint32_t range,
                                   uint64_t index_base, unsigned int* d_score_bits, hipStream_t stream, bool bound_pruning = true,
-                                  float prune_from = 0.7f);
+                                  float prune_from = 0.7f, uint32_t b_min = 0);
+// b_min > 0 (kSlideSplitBelow): the scan is SPLIT -- entries of fewer sub-fingerprints that are not longer than the query go
+// through the systolic scan (a second launch over the records), everything else through the task kernel; tasks_b and the
+// plan then count only the "B" entries of at least b_min sub-fingerprints
+constexpr uint32_t kSlideSplitBelow = 16;
 // limits of a ragged corpus (the key carries a 32-bit index, the scan's claim cursor and its record offsets want a little slack)
 constexpr uint64_t kMaxRaggedEntries = 0xFFFF0000ull;
 constexpr uint64_t kMaxRaggedRecords = 0xFFFFFF00ull;
@@ -459,7 +463,7 @@ struct LBAudioDetectiveCorpus {
     std::map<uint32_t, uint64_t> len_hist;       // entries per length: the scan's task totals for any query length
     // the scan's plan for ONE query length (k_sliding.hip): rebuilt when the length, the entries or the grid change
     uint32_t* d_plan = nullptr;
-    uint32_t plan_nq = 0, plan_grid = 0;
+    uint32_t plan_nq = 0, plan_grid = 0, plan_bmin = 0;
     bool bound_pruning = true;     // top-1 scans of a ragged corpus may drop passes that cannot reach the best match so far (exact)
     float prune_from = 0.7f;       // ... once a match of at least this score is known (LBAudioDetectiveCorpusSetBoundPruningThreshold)
     uint64_t plan_count = 0;

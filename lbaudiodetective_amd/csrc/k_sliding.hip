@@ -119,6 +119,7 @@ struct SlideArgs {                // the scalars of a scan (the pointers are ker
     uint32_t prune;               // 1: a top-1 scan (no per-entry scores wanted) may drop passes that cannot reach the best match so far
     float prune_from;             // ... once a match of at least this score has been published (CorpusSetBoundPruningThreshold)
     uint32_t q_in_args;           // 1: the query block travels in the kernel's argument segment (QueryArg), not through d_query
+    uint32_t b_min;               // "B" tasks only for entries of at least this many sub-fingerprints (the shorter ones: systolic scan)
 };
 
 // A query of up to kSlideQueryArgSubs sub-fingerprints fits the kernel's argument segment (4 KB): no copy to the device, one
@@ -705,7 +706,7 @@ __device__ __forceinline__ void scan_mode(const SlideArgs& a, const SlidePtrs& p
                 o = p.off[e];
                 ne = p.off[(uint64_t)e + 1] - o;
                 // Fp.m:123-131 swaps only when the query is SHORTER: an entry of the query's length is a "B" entry
-                if (MODE_B) tasks = ne <= nq ? (nq - ne + 4u) >> 2 : 0u;         // ceil((nq - ne + 1) / 4)
+                if (MODE_B) tasks = (ne <= nq && ne >= a.b_min) ? (nq - ne + 4u) >> 2 : 0u;   // ceil((nq - ne + 1) / 4)
                 else tasks = ne > nq ? (ne - nq + 4u) >> 2 : 0u;
             }
             cur = part_end;
@@ -963,15 +964,16 @@ __global__ __launch_bounds__(THREADS, 1) void compare_sliding_kernel(
 // ---- the plan of a query length: where every workgroup's run of entries starts ---------------------------------------
 // tasks of an entry of ne sub-fingerprints against a query of nq: groups of four of its |ne - nq| + 1 sliding offsets;
 // Fp.m:123-131 swaps only when the query is SHORTER, so an entry of the query's length slides along the query ("B")
-__device__ __forceinline__ void entry_tasks(uint32_t ne, uint32_t nq, uint32_t& ta, uint32_t& tb) {
+// (b_min: "B" entries shorter than this are not the task kernel's -- launch_compare_sliding hands them to the systolic scan)
+__device__ __forceinline__ void entry_tasks(uint32_t ne, uint32_t nq, uint32_t b_min, uint32_t& ta, uint32_t& tb) {
     ta = ne > nq ? (ne - nq + 4u) >> 2 : 0u;
-    tb = ne <= nq ? (nq - ne + 4u) >> 2 : 0u;
+    tb = (ne <= nq && ne >= b_min) ? (nq - ne + 4u) >> 2 : 0u;
 }
 constexpr uint32_t kPlanPerThread = 4, kPlanPerBlock = kSlThreads * kPlanPerThread;
 
 // sums of a block of 1024 entries -> block_sums[2 b], [2 b + 1]
 __global__ __launch_bounds__(kSlThreads) void slide_plan_sums_kernel(const uint32_t* __restrict__ off, uint64_t n_entries, uint32_t nq,
-                                                                    uint32_t* __restrict__ block_sums) {
+                                                                    uint32_t b_min, uint32_t* __restrict__ block_sums) {
     __shared__ uint32_t s_a[kSlThreads / 64], s_b[kSlThreads / 64];
     const uint64_t e0 = (uint64_t)blockIdx.x * kPlanPerBlock + (uint64_t)threadIdx.x * kPlanPerThread;
     uint32_t sa = 0, sb = 0;
@@ -980,7 +982,7 @@ __global__ __launch_bounds__(kSlThreads) void slide_plan_sums_kernel(const uint3
         const uint64_t e = e0 + k;
         if (e < n_entries) {
             uint32_t ta, tb;
-            entry_tasks(off[e + 1] - off[e], nq, ta, tb);
+            entry_tasks(off[e + 1] - off[e], nq, b_min, ta, tb);
             sa += ta; sb += tb;
         }
     }
@@ -1036,7 +1038,7 @@ __global__ __launch_bounds__(1024) void slide_plan_scan_kernel(uint32_t* __restr
 // starts[g] = the first entry whose tasks begin at or behind task g * chunk (tasks in front of it >= g * chunk): a
 // workgroup owns WHOLE entries, its share differs from chunk by less than one entry's tasks
 __global__ __launch_bounds__(kSlThreads) void slide_plan_final_kernel(const uint32_t* __restrict__ off, uint64_t n_entries, uint32_t nq,
-                                                                     const uint32_t* __restrict__ block_sums, uint32_t chunk_a,
+                                                                     uint32_t b_min, const uint32_t* __restrict__ block_sums, uint32_t chunk_a,
                                                                      uint32_t chunk_b, uint32_t* __restrict__ starts_a,
                                                                      uint32_t* __restrict__ starts_b) {
     __shared__ uint32_t s_a[kSlThreads / 64], s_b[kSlThreads / 64];
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(kSlThreads) void slide_plan_final_kernel(const uint
 #pragma unroll
     for (uint32_t k = 0; k < kPlanPerThread; ++k) {
         ta[k] = tb[k] = 0;
-        if (e0 + k < n_entries) entry_tasks(off[e0 + k + 1] - off[e0 + k], nq, ta[k], tb[k]);
+        if (e0 + k < n_entries) entry_tasks(off[e0 + k + 1] - off[e0 + k], nq, b_min, ta[k], tb[k]);
         sa += ta[k]; sb += tb[k];
     }
     uint32_t ia = sa, ib = sb;
@@ -1177,7 +1179,9 @@ template <int K, int QN>
 __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compare_short_kernel(     // (four waves per SIMD: 128 registers, as round 4's)
     const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
     uint64_t n_chunks, uint4 range_mask, const float* __restrict__ tri_tbl, uint64_t index_base,
-    unsigned int* __restrict__ score_bits, const ScanOut out) {
+    unsigned int* __restrict__ score_bits, const ScanOut out, uint32_t only_upto) {
+    // only_upto (0: every entry): the scan of a corpus that is split between the two kernels -- only entries of at most
+    // this many sub-fingerprints are scored here (the task kernel has the others), chunks without one are passed over
     __shared__ float s_tri[kTriSize];
     __shared__ unsigned long long s_k[kSlThreads / 64][QN];
     for (uint32_t i = threadIdx.x; i < kTriSize; i += kSlThreads) s_tri[i] = tri_tbl[i];
@@ -1216,14 +1220,16 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
             }
             tri[k] = possible * (possible + 1u) / 2u;
             isat[k] = r.isat; rem[k] = r.rem; idx[k] = r.idx;
-            const uint32_t ne = r.isat + r.rem + 1u;       // saturated; exact whenever it is <= nq
+            const uint32_t ne = r.isat + r.rem + 1u;       // saturated (both fields at 15); exact whenever it is <= 16
             case_a[k] = ne > nq;                           // the entry is the longer side (Fp.m:123-131)
             n2[k] = case_a[k] ? nq : ne;
             start_b[k] = !case_a[k] && r.isat == 0u;
+            if (only_upto && ne > only_upto) inb[k] = false;   // (not this scan's entry: its lanes never score)
             some_a |= case_a[k] && inb[k];
             some_b |= !case_a[k] && inb[k];
         }
         const bool any_a = __ballot(some_a) != 0ull, any_b = __ballot(some_b) != 0ull;
+        if (only_upto && !any_a && !any_b) continue;       // (uniform)
 
         float acc[QN][K];
         int smax[QN][K];
@@ -1585,18 +1591,18 @@ size_t sliding_plan_words(uint64_t capacity) {
 // Where every workgroup's run of entries starts, for queries of n_query sub-fingerprints: three small launches (block
 // sums of the entries' task counts, their scan, the boundaries), about 15 us for 1 M entries; the corpus keeps the plan
 // until the query length or the entries change.
-hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, const SlideShape& sh, uint32_t* d_plan,
-                               hipStream_t stream) {
+hipError_t launch_sliding_plan(const uint32_t* d_off, uint64_t n_entries, uint32_t n_query, uint32_t b_min, const SlideShape& sh,
+                               uint32_t* d_plan, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     uint32_t* starts_a = d_plan;
     uint32_t* starts_b = starts_a + (kSlideMaxGrid + 1);
     uint32_t* sums = starts_b + (kSlideMaxGrid + 1);
     const uint64_t nb = (n_entries + kPlanPerBlock - 1) / kPlanPerBlock;
     if (nb > 0x7fffffffull || n_entries > 0xFFFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(slide_plan_sums_kernel, dim3((uint32_t)nb), dim3(kSlThreads), 0, stream, d_off, n_entries, n_query, sums);
+    hipLaunchKernelGGL(slide_plan_sums_kernel, dim3((uint32_t)nb), dim3(kSlThreads), 0, stream, d_off, n_entries, n_query, b_min, sums);
     hipLaunchKernelGGL(slide_plan_scan_kernel, dim3(1), dim3(1024), 0, stream, sums, (uint32_t)nb, (uint32_t)n_entries, sh.grid,
                        sh.chunk_a, sh.chunk_b, starts_a, starts_b);
-    hipLaunchKernelGGL(slide_plan_final_kernel, dim3((uint32_t)nb), dim3(kSlThreads), 0, stream, d_off, n_entries, n_query, sums,
+    hipLaunchKernelGGL(slide_plan_final_kernel, dim3((uint32_t)nb), dim3(kSlThreads), 0, stream, d_off, n_entries, n_query, b_min, sums,
                        sh.chunk_a, sh.chunk_b, starts_a, starts_b);
     return hipGetLastError();
 }
@@ -1609,7 +1615,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
                                   uint32_t zero_rec, uint64_t tasks_a, uint64_t tasks_b, const SlideShape& sh, const uint32_t* d_plan,
                                   uint32_t subfp_len, const SlideScan& scan, uint32_t n_query, uint32_t range,
                                   uint64_t index_base, unsigned int* d_score_bits, hipStream_t stream, bool bound_pruning,
-                                  float prune_from) {
+                                  float prune_from, uint32_t b_min) {
     const uint32_t n_q = scan.n_q;
     if (n_entries == 0 || n_query == 0 || tasks_a + tasks_b == 0 || n_q == 0) return hipErrorInvalidValue;   // (the caller clears the keys itself)
     if (tasks_a > 0xFFFFFFFFull || tasks_b > 0xFFFFFFFFull) return hipErrorInvalidValue;    // the plan counts in 32 bits
@@ -1620,11 +1626,10 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     ScanOut out;
     out.acc = scan.d_acc; out.ticket = scan.d_ticket; out.keys = scan.d_keys;
     for (int i = 0; i < 8; ++i) out.pos[i] = scan.key_pos[i];
-    if (sliding_short(n_query, ne_max)) {
-        // the systolic scan: 64 K records per wave and chunk (K = 4 records per lane once a window reaches back more than six
-        // records: the overlap of consecutive chunks stays a small part of a chunk)
+    // the systolic scan: 64 K records per wave and chunk (K = 4 records per lane once a window reaches back more than six
+    // records: the overlap of consecutive chunks stays a small part of a chunk); only_upto: see compare_short_kernel
+    auto run_short = [&](uint32_t look, uint32_t only_upto) -> hipError_t {
         if (!scan.d_queries) return hipErrorInvalidValue;
-        const uint32_t look = (n_query < ne_max ? n_query : ne_max) - 1u;
         const uint32_t K = look <= 6u ? 1u : 4u;
         const uint32_t step = 64u * K - look;
         const uint64_t span = 64ull * K;
@@ -1635,7 +1640,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         const uint4 rm4 = sliding_range_mask(subfp_len, range);
 #define LBAD_SHORT(KK, QQ)                                                                                                    \
     hipLaunchKernelGGL((compare_short_kernel<KK, QQ>), dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
-                       n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, out)
+                       n_query, step, n_chunks, rm4, tri, index_base, d_score_bits, out, only_upto)
         if (K == 1) {
             if (n_q == 1) LBAD_SHORT(1, 1); else if (n_q == 2) LBAD_SHORT(1, 2); else if (n_q == 4) LBAD_SHORT(1, 4);
             else if (n_q == 8) LBAD_SHORT(1, 8); else return hipErrorInvalidValue;
@@ -1645,7 +1650,8 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         }
 #undef LBAD_SHORT
         return hipGetLastError();
-    }
+    };
+    if (sliding_short(n_query, ne_max)) return run_short((n_query < ne_max ? n_query : ne_max) - 1u, 0u);
     SlideArgs a;
     a.index_base = index_base; a.n_entries = n_entries; a.nq = n_query; a.zero_rec = zero_rec;
     const uint4 rm = sliding_range_mask(subfp_len, range);
@@ -1659,6 +1665,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
     a.dense_b = dense(tasks_b);
     a.prune = (bound_pruning && d_score_bits == nullptr && n_q == 1 && n_query <= kPruneMaxQuery) ? 1u : 0u;
     a.prune_from = prune_from;
+    a.b_min = b_min;
     bool full, qlds;
     uint32_t dyn_lds;
     sliding_variant(subfp_len, n_query, range, n_q, full, qlds, dyn_lds);
@@ -1694,7 +1701,13 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         return hipErrorInvalidValue;
     }
 #undef LBAD_SLIDE
-    return hipGetLastError();
+    const hipError_t launched = hipGetLastError();
+    if (launched != hipSuccess || b_min == 0) return launched;
+    // The corpus is split: "B" entries of fewer than b_min sub-fingerprints were no tasks above (an entry of n records
+    // costs the task kernel a pass of n_query steps per four offsets whatever n is: 15.5 ms against 2.1 for 4 M entries of
+    // 8..15 and a query of 100).  The systolic scan takes them -- every record once, n_query steps per record, nothing for
+    // chunks without such an entry -- and maxes into the keys the task kernel has just written (same stream).
+    return run_short(b_min - 2u, b_min - 1u);
 }
 
 #if defined(LBAD_SLIDE_PROF) || defined(LBAD_SLIDE_STAMPS)

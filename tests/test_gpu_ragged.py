@@ -102,6 +102,43 @@ def test_ragged_short_entries_against_any_query(lb, gpu, oracle, longest):
         assert (g[0], _bits(g[1])) == (bi, _bits(bs)), (longest, g, bi, bs)
 
 
+@pytest.mark.parametrize("variant", [0, 3, 4])
+def test_ragged_scan_split_between_the_two_kernels(lb, gpu, oracle, variant):
+    """A corpus that mixes many entries of at most 15 sub-fingerprints with longer ones, asked queries longer than the short
+    entries: the library may hand the short entries to the systolic scan and keep the rest on the task kernel (two launches
+    that max into the same keys and scores; variant 3 forces that, 4 forbids it, 0 decides by the entries' lengths) --
+    every entry's score and the top-1 equal the oracle's either way, also for batches and planted matches on both sides."""
+    rng = np.random.default_rng(5100 + variant)
+    lens = np.concatenate([rng.integers(1, 16, 700), rng.integers(16, 90, 150)])
+    rng.shuffle(lens)
+    lens[:4] = [15, 16, 1, 89]
+    entries = [_rand_fp(rng, int(n), 200, p_zero=0.03, p_both=0.01) for n in lens]
+    corpus, _ = _ragged_corpus(lb, gpu, entries, 200)
+    corpus.set_kernel_variant(variant)
+    short = [i for i, n in enumerate(lens) if n <= 15]
+    long_ = [i for i, n in enumerate(lens) if n > 40]
+    for nq in (16, 17, 30, 48, 100):
+        for src_i in (short[int(rng.integers(0, len(short)))], long_[int(rng.integers(0, len(long_)))]):
+            q = _rand_fp(rng, nq, 200, p_zero=0.03, p_both=0.01)
+            src = entries[src_i]
+            k = min(nq, src.shape[0])
+            at = int(rng.integers(0, nq - k + 1))
+            q[at:at + k] = src[:k]                                       # the entry (or its beginning) planted inside the query
+            q[::5, :10] ^= 1
+            for rg in (0, 64):
+                _check_query(lb, oracle, corpus, entries, q, rg)
+    for nq in (21, 60):
+        qs = [_rand_fp(rng, nq, 200) for _ in range(7)]
+        for i, q in enumerate(qs):
+            src = entries[short[i]] if i % 2 else entries[long_[i]]
+            k = min(nq, src.shape[0])
+            q[:k] = src[:k]
+        got = corpus.query_batch([lb.Fingerprint.from_bools(q) for q in qs])
+        for q, g in zip(qs, got):
+            bi, bs = oracle.corpus_best_ragged(q, entries, 200)
+            assert (g[0], _bits(g[1])) == (bi, _bits(bs)), (variant, nq, g, bi, bs)
+
+
 def test_ragged_long_query_against_long_entries(lb, gpu, oracle):
     """Both sides long (a window reaches back 64 records or more): the per-entry kernel; and entries beyond the
     saturation of the record's 12-bit position fields."""

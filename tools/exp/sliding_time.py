@@ -19,6 +19,7 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--json")
 ap.add_argument("--prune", type=int, default=0, help="1: leave the bound pruning of top-1 scans on (default here: off = every offset is evaluated)")
 ap.add_argument("--no-match", action="store_true", help="a query that matches nothing in the corpus")
+ap.add_argument("--variant", type=int, default=0, help="CorpusSetKernelVariant: 3 forces the split of short entries off to the systolic scan, 4 forbids it")
 a = ap.parse_args()
 SEED = 0x4C424145
 counts = O.synth_ragged_counts(SEED, 0, a.n, a.lo, a.hi)
@@ -28,6 +29,8 @@ c = lb.Corpus.ragged(200, a.n, total)
 c.append_ragged_packed_device(packed, counts)
 del packed
 c.set_bound_pruning(bool(a.prune))
+if a.variant:
+    c.set_kernel_variant(a.variant)
 key = torch.zeros(1, dtype=torch.int64, device="cuda")
 out = []
 for nq in a.nq:

@@ -71,6 +71,8 @@ for t in range(trials):
     look = min(nq, int(counts.max())) - 1
     modes["short (systolic kernel)" if (nq <= 7 or counts.max() <= 15) else "A only" if counts.min() > nq else "B only" if counts.max() <= nq else "A and B"] += 1
     corpus = lb.Corpus.ragged(L, n + 1, int(counts.sum()) + 200)
+    if t % 3 == 1:
+        corpus.set_kernel_variant(3)                                        # short entries split off to the systolic scan wherever a split exists
     flat = np.concatenate(entries, axis=0)
     packed = np.stack([lb.pack_subfingerprint(r) for r in flat]).view(np.uint8).reshape(-1, 32)
     cut = int(rng.integers(0, n + 1))                                       # appended in two pieces
