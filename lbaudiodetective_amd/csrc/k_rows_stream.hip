@@ -45,13 +45,18 @@ constexpr int kThreads = kWaves * 64;
 constexpr int kRowDw = 68;                    // 32 complex + 16 B: lanes 0..15 of a b128 read hit disjoint banks
 constexpr int kTDw = 64 * kRowDw;             // transpose of one window (one wave)
 constexpr int kCrossTw = 27;                  // cross-stage twiddles a lane uses: 1 + 2 + 4 + 8 + 12
+constexpr int kCtwDw = 66;                    // their pitch: the 32 lanes of a ds_read_b64 on 64 different banks (at 68 lanes l, l + 16 shared theirs)
 constexpr int kQ = 6;                         // low outputs per row: bins a + 64 q < 384
 constexpr int kMaxBin = 64 * kQ;
 constexpr int kMaxTerms = 48;                 // bins of the widest band (the band sums are unrolled this far)
-constexpr int kPowerDw = kMaxBin + 64 + kMaxTerms;   // power terms of a window, one dummy word per lane, read overrun of the last band
+// power terms of a window: band after band, every band starting on a bank of its own (BandTable::term_at -- see
+// k_rows_stream2.hip; by bin number until round 5: 34 % of the LDS-active cycles were bank conflicts), a dump word per lane
+// and the read overrun of the last band behind them
+constexpr int kPowerDw = kTDw / 2;
+static_assert(kMaxBin + 32 * 31 + 64 + kMaxTerms + 7 <= kPowerDw, "skewed power terms of a window fit half the transpose area");
 constexpr int kP1 = 24;                       // phase-1 twiddles per half: 8 of stage 5, 16 of stage 6
-constexpr int kLdsDw = kWaves * kTDw + 64 * kRowDw + kQ * 64 * 2 + 2 * kP1 * 2;
-constexpr int kLdsBytes = kLdsDw * 4;         // 160 256 B: one workgroup per CU
+constexpr int kLdsDw = kWaves * kTDw + 64 * kCtwDw + kQ * 64 * 2 + 2 * kP1 * 2;
+constexpr int kLdsBytes = kLdsDw * 4;         // 159 744 B: one workgroup per CU
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 static_assert(2 * kPowerDw <= kTDw, "the power terms of two windows reuse the transpose area");
 
@@ -73,8 +78,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     float* tbuf = smem + wave * kTDw;                       // this wave's transpose / power terms
-    float* ctw = smem + kWaves * kTDw;                      // [lane][27 complex], row pitch kRowDw
-    float2* stw = reinterpret_cast<float2*>(ctw + 64 * kRowDw);   // [q][lane]
+    float* ctw = smem + kWaves * kTDw;                      // [lane][27 complex], row pitch kCtwDw
+    float2* stw = reinterpret_cast<float2*>(ctw + 64 * kCtwDw);   // [q][lane]
     float2* p1tw = stw + kQ * 64;                           // [h][24]: stage 5 W_32^(8 h + j), stage 6 W_64^k(h, kk)
 
     // ---- once per workgroup: tables --------------------------------------------------------------------
@@ -88,8 +93,8 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
         else if (e < 15) { s = 4; jj = e - 7; }
         else { s = 5; jj = e - 15 < 6 ? e - 15 : e - 15 + 4; }     // jj = 0..5, 10..15
         const uint32_t ti = (uint32_t)(a + 64 * jj) << (6 - s);     // W_(64 * 2^s)^(a + 64 jj)
-        ctw[l * kRowDw + 2 * e] = tw[ti];
-        ctw[l * kRowDw + 2 * e + 1] = tw[kN + ti];
+        ctw[l * kCtwDw + 2 * e] = tw[ti];
+        ctw[l * kCtwDw + 2 * e + 1] = tw[kN + ti];
     }
     for (int i = threadIdx.x; i < kQ * 64; i += kThreads) {
         const int q = i / 64, l = i % 64;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     const float2* my_p1 = p1tw + kP1 * h;
     float* my_col = tbuf + n * 2;                            // column n of the transpose (row pitch kRowDw)
     const float* my_trow = tbuf + lane * kRowDw;             // the row this lane transforms (stored by destination lane)
-    const float* my_ctw = ctw + lane * kRowDw;
+    const float* my_ctw = ctw + lane * kCtwDw;
     // Lane (n, h) holds D5[k] for k = k(h, kk) = 8 h + kk (kk < 8), 8 + 8 h + kk (kk >= 8) and emits rows k and
     // k + 32.  A row is stored at the slot of the lane that transforms it (the inverse of row_of_lane: 0 -> 0,
     // 32 -> 1, k < 32 -> 2 k, else 2 (64 - k) + 1), which is affine in kk within each group of eight.
@@ -126,19 +131,26 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
     float* col_m0 = my_col + ((h ? 49 : 65) - 14) * kRowDw;  //  k + 32 -> lane (h ? 49 : 65) - 2 kk      (kk < 8), + (14 - 2 kk)
     float* col_m1 = my_col + ((h ? 33 : 49) - 30) * kRowDw;  //  k + 32 -> lane (h ? 33 : 49) - 2 kk      (kk >= 8), + (30 - 2 kk)
     float* col_m00 = my_col + (h ? 49 : 1) * kRowDw;         //  row 32 (h = 0, kk = 0) -> lane 1
-    // which of this lane's six low bins a band reads, and where their power terms go
-    uint32_t need = 0;
+    // where the power terms of this lane's six low bins go inside a window's area: the word the band that reads the bin keeps
+    // for it, or the lane's dump word (fixed for the life of the workgroup: six registers)
+    const uint32_t term_end = band_tbl[8 * nbands];
+    uint32_t at[kQ];
 #pragma unroll
     for (int q = 0; q < kQ; ++q) {
         const uint32_t k = (uint32_t)(my_row + 64 * q);
-        if (k >= kmin && k < kmax && k != 0) need |= 1u << q;
+        at[q] = term_end + (uint32_t)lane;
+        if (k != 0)
+            for (uint32_t b = 0; b < nbands; ++b) {
+                const uint32_t lo = band_tbl[b], hi = band_tbl[nbands + b];
+                if (k >= lo && k < hi) at[q] = band_tbl[7 * nbands + b] + (k - lo);
+            }
     }
     float* vbuf = tbuf;                                      // power terms: [2 windows][kPowerDw]
-    float* dummy = tbuf + kMaxBin + lane;
-    uint32_t b_lo = 0, b_full = 0, b_rem = 0;                 // band lane & 31 (both halves: two windows per pass)
+    uint32_t b_at = 0, b_full = 0, b_rem = 0;                 // band lane & 31 (both halves: two windows per pass)
     float b_div = 1.0f;
     if ((uint32_t)(lane & 31) < nbands) {
-        b_lo = band_tbl[lane & 31];
+        const uint32_t b_lo = band_tbl[lane & 31];
+        b_at = band_tbl[7 * nbands + (lane & 31)];
         const uint32_t b_hi = band_tbl[nbands + (lane & 31)];
         const uint32_t b_width = b_hi > b_lo ? b_hi - b_lo : 0;
         b_full = b_width >> 3;                                // whole batches of 8 terms
@@ -333,12 +345,11 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
             wave_sync();                                                  // every row of the last window has been read
 #pragma unroll
             for (int q = 0; q < kQ; ++q) {
-                float* d0 = (need >> q) & 1u ? vbuf + (my_row + 64 * q) : dummy;
-                d0[0] = pw0[q];
-                d0[kPowerDw] = pw1[q];
+                vbuf[at[q]] = pw0[q];
+                vbuf[kPowerDw + at[q]] = pw1[q];
             }
             wave_sync();
-            const float* vb = vbuf + h * kPowerDw + b_lo;
+            const float* vb = vbuf + h * kPowerDw + b_at;
             // A band of width w is w / 8 whole batches of 8 terms -- added under a lane mask, no per-term select --
             // and one partial batch of w % 8 terms read from the lane's own offset.
             float v[kMaxTerms], vt[7];
@@ -391,6 +402,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_stream_kernel(const void* __
 bool rows_stream_supported(const Plan& p) {
     if (p.window != (uint32_t)kW || p.stride != (uint32_t)kStride || p.bands == 0 || p.bands > 32) return false;
     if (p.table.kmax <= p.table.kmin || p.table.kmin < 1 || p.table.kmax > (uint32_t)kMaxBin) return false;
+    if (!p.table.ordered) return false;                        // (bands in bin order, no bin in two of them: the terms' layout)
     for (uint32_t b = 0; b < p.bands; ++b)
         if (p.table.hi[b] > p.table.lo[b] && p.table.hi[b] - p.table.lo[b] > (uint32_t)kMaxTerms) return false;
     std::vector<float> re, im;
