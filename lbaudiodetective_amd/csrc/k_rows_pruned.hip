@@ -230,12 +230,23 @@ __global__ __launch_bounds__(kThreads, kWgPerCu) void frame_rows_pruned_kernel(c
 
     const int w8 = lane >> 3, r = lane & 7;
     const float inv_norm = 1.0f / (float)(kW / 4);
-    // bin tasks: the 8 lanes of a window share its 22 bins, lane r taking bins r, r + 8, r + 16 (< 22).
-    // Eight consecutive lanes then read eight consecutive rows of one window: conflict-free b128 reads.
+    // bin tasks: the 8 lanes of a window share its 22 bins, lane r taking bins r', r' + 8, r' + 16 (< 22): eight lanes
+    // read eight consecutive rows of one window.  r' = r, or r ^ 4 in the windows 1, 2 (mod 4) of the wave (round 5):
+    // a ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... -- lanes 0-3 of window
+    // 0, 4-7 of windows 1 and 2, 0-3 of window 3 --, and with r' = r throughout two of the four windows of a group
+    // met on the same 16-byte slots (window pitch 116 slots = 4 mod 16, rows 5 slots apart): every tree read took twice
+    // its cycles, 18 % of the kernel's LDS-active cycles were conflicts.  With the halves of windows 1 and 2 swapped the
+    // sixteen lanes of every group read sixteen different slots (the pitch stays: the 16 contiguous lanes of a
+    // ds_write_b64 group want the windows 16 banks apart).
+#ifdef LBAD_EXP_TREE_NOSWAP
+    const int rr = r;
+#else
+    const int rr = r ^ ((((w8 + 1) >> 1) & 1) << 2);
+#endif
     int tk[3];
 #pragma unroll
-    for (int rd = 0; rd < 3; ++rd) tk[rd] = r + 8 * rd < kBins ? r + 8 * rd : kBins - 1;
-    const bool last_valid = r + 16 < kBins;
+    for (int rd = 0; rd < 3; ++rd) tk[rd] = rr + 8 * rd < kBins ? rr + 8 * rd : kBins - 1;
+    const bool last_valid = rr + 16 < kBins;
 
     // a lane serves the same three (window, bin) tasks in every quarter frame: their twiddles stay in registers
     __syncthreads();
