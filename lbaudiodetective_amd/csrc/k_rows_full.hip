@@ -292,9 +292,20 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     }
 
     const int wl = lane / L, r = lane % L;          // window of the wave, lane of the window
+    // The row of a pass this lane RECEIVES (and with it the bins, twiddles and term addresses of everything behind the
+    // transpose): its own number -- at eight lanes per window the halves of windows 1 and 2 (mod 4) trade rows, which puts the
+    // sixteen lanes of every ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...: half of one window, half of each of the next
+    // two, half of the fourth) on sixteen different 16-byte slots, as in k_rows_pruned.hip (same rows of 5 slots, same
+    // window pitch of 4 slots mod 8 that the ds_write_b64 groups need).  What a lane CONTRIBUTES (its points, its column of
+    // every row) stays with its own number.
+#ifdef LBAD_EXP_RECV_NOSWAP
+    const int r_recv = r;
+#else
+    const int r_recv = L == 8 ? r ^ ((((wl + 1) >> 1) & 1) << 2) : r;
+#endif
     const float inv_norm = 1.0f / (float)(S::W / 4);
-    float* tcol = tbuf + wl * S::kWinDw + 2 * r;                 // this lane's column of its window's pass
-    const float* trow = tbuf + wl * S::kWinDw + r * S::kRowDw;   // the row this lane receives
+    float* tcol = tbuf + wl * S::kWinDw + 2 * r;                      // this lane's column of its window's pass
+    const float* trow = tbuf + wl * S::kWinDw + r_recv * S::kRowDw;   // the row this lane receives
 
     for (;;) {
     // ---- A: this unit's span has landed (own loads: vmcnt, the other waves': barrier) -------------------
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 2) void rows_full_kernel(const void* __re
     // ---- C: log2 L cross-lane stages, R passes; pairs of passes end in the split pass ---------------
     // (bin numbers, twiddle addresses and store predicates are loop-invariant per lane; laundering r keeps
     // the compiler from hoisting a hundred of them out of the persistent loop and spilling them)
-    int r_now = r;
+    int r_now = r_recv;
     asm volatile("" : "+v"(r_now));
     float pw[R / 2][2 * L];
     auto run_pass = [&](auto pass_tag, cplx (&y)[L], int row) {
