@@ -1283,6 +1283,182 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
     }
 }
 
+// ---- round 6: SEVERAL short queries per launch ----------------------------------------------------------------------------
+// compare_short_kernel<1, 8> above spent 22 vector instructions per (record, query sub-fingerprint) pair at 4 cycles each:
+// every v_bitop3 took a query word as its SCALAR operand, one v_mov_dpp per pair moved the partial sum to the next lane, the
+// division branch of the epilogue was taken by every chunk (a lane's own best is beaten by one of its next four windows
+// with probability 1 / chunks seen, and one lane of 64 is enough), and the 40 table look-ups per record met on the LDS
+// banks (63 % of the LDS cycles).  This kernel keeps the systolic idea (the records rest, the partial sums of a diagonal
+// travel) and changes what surrounds it:
+//   * FOUR records per lane (a chunk = 256 records per wave): a diagonal crosses a lane boundary once per four pairs;
+//   * the query words of step a come from LDS as two broadcast ds_read_b128 per (query, step) into VECTOR registers and
+//     serve the lane's four records;
+//   * NO v_bitop3 READS THREE REGISTERS OF ONE BANK.  tools/ubench/operand_rates.hip (profiles/r06_operand_rates.txt): a
+//     wave64 v_bitop3 / v_fma_f32 issues in 2 cycles unless all three sources lie on one of the four register banks
+//     (register number mod 4), then in 4 -- and a compiler that puts every 16-byte load into a 4-aligned quad makes
+//     (P[w], N[w], qP[w]) exactly such a triple (25 of the 32 bit operations of a step in the first build).  The record
+//     words are used where the loads put them (register base even + w: the tuples of gfx950 are even-aligned) and the
+//     query quads are stored ROTATED by one word (word w in register base + (w + 1 & 3)): a query word's bank differs in
+//     parity from the bank of the record words it meets, whatever the allocator does;
+//   * the records are not unpacked: the query words are cut to the RANGE instead (a pair outside it -- and every field
+//     bit of w3 / w7 -- meets query Booleans 0 0 and can only "match" where the record's pair is 0 0 as well, which is no
+//     hit); the mask of a pair is folded into the first bit operation (0xA4: (P | N) & ~(P ^ qP));
+//   * one query after the other (their sums are independent): four running sums per lane, whatever the number of queries;
+//   * only entries LONGER than the query are scored here ("A" lanes: a diagonal starts in step 0 in every lane and is an
+//     offset of its entry iff it stayed inside it); the host sends the entries of at most n_query sub-fingerprints, where the
+//     corpus has any, through compare_short_kernel in its only_upto mode (same keys, atomic maxima);
+//   * RATIO = hits / possible without the table: with pf = (float)possible, rh = RN(1 / pf) and
+//     rl = RN(fma(-pf, rh, 1) * rh), fma(hf, rh, RN(hf * rl)) IS the correctly rounded quotient for every
+//     0 <= hits <= possible <= 100 (tools/verify_ratio_fma.c checks all 5151 pairs against the IEEE division with the very
+//     operations used here); possible == 0 gives rh = rl = 0 -> +0.0 like the table's row 0.  (rh, rl) of the 101 values
+//     of `possible` sit in LDS; hits are counted on top of the bits of 2^23, so hf is one subtraction;
+//   * the exact division of the epilogue runs where a sum can reach the WAVE's best so far (a wave-uniform threshold,
+//     refreshed where the branch is taken: about ln(chunks) times per wave and query instead of every time).
+#ifndef LBAD_SHORT_MULTI_WAVES
+#define LBAD_SHORT_MULTI_WAVES 5
+#endif
+constexpr uint32_t kShortMultiMaxQuery = 7;          // queries of up to seven sub-fingerprints (windows reach back six records)
+constexpr int kShortMultiK = 4;
+
+template <int QN>
+__global__ __launch_bounds__(kSlThreads, LBAD_SHORT_MULTI_WAVES) void compare_short_multi_kernel(
+    const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
+    uint64_t n_chunks, uint4 range_mask, uint64_t index_base, const ScanOut out) {
+    constexpr int K = kShortMultiK;
+    __shared__ uint4 s_q[QN * kShortMultiMaxQuery * 2];          // per (query, step): P words, N words, each rotated by one
+    __shared__ float2 s_rr[kTriPairs + 1];                       // (rh, rl) of possible = 0 .. 100
+    __shared__ unsigned long long s_k[kSlThreads / 64][QN];
+    const uint32_t q_stride = (nq + 1u) * kQWords;
+    const uint32_t rm[4] = {range_mask.x, range_mask.y, range_mask.z, range_mask.w};
+    for (uint32_t i = threadIdx.x; i < QN * nq * 2u; i += kSlThreads) {
+        const uint32_t qi = i / (2u * nq), rest = i - qi * 2u * nq;              // rest = 2 a + (0: P, 1: N)
+        const uint32_t* src = q + (size_t)qi * q_stride + (size_t)(rest >> 1) * kQWords + (rest & 1u) * 4u;
+        s_q[i] = make_uint4(src[3] & rm[3], src[0] & rm[0], src[1] & rm[1], src[2] & rm[2]);
+    }
+    if (threadIdx.x <= kTriPairs) {
+        const float pf = (float)threadIdx.x;
+        const float r1 = threadIdx.x ? __fdiv_rn(1.0f, pf) : 0.0f;
+        s_rr[threadIdx.x] = make_float2(r1, __fmul_rn(__fmaf_rn(-pf, r1, threadIdx.x ? 1.0f : 0.0f), r1));
+    }
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * (kSlThreads / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kSlThreads / 64);
+    const float nqf = (float)nq;
+    const uint32_t magic = 0x4B000000u;                    // the bits of 2^23: hits counted on top of them are 2^23 + hits as a float
+    unsigned long long best[QN];
+    float wthr[QN];                                        // wave-uniform: what a sum must reach to matter
+#pragma unroll
+    for (int qi = 0; qi < QN; ++qi) { best[qi] = 0ull; wthr[qi] = 0.0f; }
+
+    for (uint64_t c = wave; c < n_chunks; c += n_waves) {
+        const uint64_t p0 = c * chunk_step + (uint64_t)lane * K;
+        uint4 ra[K], rb[K];
+        uint32_t idx[K];
+        float rh[K], rl[K];
+        bool valid[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool inb = p0 + k < n_pos;
+            ra[k] = make_uint4(0, 0, 0, 0);
+            rb[k] = make_uint4(0, 0, 0, 0);
+            if (inb) {
+                ra[k] = recs[2 * (p0 + k)];
+                rb[k] = recs[2 * (p0 + k) + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const Rec r = unpack_rec(ra[k], rb[k]);
+            uint32_t possible = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) possible += __popc((r.P[w] | r.N[w]) & rm[w]);
+            const float2 rr = s_rr[possible];
+            rh[k] = rr.x;
+            rl[k] = rr.y;
+            idx[k] = r.idx;
+            const uint32_t ne = r.isat + r.rem + 1u;       // saturated (both fields at 15); exact whenever it is <= 16
+            // a record closes a window of an "A" entry iff the window lies inside its entry AND inside this chunk
+            valid[k] = p0 + k < n_pos && ne > nq && r.isat >= nq - 1u && lane * K + k >= nq - 1u;
+        }
+
+#pragma unroll
+        for (int qi = 0; qi < QN; ++qi) {
+            float acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] = 0.0f;
+            const uint4* __restrict__ sq = s_q + (size_t)qi * nq * 2u;
+            for (uint32_t a = 0; a < nq; ++a) {
+                const uint4 qp4 = sq[2 * a], qn4 = sq[2 * a + 1];
+                const uint32_t qP[4] = {qp4.y, qp4.z, qp4.w, qp4.x}, qN[4] = {qn4.y, qn4.z, qn4.w, qn4.x};    // (rotated by one)
+                float ratio[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const uint32_t P[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w}, N[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+                    uint32_t h = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const uint32_t u = __builtin_amdgcn_bitop3_b32(P[w], N[w], qP[w], 0xA4);   // (P | N) & ~(P ^ qP)
+                        const uint32_t v = __builtin_amdgcn_bitop3_b32(u, N[w], qN[w], 0x90);      // u & ~(N ^ qN)
+                        if (w == 0) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(v), "v"(magic));
+                        else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(v));
+                    }
+                    const float hf = __fsub_rn(__uint_as_float(h), 8388608.0f);
+                    const float t = __fmul_rn(hf, rl[k]);
+                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(ratio[k]) : "v"(hf), "v"(rh[k]), "v"(t));
+                }
+                const float in0 = __uint_as_float(from_left_lane(__float_as_uint(acc[K - 1])));
+#pragma unroll
+                for (int k = K - 1; k >= 0; --k) {
+                    // (as single adds in place: packed, the compiler renames the sums with three moves per step)
+                    const float from = k ? acc[k - 1] : in0;
+                    asm("v_add_f32 %0, %1, %2" : "=v"(acc[k]) : "v"(from), "v"(ratio[k]));
+                }
+            }
+            // The exact division (Fp.m:144) runs only where the sum can reach the wave's best so far.
+            float m = __int_as_float(kNegInf);
+#pragma unroll
+            for (int k = 0; k < K; ++k) m = fmaxf(m, valid[k] ? acc[k] : __int_as_float(kNegInf));
+            if (__ballot(m >= wthr[qi]) != 0ull) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (valid[k] && acc[k] >= wthr[qi]) {
+                        const float cand = __fdiv_rn(acc[k], nqf);
+                        const float match = (0.0f < cand) ? cand : 0.0f;     // MAX(match, cand) from match = 0
+                        const unsigned long long key = sl_key(match, index_base + idx[k]);
+                        best[qi] = key > best[qi] ? key : best[qi];
+                    }
+                }
+                uint32_t top = (uint32_t)(best[qi] >> 32);                   // scores are >= +0: their bits order like the values
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const uint32_t o = __shfl_xor(top, off, 64);
+                    top = o > top ? o : top;
+                }
+                wthr[qi] = __uint_as_float(__builtin_amdgcn_readfirstlane(top)) * 0.99999f * nqf;
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < QN; ++qi) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best[qi], off, 64);
+            best[qi] = o > best[qi] ? o : best[qi];
+        }
+        if (lane == 0) s_k[threadIdx.x >> 6][qi] = best[qi];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                       // the keys are max-ed in place (the host clears them in front of the launch)
+        for (int qi = 0; qi < QN; ++qi) {
+            unsigned long long m = s_k[0][qi];
+            for (int i = 1; i < kSlThreads / 64; ++i) m = s_k[i][qi] > m ? s_k[i][qi] : m;
+            if (m) atomicMax(&out.keys[out.pos[qi]], m);
+        }
+    }
+}
+
 // even-position bits of a 32-bit word, compacted into 16
 __device__ __forceinline__ uint32_t even_bits(uint32_t x) {
     x &= 0x55555555u;
@@ -1651,7 +1827,33 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
 #undef LBAD_SHORT
         return hipGetLastError();
     };
-    if (sliding_short(n_query, ne_max)) return run_short((n_query < ne_max ? n_query : ne_max) - 1u, 0u);
+    // several queries of up to seven sub-fingerprints: the entries longer than the query through compare_short_multi_kernel
+    // (four records per lane, query words in vector registers), the others -- where the corpus has any (tasks_b counts their
+    // offsets) -- through the systolic scan above in its only_upto mode, which maxes into the same keys
+    auto run_short_multi = [&]() -> hipError_t {
+        if (!scan.d_queries) return hipErrorInvalidValue;
+        const uint32_t look = n_query - 1u;
+        const uint32_t step = 64u * kShortMultiK - look;
+        const uint64_t span = 64ull * kShortMultiK;
+        const uint64_t n_chunks = n_pos <= span ? 1u : (n_pos - span + step - 1u) / step + 1u;
+        const uint64_t want = (n_chunks + (kSlThreads / 64) - 1) / (kSlThreads / 64);
+        const uint64_t cap = (uint64_t)device_cu_count() * LBAD_SHORT_MULTI_WAVES;
+        const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+        const uint4 rm4 = sliding_range_mask(subfp_len, range);
+#define LBAD_SHORT_MULTI(QQ)                                                                                                  \
+    hipLaunchKernelGGL((compare_short_multi_kernel<QQ>), dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
+                       n_query, step, n_chunks, rm4, index_base, out)
+        if (n_q == 2) LBAD_SHORT_MULTI(2); else if (n_q == 4) LBAD_SHORT_MULTI(4); else if (n_q == 8) LBAD_SHORT_MULTI(8);
+        else return hipErrorInvalidValue;
+#undef LBAD_SHORT_MULTI
+        const hipError_t launched = hipGetLastError();
+        if (launched != hipSuccess || tasks_b == 0) return launched;
+        return run_short(look, n_query);
+    };
+    if (sliding_short(n_query, ne_max)) {
+        if (n_q > 1 && n_query <= kShortMultiMaxQuery && tasks_a != 0 && !d_score_bits) return run_short_multi();
+        return run_short((n_query < ne_max ? n_query : ne_max) - 1u, 0u);
+    }
     SlideArgs a;
     a.index_base = index_base; a.n_entries = n_entries; a.nq = n_query; a.zero_rec = zero_rec;
     const uint4 rm = sliding_range_mask(subfp_len, range);
