@@ -1314,27 +1314,31 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
 //     of `possible` sit in LDS; hits are counted on top of the bits of 2^23, so hf is one subtraction;
 //   * the exact division of the epilogue runs where a sum can reach the WAVE's best so far (a wave-uniform threshold,
 //     refreshed where the branch is taken: about ln(chunks) times per wave and query instead of every time).
-#ifndef LBAD_SHORT_MULTI_WAVES
-#define LBAD_SHORT_MULTI_WAVES 5
-#endif
+//   * ONE workgroup of sixteen waves per CU owns a contiguous run of chunks and its waves CLAIM them from a cursor in LDS.
+//     With equal static shares the waves did not finish together: the SIMD serves its oldest wave first, the workgroups
+//     placed first ended at 0.51 ms, the last at 1.09 (tools/exp/short_multi_stamps.py), and a SIMD's last wave, alone,
+//     issues at a fraction of the rate four waves reach together -- the vector ALU idled 60 % of the scan.
 constexpr uint32_t kShortMultiMaxQuery = 7;          // queries of up to seven sub-fingerprints (windows reach back six records)
 constexpr int kShortMultiK = 4;
+constexpr int kSmThreads = 1024;
 
 template <int QN>
-__global__ __launch_bounds__(kSlThreads, LBAD_SHORT_MULTI_WAVES) void compare_short_multi_kernel(
+__global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
     const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
-    uint64_t n_chunks, uint4 range_mask, uint64_t index_base, const ScanOut out) {
+    uint64_t n_chunks, uint64_t chunks_per_group, uint4 range_mask, uint64_t index_base, const ScanOut out) {
     constexpr int K = kShortMultiK;
     __shared__ uint4 s_q[QN * kShortMultiMaxQuery * 2];          // per (query, step): P words, N words, each rotated by one
     __shared__ float2 s_rr[kTriPairs + 1];                       // (rh, rl) of possible = 0 .. 100
-    __shared__ unsigned long long s_k[kSlThreads / 64][QN];
+    __shared__ unsigned long long s_k[kSmThreads / 64][QN];
+    __shared__ unsigned int s_cursor;                            // chunks of this workgroup's run handed out so far
     const uint32_t q_stride = (nq + 1u) * kQWords;
     const uint32_t rm[4] = {range_mask.x, range_mask.y, range_mask.z, range_mask.w};
-    for (uint32_t i = threadIdx.x; i < QN * nq * 2u; i += kSlThreads) {
+    for (uint32_t i = threadIdx.x; i < QN * nq * 2u; i += kSmThreads) {
         const uint32_t qi = i / (2u * nq), rest = i - qi * 2u * nq;              // rest = 2 a + (0: P, 1: N)
         const uint32_t* src = q + (size_t)qi * q_stride + (size_t)(rest >> 1) * kQWords + (rest & 1u) * 4u;
         s_q[i] = make_uint4(src[3] & rm[3], src[0] & rm[0], src[1] & rm[1], src[2] & rm[2]);
     }
+    if (threadIdx.x == 0) s_cursor = 0u;
     if (threadIdx.x <= kTriPairs) {
         const float pf = (float)threadIdx.x;
         const float r1 = threadIdx.x ? __fdiv_rn(1.0f, pf) : 0.0f;
@@ -1343,31 +1347,69 @@ __global__ __launch_bounds__(kSlThreads, LBAD_SHORT_MULTI_WAVES) void compare_sh
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave = (uint64_t)blockIdx.x * (kSlThreads / 64) + (threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * (kSlThreads / 64);
+    const uint64_t run_first = (uint64_t)blockIdx.x * chunks_per_group;
+    const uint64_t run_left = run_first < n_chunks ? n_chunks - run_first : 0ull;
+    const uint32_t run_chunks = (uint32_t)(run_left < chunks_per_group ? run_left : chunks_per_group);
+    // the next chunk of the run (>= run_chunks: none left); one LDS atomic per wave and chunk
+    auto claim = [&]() -> uint32_t {
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(&s_cursor, 1u);
+        return __builtin_amdgcn_readfirstlane(got);
+    };
     const float nqf = (float)nq;
     const uint32_t magic = 0x4B000000u;                    // the bits of 2^23: hits counted on top of them are 2^23 + hits as a float
+    // wave-uniform: the wave's best key so far and what a sum must reach to matter (scalar registers: they change only in
+    // the rare division branch, where the lanes' candidates are reduced over the wave at once)
     unsigned long long best[QN];
-    float wthr[QN];                                        // wave-uniform: what a sum must reach to matter
+    float wthr[QN];
 #pragma unroll
     for (int qi = 0; qi < QN; ++qi) { best[qi] = 0ull; wthr[qi] = 0.0f; }
 
-    for (uint64_t c = wave; c < n_chunks; c += n_waves) {
+    // The records of the NEXT chunk are requested before this chunk's steps run (a second set of 32 registers): waves that
+    // run equal phases fall into step -- all of a CU's waves waited for their records at the same time, 0.36 of 0.88 ms with
+    // nothing issued (knock-out LBAD_EXP_SM_NOLOAD).
+    uint4 na[K], nb[K];
+    auto request = [&](uint64_t c) {
+        const uint64_t p0 = c * chunk_step + (uint64_t)lane * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            na[k] = make_uint4(0, 0, 0, 0);
+            nb[k] = make_uint4(0, 0, 0, 0);
+#ifdef LBAD_EXP_SM_NOLOAD
+            na[k] = make_uint4(lane, k, c, 7);
+            nb[k] = make_uint4(k, lane, 5, 0x50 + (lane << 8));
+#else
+            if (p0 + k < n_pos) {
+                na[k] = recs[2 * (p0 + k)];
+                nb[k] = recs[2 * (p0 + k) + 1];
+            }
+#endif
+        }
+    };
+#ifdef LBAD_SLIDE_STAMPS
+#define LBAD_SM_STAMP(slot) do { if (lane == 0) g_slide_times[(blockIdx.x * (kSmThreads / 64) + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    uint32_t chunks_done = 0;
+#else
+#define LBAD_SM_STAMP(slot)
+#endif
+    LBAD_SM_STAMP(0);
+    uint32_t cur = claim(), next = run_chunks;
+    if (cur < run_chunks) request(run_first + cur);
+    for (; cur < run_chunks; cur = next) {
+        const uint64_t c = run_first + cur;
+#ifdef LBAD_SLIDE_STAMPS
+        if (chunks_done == 1) LBAD_SM_STAMP(1);
+        if (chunks_done == 17) LBAD_SM_STAMP(2);
+        ++chunks_done;
+#endif
         const uint64_t p0 = c * chunk_step + (uint64_t)lane * K;
         uint4 ra[K], rb[K];
-        uint32_t idx[K];
         float rh[K], rl[K];
         bool valid[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const bool inb = p0 + k < n_pos;
-            ra[k] = make_uint4(0, 0, 0, 0);
-            rb[k] = make_uint4(0, 0, 0, 0);
-            if (inb) {
-                ra[k] = recs[2 * (p0 + k)];
-                rb[k] = recs[2 * (p0 + k) + 1];
-            }
-        }
+        for (int k = 0; k < K; ++k) { ra[k] = na[k]; rb[k] = nb[k]; }
+        next = claim();
+        if (next < run_chunks) request(run_first + next);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const Rec r = unpack_rec(ra[k], rb[k]);
@@ -1377,7 +1419,6 @@ __global__ __launch_bounds__(kSlThreads, LBAD_SHORT_MULTI_WAVES) void compare_sh
             const float2 rr = s_rr[possible];
             rh[k] = rr.x;
             rl[k] = rr.y;
-            idx[k] = r.idx;
             const uint32_t ne = r.isat + r.rem + 1u;       // saturated (both fields at 15); exact whenever it is <= 16
             // a record closes a window of an "A" entry iff the window lies inside its entry AND inside this chunk
             valid[k] = p0 + k < n_pos && ne > nq && r.isat >= nq - 1u && lane * K + k >= nq - 1u;
@@ -1389,7 +1430,11 @@ __global__ __launch_bounds__(kSlThreads, LBAD_SHORT_MULTI_WAVES) void compare_sh
 #pragma unroll
             for (int k = 0; k < K; ++k) acc[k] = 0.0f;
             const uint4* __restrict__ sq = s_q + (size_t)qi * nq * 2u;
+#ifdef LBAD_EXP_SM_STEPS
+            for (uint32_t a = 0; a < LBAD_EXP_SM_STEPS; ++a) {
+#else
             for (uint32_t a = 0; a < nq; ++a) {
+#endif
                 const uint4 qp4 = sq[2 * a], qn4 = sq[2 * a + 1];
                 const uint32_t qP[4] = {qp4.y, qp4.z, qp4.w, qp4.x}, qN[4] = {qn4.y, qn4.z, qn4.w, qn4.x};    // (rotated by one)
                 float ratio[K];
@@ -1420,40 +1465,46 @@ __global__ __launch_bounds__(kSlThreads, LBAD_SHORT_MULTI_WAVES) void compare_sh
             float m = __int_as_float(kNegInf);
 #pragma unroll
             for (int k = 0; k < K; ++k) m = fmaxf(m, valid[k] ? acc[k] : __int_as_float(kNegInf));
+#ifdef LBAD_EXP_SM_NOEPI
+            if (__ballot(m >= 1e30f) != 0ull) {
+#else
             if (__ballot(m >= wthr[qi]) != 0ull) {
+#endif
+                unsigned long long mine = 0ull;
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     if (valid[k] && acc[k] >= wthr[qi]) {
                         const float cand = __fdiv_rn(acc[k], nqf);
                         const float match = (0.0f < cand) ? cand : 0.0f;     // MAX(match, cand) from match = 0
-                        const unsigned long long key = sl_key(match, index_base + idx[k]);
-                        best[qi] = key > best[qi] ? key : best[qi];
+                        const uint32_t idx = (rb[k].w >> 4) | ((ra[k].w >> 17) & 0xFu) << 28;       // (unpack_rec's idx)
+                        const unsigned long long key = sl_key(match, index_base + idx);
+                        mine = key > mine ? key : mine;
                     }
                 }
-                uint32_t top = (uint32_t)(best[qi] >> 32);                   // scores are >= +0: their bits order like the values
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) {
-                    const uint32_t o = __shfl_xor(top, off, 64);
-                    top = o > top ? o : top;
+                    const unsigned long long o = __shfl_xor(mine, off, 64);
+                    mine = o > mine ? o : mine;
                 }
-                wthr[qi] = __uint_as_float(__builtin_amdgcn_readfirstlane(top)) * 0.99999f * nqf;
+                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(mine >> 32));
+                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)mine);
+                const unsigned long long wave_key = ((unsigned long long)hi << 32) | lo;
+                if (wave_key > best[qi]) best[qi] = wave_key;
+                // (scores are >= +0: their bits order like the values)
+                wthr[qi] = __uint_as_float((uint32_t)(best[qi] >> 32)) * 0.99999f * nqf;
             }
         }
     }
+    LBAD_SM_STAMP(3);
+    if (lane == 0) {
 #pragma unroll
-    for (int qi = 0; qi < QN; ++qi) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best[qi], off, 64);
-            best[qi] = o > best[qi] ? o : best[qi];
-        }
-        if (lane == 0) s_k[threadIdx.x >> 6][qi] = best[qi];
+        for (int qi = 0; qi < QN; ++qi) s_k[threadIdx.x >> 6][qi] = best[qi];
     }
     __syncthreads();
     if (threadIdx.x == 0) {                       // the keys are max-ed in place (the host clears them in front of the launch)
         for (int qi = 0; qi < QN; ++qi) {
             unsigned long long m = s_k[0][qi];
-            for (int i = 1; i < kSlThreads / 64; ++i) m = s_k[i][qi] > m ? s_k[i][qi] : m;
+            for (int i = 1; i < kSmThreads / 64; ++i) m = s_k[i][qi] > m ? s_k[i][qi] : m;
             if (m) atomicMax(&out.keys[out.pos[qi]], m);
         }
     }
@@ -1836,13 +1887,17 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         const uint32_t step = 64u * kShortMultiK - look;
         const uint64_t span = 64ull * kShortMultiK;
         const uint64_t n_chunks = n_pos <= span ? 1u : (n_pos - span + step - 1u) / step + 1u;
-        const uint64_t want = (n_chunks + (kSlThreads / 64) - 1) / (kSlThreads / 64);
-        const uint64_t cap = (uint64_t)device_cu_count() * LBAD_SHORT_MULTI_WAVES;
+        // one workgroup of sixteen waves per CU, each with a contiguous run of chunks its waves claim from an LDS cursor
+        const uint64_t waves = kSmThreads / 64;
+        const uint64_t want = (n_chunks + waves - 1) / waves;
+        const uint64_t cap = (uint64_t)device_cu_count();
         const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+        const uint64_t per_group = (n_chunks + grid - 1) / grid;
+        if (per_group >= 0xFFFFFFFFull) return hipErrorInvalidValue;
         const uint4 rm4 = sliding_range_mask(subfp_len, range);
 #define LBAD_SHORT_MULTI(QQ)                                                                                                  \
-    hipLaunchKernelGGL((compare_short_multi_kernel<QQ>), dim3(grid), dim3(kSlThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
-                       n_query, step, n_chunks, rm4, index_base, out)
+    hipLaunchKernelGGL((compare_short_multi_kernel<QQ>), dim3(grid), dim3(kSmThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
+                       n_query, step, n_chunks, per_group, rm4, index_base, out)
         if (n_q == 2) LBAD_SHORT_MULTI(2); else if (n_q == 4) LBAD_SHORT_MULTI(4); else if (n_q == 8) LBAD_SHORT_MULTI(8);
         else return hipErrorInvalidValue;
 #undef LBAD_SHORT_MULTI

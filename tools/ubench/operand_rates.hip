@@ -63,6 +63,18 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters) {
         else if (OP == 16)  // the scan's pair with every source triple on three banks: 8 bitop3 + 4 bcnt
             { REP8(asm volatile(B3(16, 0, 2, 1) B3(17, 16, 2, 3) BCNT(20, 17, 20) B3(18, 4, 6, 5) B3(19, 18, 6, 7) BCNT(20, 19, 20)
                               B3(16, 8, 10, 9) B3(17, 16, 10, 11) BCNT(21, 17, 21) B3(18, 0, 6, 9) B3(19, 18, 6, 3) BCNT(21, 19, 21) ::: CLOB);) }
+
+        else if (OP == 17)  // grouped: 8 bitop3 (conflict-free), then 4 bcnt
+            { REP8(asm volatile(B3(16, 0, 2, 1) B3(18, 4, 6, 5) B3(12, 8, 10, 9) B3(14, 0, 6, 9) B3(17, 16, 2, 3) B3(19, 18, 6, 7) B3(13, 12, 10, 11) B3(15, 14, 6, 3)
+                              BCNT(20, 17, 20) BCNT(21, 19, 21) BCNT(22, 13, 22) BCNT(23, 15, 23) ::: CLOB);) }
+        else if (OP == 18)  // grouped x 2: 16 bitop3, then 8 bcnt
+            { REP8(asm volatile(B3(16, 0, 2, 1) B3(18, 4, 6, 5) B3(12, 8, 10, 9) B3(14, 0, 6, 9) B3(17, 16, 2, 3) B3(19, 18, 6, 7) B3(13, 12, 10, 11) B3(15, 14, 6, 3)
+                              B3(16, 0, 2, 1) B3(18, 4, 6, 5) B3(12, 8, 10, 9) B3(14, 0, 6, 9) B3(16, 16, 2, 3) B3(18, 18, 6, 7) B3(12, 12, 10, 11) B3(14, 14, 6, 3)
+                              BCNT(20, 17, 20) BCNT(21, 19, 21) BCNT(22, 13, 22) BCNT(23, 15, 23) BCNT(20, 16, 20) BCNT(21, 18, 21) BCNT(22, 12, 22) BCNT(23, 14, 23) ::: CLOB);) }
+        else if (OP == 19)  // strictly alternating fast / slow: bitop3, bcnt, bitop3, bcnt ...
+            { REP8(asm volatile(B3(16, 0, 2, 1) BCNT(20, 17, 20) B3(18, 4, 6, 5) BCNT(21, 19, 21) B3(12, 8, 10, 9) BCNT(22, 13, 22) B3(14, 0, 6, 9) BCNT(23, 15, 23) ::: CLOB);) }
+        else if (OP == 20)  // fast only, but DEPENDENT pairs back to back (second reads the first's result)
+            { REP8(asm volatile(B3(16, 0, 2, 1) B3(17, 16, 2, 3) B3(18, 4, 6, 5) B3(19, 18, 6, 7) B3(12, 8, 10, 9) B3(13, 12, 10, 11) B3(14, 0, 6, 9) B3(15, 14, 6, 3) ::: CLOB);) }
     }
     unsigned s;
     asm volatile("v_add_u32 %0, v16, v17\nv_add_u32 %0, %0, v18\nv_add_u32 %0, %0, v19\nv_add_u32 %0, %0, v20\nv_add_u32 %0, %0, v21\n"
@@ -71,8 +83,8 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters) {
 }
 static const char* kNames[] = {"bitop3 3 distinct, banks 0 1 2", "bitop3 3 distinct, one bank", "bitop3 a b a", "bitop3 d a d (dest = source)",
                                "bitop3 3 distinct, varying", "v_fma_f32 3 distinct", "v_and_b32 2 distinct", "v_add_f32 2 distinct",
-                               "scan pair mix (6 bitop3 + 3 bcnt)", "bitop3 a a b", "bitop3 banks 0 0 1", "bitop3 banks 0 1 0", "bitop3 banks 1 0 0", "v_fma_f32 one bank", "v_and_b32 one bank", "v_bcnt two banks", "pair mix, conflict-free (8 bitop3 + 4 bcnt)"};
-static const int kPer[] = {8, 8, 8, 8, 8, 8, 8, 8, 9, 8, 8, 8, 8, 8, 8, 8, 12};
+                               "scan pair mix (6 bitop3 + 3 bcnt)", "bitop3 a a b", "bitop3 banks 0 0 1", "bitop3 banks 0 1 0", "bitop3 banks 1 0 0", "v_fma_f32 one bank", "v_and_b32 one bank", "v_bcnt two banks", "pair mix, conflict-free (8 bitop3 + 4 bcnt)", "grouped 8 bitop3 then 4 bcnt", "grouped 16 bitop3 then 8 bcnt", "alternating bitop3 / bcnt (4 + 4)", "8 bitop3, dependent pairs"};
+static const int kPer[] = {8, 8, 8, 8, 8, 8, 8, 8, 9, 8, 8, 8, 8, 8, 8, 8, 12, 12, 24, 8, 8};
 template <int OP>
 void run(unsigned* d_out) {
     const int iters = 1000;
@@ -93,7 +105,7 @@ void run(unsigned* d_out) {
         ns[w] = ms * 1e6 / ((double)iters * 8 * kPer[OP] * waves);
     }
     printf("%-36s %5.2f / %5.2f ns per instruction and SIMD at 4 / 8 waves per SIMD\n", kNames[OP], ns[0], ns[1]);
-    if constexpr (OP + 1 < 17) run<OP + 1>(d_out);
+    if constexpr (OP + 1 < 21) run<OP + 1>(d_out);
 }
 int main() {
     unsigned* d_out;
