@@ -1314,6 +1314,11 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
 //     of `possible` sit in LDS; hits are counted on top of the bits of 2^23, so hf is one subtraction;
 //   * the exact division of the epilogue runs where a sum can reach the WAVE's best so far (a wave-uniform threshold,
 //     refreshed where the branch is taken: about ln(chunks) times per wave and query instead of every time).
+//   * the LAST FOUR PAIRS (96..99: a word of their own in either plane, two bit operations and a count for 4 % of the pairs)
+//     come from LDS instead: per (query, step) a table of the 256 tails a record can have (its four P and four N Booleans)
+//     holds 2^23's bits + the tail's hits -- the value the three remaining counts start from; the query length is a
+//     template argument, so table and query words are read at immediate offsets (14.5 instead of 16.5 vector
+//     instructions per pair; the look-ups meet on the banks, but nothing else uses the LDS here);
 //   * ONE workgroup of sixteen waves per CU owns a contiguous run of chunks and its waves CLAIM them from a cursor in LDS.
 //     With equal static shares the waves did not finish together: the SIMD serves its oldest wave first, the workgroups
 //     placed first ended at 0.51 ms, the last at 1.09 (tools/exp/short_multi_stamps.py), and a SIMD's last wave, alone,
@@ -1322,12 +1327,14 @@ constexpr uint32_t kShortMultiMaxQuery = 7;          // queries of up to seven s
 constexpr int kShortMultiK = 4;
 constexpr int kSmThreads = 1024;
 
-template <int QN>
+template <int QN, int NQ>
 __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
-    const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t nq, uint32_t chunk_step,
+    const uint4* __restrict__ recs, uint64_t n_pos, const uint32_t* __restrict__ q, uint32_t chunk_step,
     uint64_t n_chunks, uint64_t chunks_per_group, uint4 range_mask, uint64_t index_base, const ScanOut out) {
     constexpr int K = kShortMultiK;
-    __shared__ uint4 s_q[QN * kShortMultiMaxQuery * 2];          // per (query, step): P words, N words, each rotated by one
+    constexpr uint32_t nq = NQ;
+    __shared__ uint4 s_q[QN * NQ * 2];                           // per (query, step): P words, N words, each rotated by one
+    __shared__ uint32_t s_tail[QN * NQ][256];                    // per (query, step) and record tail: bits of 2^23 + hits in pairs 96..99
     __shared__ float2 s_rr[kTriPairs + 1];                       // (rh, rl) of possible = 0 .. 100
     __shared__ unsigned long long s_k[kSmThreads / 64][QN];
     __shared__ unsigned int s_cursor;                            // chunks of this workgroup's run handed out so far
@@ -1337,6 +1344,12 @@ __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
         const uint32_t qi = i / (2u * nq), rest = i - qi * 2u * nq;              // rest = 2 a + (0: P, 1: N)
         const uint32_t* src = q + (size_t)qi * q_stride + (size_t)(rest >> 1) * kQWords + (rest & 1u) * 4u;
         s_q[i] = make_uint4(src[3] & rm[3], src[0] & rm[0], src[1] & rm[1], src[2] & rm[2]);
+    }
+    for (uint32_t i = threadIdx.x; i < QN * nq * 256u; i += kSmThreads) {
+        const uint32_t qa = i >> 8, t = i & 255u, qi = qa / nq, a = qa - qi * nq;
+        const uint32_t* src = q + (size_t)qi * q_stride + (size_t)a * kQWords;
+        const uint32_t qp = src[3] & rm[3], qn = src[7] & rm[3], p = t & 15u, n = t >> 4;
+        s_tail[qa][t] = 0x4B000000u + (uint32_t)__popc((p | n) & ~(p ^ qp) & ~(n ^ qn) & 15u);
     }
     if (threadIdx.x == 0) s_cursor = 0u;
     if (threadIdx.x <= kTriPairs) {
@@ -1357,7 +1370,6 @@ __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
         return __builtin_amdgcn_readfirstlane(got);
     };
     const float nqf = (float)nq;
-    const uint32_t magic = 0x4B000000u;                    // the bits of 2^23: hits counted on top of them are 2^23 + hits as a float
     // wave-uniform: the wave's best key so far and what a sum must reach to matter (scalar registers: they change only in
     // the rare division branch, where the lanes' candidates are reduced over the wave at once)
     unsigned long long best[QN];
@@ -1405,6 +1417,7 @@ __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
         const uint64_t p0 = c * chunk_step + (uint64_t)lane * K;
         uint4 ra[K], rb[K];
         float rh[K], rl[K];
+        const uint32_t* tail[K];                           // the record's row of s_tail[0]
         bool valid[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) { ra[k] = na[k]; rb[k] = nb[k]; }
@@ -1419,6 +1432,7 @@ __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
             const float2 rr = s_rr[possible];
             rh[k] = rr.x;
             rl[k] = rr.y;
+            tail[k] = &s_tail[0][r.P[3] | r.N[3] << 4];
             const uint32_t ne = r.isat + r.rem + 1u;       // saturated (both fields at 15); exact whenever it is <= 16
             // a record closes a window of an "A" entry iff the window lies inside its entry AND inside this chunk
             valid[k] = p0 + k < n_pos && ne > nq && r.isat >= nq - 1u && lane * K + k >= nq - 1u;
@@ -1429,27 +1443,33 @@ __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
             float acc[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) acc[k] = 0.0f;
-            const uint4* __restrict__ sq = s_q + (size_t)qi * nq * 2u;
 #ifdef LBAD_EXP_SM_STEPS
-            for (uint32_t a = 0; a < LBAD_EXP_SM_STEPS; ++a) {
+#pragma unroll
+            for (int a = 0; a < LBAD_EXP_SM_STEPS; ++a) {
 #else
-            for (uint32_t a = 0; a < nq; ++a) {
+#pragma unroll
+            for (int a = 0; a < NQ; ++a) {
 #endif
-                const uint4 qp4 = sq[2 * a], qn4 = sq[2 * a + 1];
-                const uint32_t qP[4] = {qp4.y, qp4.z, qp4.w, qp4.x}, qN[4] = {qn4.y, qn4.z, qn4.w, qn4.x};    // (rotated by one)
+                const u32x4 qp4 = reinterpret_cast<const u32x4*>(s_q)[(qi * NQ + a) * 2];
+                const u32x4 qn4 = reinterpret_cast<const u32x4*>(s_q)[(qi * NQ + a) * 2 + 1];
+                // (both stay whole 16-byte reads into register quads: as three single words the rotation's parity argument
+                // would no longer hold -- the compiler narrows a read whose .x nobody uses)
+                asm volatile("" :: "v"(qp4), "v"(qn4));
+                const uint32_t qP[3] = {qp4.y, qp4.z, qp4.w}, qN[3] = {qn4.y, qn4.z, qn4.w};    // (rotated by one; .x = pairs 96..99: in the table)
                 float ratio[K];
+                uint32_t h[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) h[k] = tail[k][(qi * NQ + a) * 256];
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const uint32_t P[4] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w}, N[4] = {rb[k].x, rb[k].y, rb[k].z, rb[k].w};
-                    uint32_t h = 0;
+                    const uint32_t P[3] = {ra[k].x, ra[k].y, ra[k].z}, N[3] = {rb[k].x, rb[k].y, rb[k].z};
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
+                    for (int w = 0; w < 3; ++w) {
                         const uint32_t u = __builtin_amdgcn_bitop3_b32(P[w], N[w], qP[w], 0xA4);   // (P | N) & ~(P ^ qP)
                         const uint32_t v = __builtin_amdgcn_bitop3_b32(u, N[w], qN[w], 0x90);      // u & ~(N ^ qN)
-                        if (w == 0) asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(h) : "v"(v), "v"(magic));
-                        else asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h) : "v"(v));
+                        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(h[k]) : "v"(v));
                     }
-                    const float hf = __fsub_rn(__uint_as_float(h), 8388608.0f);
+                    const float hf = __fsub_rn(__uint_as_float(h[k]), 8388608.0f);
                     const float t = __fmul_rn(hf, rl[k]);
                     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(ratio[k]) : "v"(hf), "v"(rh[k]), "v"(t));
                 }
@@ -1460,6 +1480,9 @@ __global__ __launch_bounds__(kSmThreads, 1) void compare_short_multi_kernel(
                     const float from = k ? acc[k - 1] : in0;
                     asm("v_add_f32 %0, %1, %2" : "=v"(acc[k]) : "v"(from), "v"(ratio[k]));
                 }
+                // (a step at a time: left alone, the scheduler pulls the LDS reads of every unrolled step to the front and
+                // spills 240 registers)
+                __builtin_amdgcn_sched_barrier(0);
             }
             // The exact division (Fp.m:144) runs only where the sum can reach the wave's best so far.
             float m = __int_as_float(kNegInf);
@@ -1895,11 +1918,23 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         const uint64_t per_group = (n_chunks + grid - 1) / grid;
         if (per_group >= 0xFFFFFFFFull) return hipErrorInvalidValue;
         const uint4 rm4 = sliding_range_mask(subfp_len, range);
-#define LBAD_SHORT_MULTI(QQ)                                                                                                  \
-    hipLaunchKernelGGL((compare_short_multi_kernel<QQ>), dim3(grid), dim3(kSmThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
-                       n_query, step, n_chunks, per_group, rm4, index_base, out)
-        if (n_q == 2) LBAD_SHORT_MULTI(2); else if (n_q == 4) LBAD_SHORT_MULTI(4); else if (n_q == 8) LBAD_SHORT_MULTI(8);
+#define LBAD_SHORT_MULTI(QQ, NN)                                                                                                  \
+    hipLaunchKernelGGL((compare_short_multi_kernel<QQ, NN>), dim3(grid), dim3(kSmThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
+                       step, n_chunks, per_group, rm4, index_base, out)
+#define LBAD_SHORT_MULTI_N(QQ)                                                                                                    \
+    switch (n_query) {                                                                                                            \
+        case 1: LBAD_SHORT_MULTI(QQ, 1); break;                                                                                   \
+        case 2: LBAD_SHORT_MULTI(QQ, 2); break;                                                                                   \
+        case 3: LBAD_SHORT_MULTI(QQ, 3); break;                                                                                   \
+        case 4: LBAD_SHORT_MULTI(QQ, 4); break;                                                                                   \
+        case 5: LBAD_SHORT_MULTI(QQ, 5); break;                                                                                   \
+        case 6: LBAD_SHORT_MULTI(QQ, 6); break;                                                                                   \
+        case 7: LBAD_SHORT_MULTI(QQ, 7); break;                                                                                   \
+        default: return hipErrorInvalidValue;                                                                                     \
+    }
+        if (n_q == 2) { LBAD_SHORT_MULTI_N(2) } else if (n_q == 4) { LBAD_SHORT_MULTI_N(4) } else if (n_q == 8) { LBAD_SHORT_MULTI_N(8) }
         else return hipErrorInvalidValue;
+#undef LBAD_SHORT_MULTI_N
 #undef LBAD_SHORT_MULTI
         const hipError_t launched = hipGetLastError();
         if (launched != hipSuccess || tasks_b == 0) return launched;
