@@ -91,6 +91,9 @@ constexpr uint32_t kSlots = 128;      // queue slots per wave (at most 63 left o
 // and an entry matters only if fl(S / nq) >= bs, i.e. S >= bs nq (1 - u).  T < bs nq kPruneMargin (1 + 2 u) therefore
 // drops nothing as long as kPruneMargin (1 + 2 u) (1 + (n + 2) u) <= 1 - u, which 0.999 satisfies for (n + 5) u <= 0.001:
 // queries of up to 16 000 sub-fingerprints (the launcher switches the pruning off beyond kPruneMaxQuery).
+#ifndef LBAD_SLIDE_QROT
+#define LBAD_SLIDE_QROT 1          // query quads rotated by one word in LDS: no three-sources-on-one-bank v_bitop3 (0: as round 5)
+#endif
 constexpr uint32_t kPassSpan = 1u << 26;      // records an "A" pass may span: 32-bit byte offsets inside it stay below 2^31
 constexpr float kPruneMargin = 0.999f;
 constexpr uint32_t kPruneMaxQuery = 8192;
@@ -470,8 +473,18 @@ __device__ __forceinline__ bool run_pass(const SlideArgs& a, const uint4* __rest
         if (QLDS) {
             const uint32_t* sq = s_q + (size_t)qi * q_stride + (size_t)i * kQWords;
             const uint4* ql = reinterpret_cast<const uint4*>(sq);
+#if LBAD_SLIDE_QROT
+            // The P and N quads lie in LDS rotated by one word (the kernel's copy loop): word w sits in register base +
+            // (w + 1 & 3) of an even-aligned quad, on a bank of the other parity than the record words P[w], N[w] it
+            // meets (register base' + w, base' even) -- no v_bitop3 of the step reads three registers of one bank and
+            // falls back to the 4-cycle issue (tools/ubench/operand_rates.hip).  The empty asm keeps each read whole.
+            const u32x4 q0 = reinterpret_cast<const u32x4*>(sq)[0], q1 = reinterpret_cast<const u32x4*>(sq)[1];
+            asm volatile("" :: "v"(q0), "v"(q1));
+            o.v[0] = q0.y; o.v[1] = q0.z; o.v[2] = q0.w; o.v[3] = q0.x; o.v[4] = q1.y; o.v[5] = q1.z; o.v[6] = q1.w; o.v[7] = q1.x;
+#else
             const uint4 q0 = ql[0], q1 = ql[1];
             o.v[0] = q0.x; o.v[1] = q0.y; o.v[2] = q0.z; o.v[3] = q0.w; o.v[4] = q1.x; o.v[5] = q1.y; o.v[6] = q1.z; o.v[7] = q1.w;
+#endif
             if (MODE_B) {
                 const uint4 q2 = ql[2];
                 o.nz[0] = q2.x; o.nz[1] = q2.y; o.nz[2] = q2.z; o.nz[3] = q2.w;
@@ -880,10 +893,12 @@ __global__ __launch_bounds__(THREADS, 1) void compare_sliding_kernel(
     for (uint32_t i = threadIdx.x; i < kTriSize; i += THREADS) s_tri[i] = tri_tbl[i];
     if (QLDS) {
         const uint32_t words = (uint32_t)QN * (a.nq + 1u) * kQWords;
+        // (the P and N quads of a sub-fingerprint rotated by one word: see fetch_q)
+        auto place = [](uint32_t i) -> uint32_t { return (LBAD_SLIDE_QROT && (i & 15u) < 8u) ? ((i & ~3u) | ((i + 1u) & 3u)) : i; };
         if (QN == 1 && a.q_in_args) {
-            for (uint32_t i = threadIdx.x; i < words; i += THREADS) s_qbuf[i] = qa.w[i];
+            for (uint32_t i = threadIdx.x; i < words; i += THREADS) s_qbuf[place(i)] = qa.w[i];
         } else {
-            for (uint32_t i = threadIdx.x; i < words; i += THREADS) s_qbuf[i] = q[i];
+            for (uint32_t i = threadIdx.x; i < words; i += THREADS) s_qbuf[place(i)] = q[i];
         }
     }
     if (threadIdx.x == 0) {
@@ -891,7 +906,9 @@ __global__ __launch_bounds__(THREADS, 1) void compare_sliding_kernel(
         s_cursor[1][0] = starts_b[blockIdx.x]; s_cursor[1][1] = starts_b[blockIdx.x + 1];
     }
     __syncthreads();
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // (the wave's number is wave-uniform: held in a scalar register it costs no vector register across the scan -- as a
+    // vector value it was the one spilled register of the single-query instance at the 128-register cap)
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     uint32_t* s_start = s_queue[wave];            // kSlots + 1 task starts
     uint32_t* s_off = s_start + kSlots + 4;
     uint32_t* s_ne = s_off + kSlots;
