@@ -179,6 +179,10 @@ private:
 #define LBAD_MIN_RUN_MB 16
 #endif
 constexpr uint64_t kMinRunBytes = (uint64_t)LBAD_MIN_RUN_MB << 20;
+#ifndef LBAD_RUN_RAMP
+#define LBAD_RUN_RAMP 1
+#endif
+constexpr uint64_t kFirstRunBytes = 4ull << 20;     // the shortest first run of a pipelined call
 constexpr size_t kAlign = 256;
 size_t align_up(size_t v) { return (v + kAlign - 1) & ~(kAlign - 1); }
 
@@ -513,9 +517,19 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     for (size_t i = 0; i < n; ++i)
         if (jobs[i].st == noErr) all_bytes += align_up(jobs[i].file_size);
     uint64_t kRunBytes = 512ull << 20;
+    // Round 6: the FIRST runs are short.  Nothing runs on the device until the first run has been read and uploaded -- with
+    // eight equal runs the device sat idle for the first 8 ms of a 57 ms call (profiles/r06_file_pipeline.txt: 3.6 ms of
+    // cold reads, then 161 MB over PCIe).  The first run is a sixty-fourth of the call (at least kFirstRunBytes), every
+    // run twice its predecessor until the eighth is reached: the device starts after about 2 ms and each run's kernels
+    // cover the reading of the next, larger one.
+    uint64_t ramp_bytes = 0;
     if (d->file_pipeline) {
         const uint64_t eighth = all_bytes / 8;
         kRunBytes = eighth < kMinRunBytes ? kMinRunBytes : (eighth < kRunBytes ? eighth : kRunBytes);
+        if (LBAD_RUN_RAMP && all_bytes / 64 >= kFirstRunBytes / 2) {
+            ramp_bytes = all_bytes / 64 < kFirstRunBytes ? kFirstRunBytes : all_bytes / 64;
+            if (ramp_bytes >= kRunBytes) ramp_bytes = 0;
+        }
     }
     Pending in_flight;                  // the previous run's last group
     int slot = 0;
@@ -532,7 +546,9 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
     for (size_t run_b = 0; any && run_b < n;) {
         size_t run_e = run_b;
         uint64_t total = 0;
-        while (run_e < n && (run_e == run_b || total + align_up(jobs[run_e].file_size) <= kRunBytes)) {
+        const uint64_t run_limit = ramp_bytes ? ramp_bytes : kRunBytes;
+        if (ramp_bytes) ramp_bytes = 2 * ramp_bytes >= kRunBytes ? 0 : 2 * ramp_bytes;
+        while (run_e < n && (run_e == run_b || total + align_up(jobs[run_e].file_size) <= run_limit)) {
             if (jobs[run_e].st == noErr) {
                 jobs[run_e].file_off = total;
                 total += align_up(jobs[run_e].file_size);
@@ -541,10 +557,13 @@ OSStatus process_audio_files(LBAudioDetective* d, const char* const* paths, size
         }
         void** h_files = slot ? &d->h_files_b : &d->h_files;
         size_t* h_files_cap = slot ? &d->h_files_b_cap : &d->h_files_cap;
-        st = total ? grow_pinned(h_files, h_files_cap, total) : noErr;
+        // (sized for the call's largest run at once: the short first runs must not make the later ones re-allocate)
+        const uint64_t largest = all_bytes < kRunBytes ? all_bytes : kRunBytes;
+        const uint64_t block = d->file_pipeline && total < largest ? largest : total;
+        st = total ? grow_pinned(h_files, h_files_cap, block) : noErr;
         void** d_bytes = slot ? &d->d_rs_bytes_b : &d->d_rs_bytes;
         size_t* d_bytes_cap = slot ? &d->d_rs_bytes_b_cap : &d->d_rs_bytes_cap;
-        if (st == noErr && total) st = grow_device(d_bytes, d_bytes_cap, total);
+        if (st == noErr && total) st = grow_device(d_bytes, d_bytes_cap, block);
         // the run's payloads go up on their own stream, beside the previous run's kernels: they wait for the decode kernel
         // that read this slot two runs ago, and this run's kernels wait for them
         if (st == noErr && !d->up_stream) st = hip_status(hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking), "stream", __LINE__);

@@ -16,7 +16,7 @@ n = len(batch)
 det = lb.Detective()
 L = det._L
 arr = (C.c_char_p * n)(*[p.encode() for p in batch])
-for pipe in (1, 0, 1, 0):
+for pipe in [int(v) for v in os.environ.get("PIPES", "1,0,1,0").split(",")]:
     L.LBAudioDetectiveSetFilePipeline(det._ref, pipe)
     best, tot = 1e9, 0.0
     for r in range(rounds + 1):
