@@ -1,6 +1,8 @@
 // api_detective.cpp -- LBAudioDetective* driver: configuration, PCM/file entry points and the
 // batch hot path.  Mirrors LBAudioDetective/LBAudioDetective.m; line cites refer to it.
 #include "internal.hpp"
+
+#include <new>
 #include "audiofile.hpp"
 
 #include <cmath>
@@ -429,7 +431,8 @@ using lbad::ensure_plan;
 extern "C" {
 
 LBAudioDetectiveRef LBAudioDetectiveNew(void) {  // :77-90
-    LBAudioDetective* d = new LBAudioDetective();
+    LBAudioDetective* d = new (std::nothrow) LBAudioDetective();      // (no C++ exception leaves the library: NULL like a failed malloc)
+    if (!d) return NULL;
     d->format = LBAudioDetectiveDefaultProcessingFormat();
     d->subfp_len = kLBAudioDetectiveDefaultSubfingerprintLength;
     d->window = kLBAudioDetectiveDefaultWindowSize;
@@ -914,9 +917,11 @@ struct LBAudioDetectiveStream {
 
 LBAudioDetectiveStreamRef LBAudioDetectiveStreamNew(LBAudioDetectiveRef inDetective) {
     if (!inDetective) return NULL;
-    LBAudioDetectiveStream* s = new LBAudioDetectiveStream();
+    LBAudioDetectiveStream* s = new (std::nothrow) LBAudioDetectiveStream();
+    if (!s) return NULL;
     s->detective = inDetective;
     s->fingerprint = LBAudioDetectiveFingerprintNew(0);
+    if (!s->fingerprint) { delete s; return NULL; }
     return s;
 }
 

@@ -3,6 +3,7 @@
 #include "internal.hpp"
 
 #include <mutex>
+#include <new>
 
 #include <cmath>
 #include <cstring>
@@ -31,9 +32,11 @@ void LBAudioDetectiveUnpackSubfingerprint(const UInt32* inWords, UInt32 inLength
         outBooleans[b] = b < LBAD_MAX_SUBFINGERPRINT_LENGTH ? (Boolean)((inWords[b >> 5] >> (b & 31)) & 1u) : 0;
 }
 
+// No C++ exception leaves the library: where upstream's malloc would have returned NULL, allocation failure here is a NULL
+// reference / an unchanged fingerprint (the signatures are upstream's and have no status to return).
 LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNew(UInt32 inSubfingerprintLength) {  // :18-26
-    LBAudioDetectiveFingerprint* fp = new LBAudioDetectiveFingerprint();
-    fp->length = inSubfingerprintLength;
+    LBAudioDetectiveFingerprint* fp = new (std::nothrow) LBAudioDetectiveFingerprint();
+    if (fp) fp->length = inSubfingerprintLength;
     return fp;
 }
 
@@ -42,7 +45,11 @@ void LBAudioDetectiveFingerprintDispose(LBAudioDetectiveFingerprintRef inFingerp
 }
 
 LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintCopy(LBAudioDetectiveFingerprintRef inFingerprint) {  // :41-59
-    return new LBAudioDetectiveFingerprint(*inFingerprint);
+    try {
+        return new LBAudioDetectiveFingerprint(*inFingerprint);
+    } catch (const std::exception&) {             // (bad_alloc from the copy of the Booleans)
+        return NULL;
+    }
 }
 
 UInt32 LBAudioDetectiveFingerprintGetSubfingerprintLength(LBAudioDetectiveFingerprintRef inFingerprint) {  // :64
@@ -76,7 +83,11 @@ Boolean LBAudioDetectiveFingerprintSetSubfingerprintLength(LBAudioDetectiveFinge
 
 void LBAudioDetectiveFingerprintAddSubfingerprint(LBAudioDetectiveFingerprintRef inFingerprint,
                                                   Boolean* inSubfingerprint) {  // :91-100 (deep copy of `length` bytes)
-    inFingerprint->data.insert(inFingerprint->data.end(), inSubfingerprint, inSubfingerprint + inFingerprint->length);
+    try {
+        inFingerprint->data.insert(inFingerprint->data.end(), inSubfingerprint, inSubfingerprint + inFingerprint->length);
+    } catch (const std::exception&) {             // out of memory: the fingerprint stays as it was (vector::insert at the end
+        return;                                   // of a vector of bytes gives the strong guarantee)
+    }
     inFingerprint->count++;
 }
 
@@ -108,7 +119,9 @@ UInt64 LBAudioDetectiveFingerprintGetString(LBAudioDetectiveFingerprintRef fp, c
 
 LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNewFromString(const char* inString) {
     if (!inString) return NULL;
-    LBAudioDetectiveFingerprint* fp = new LBAudioDetectiveFingerprint();
+    LBAudioDetectiveFingerprint* fp = new (std::nothrow) LBAudioDetectiveFingerprint();
+    if (!fp) return NULL;
+    try {
     std::vector<Boolean> row;
     auto flush = [&]() -> bool {
         if (fp->count == 0) fp->length = (uint32_t)row.size();
@@ -127,6 +140,10 @@ LBAudioDetectiveFingerprintRef LBAudioDetectiveFingerprintNewFromString(const ch
         } else { delete fp; return NULL; }
     }
     return fp;
+    } catch (const std::exception&) {
+        delete fp;
+        return NULL;
+    }
 }
 
 }  // extern "C"
@@ -220,12 +237,16 @@ Float32 LBAudioDetectiveFingerprintCompareToFingerprint(LBAudioDetectiveFingerpr
     // ((a < b) ? b : a) never selects: the result stays 0.
     if (a->count == 0 || b->count == 0) return 0.0f;
     if (a->length != b->length || a->length == 0 || a->length > LBAD_MAX_SUBFINGERPRINT_LENGTH) return NAN;
-    std::vector<uint32_t> pa, pb;
-    lbad::pack_fingerprint(a, pa);
-    lbad::pack_fingerprint(b, pb);
-    float r = NAN;
-    if (lbad::compare_slots_once(pa, a->count, pb, b->count, a->length, inRange, &r) != noErr) return NAN;
-    return r;
+    try {
+        std::vector<uint32_t> pa, pb;
+        lbad::pack_fingerprint(a, pa);
+        lbad::pack_fingerprint(b, pb);
+        float r = NAN;
+        if (lbad::compare_slots_once(pa, a->count, pb, b->count, a->length, inRange, &r) != noErr) return NAN;
+        return r;
+    } catch (const std::exception&) {             // out of host memory: like every other failure of a Float32 entry point
+        return NAN;
+    }
 }
 
 Float32 LBAudioDetectiveFingerprintCompareSubfingerprints(LBAudioDetectiveFingerprintRef inFingerprint,
@@ -234,12 +255,16 @@ Float32 LBAudioDetectiveFingerprintCompareSubfingerprints(LBAudioDetectiveFinger
     const uint32_t len = inFingerprint->length;
     if (len == 0) return 0.0f;
     if (len > LBAD_MAX_SUBFINGERPRINT_LENGTH) return NAN;
-    std::vector<uint32_t> pa(lbad::kPackedWords), pb(lbad::kPackedWords);
-    LBAudioDetectivePackSubfingerprint(inSubfingerprint1, len, pa.data());
-    LBAudioDetectivePackSubfingerprint(inSubfingerprint2, len, pb.data());
-    float r = NAN;
-    if (lbad::compare_slots_once(pa, 1, pb, 1, len, inRange, &r) != noErr) return NAN;
-    return r;
+    try {
+        std::vector<uint32_t> pa(lbad::kPackedWords), pb(lbad::kPackedWords);
+        LBAudioDetectivePackSubfingerprint(inSubfingerprint1, len, pa.data());
+        LBAudioDetectivePackSubfingerprint(inSubfingerprint2, len, pb.data());
+        float r = NAN;
+        if (lbad::compare_slots_once(pa, 1, pb, 1, len, inRange, &r) != noErr) return NAN;
+        return r;
+    } catch (const std::exception&) {
+        return NAN;
+    }
 }
 
 }  // extern "C"

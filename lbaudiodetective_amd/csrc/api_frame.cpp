@@ -10,23 +10,37 @@
 
 extern "C" {
 
+// No C++ exception leaves the library: allocation failure is a NULL reference, a row that was not set (SetRow returns FALSE),
+// or a frame that stays as it was (the signatures are upstream's and carry no status).
 LBAudioDetectiveFrameRef LBAudioDetectiveFrameNew(UInt32 inMaxRowCount) {  // :22-31
-    LBAudioDetectiveFrame* f = new LBAudioDetectiveFrame();
-    f->max_rows = inMaxRowCount;
-    f->rows.resize(inMaxRowCount);
-    return f;
+    LBAudioDetectiveFrame* f = nullptr;
+    try {
+        f = new LBAudioDetectiveFrame();
+        f->max_rows = inMaxRowCount;
+        f->rows.resize(inMaxRowCount);
+        return f;
+    } catch (const std::exception&) {
+        delete f;
+        return NULL;
+    }
 }
 
 void LBAudioDetectiveFrameDispose(LBAudioDetectiveFrameRef inFrame) { delete inFrame; }  // :33-44
 
 LBAudioDetectiveFrameRef LBAudioDetectiveFrameCopy(LBAudioDetectiveFrameRef inFrame) {  // :46-63
-    LBAudioDetectiveFrame* f = new LBAudioDetectiveFrame(*inFrame);
-    // upstream copies exactly rowLength floats of the first numberOfRows rows
-    for (uint32_t r = 0; r < f->max_rows; ++r) {
-        if (r < f->n_rows) f->rows[r].resize(f->row_length);
-        else f->rows[r].clear();
+    LBAudioDetectiveFrame* f = nullptr;
+    try {
+        f = new LBAudioDetectiveFrame(*inFrame);
+        // upstream copies exactly rowLength floats of the first numberOfRows rows
+        for (uint32_t r = 0; r < f->max_rows; ++r) {
+            if (r < f->n_rows) f->rows[r].resize(f->row_length);
+            else f->rows[r].clear();
+        }
+        return f;
+    } catch (const std::exception&) {
+        delete f;
+        return NULL;
     }
-    return f;
 }
 
 UInt32 LBAudioDetectiveFrameGetNumberOfRows(LBAudioDetectiveFrameRef inFrame) { return inFrame->n_rows; }  // :67
@@ -47,7 +61,11 @@ Boolean LBAudioDetectiveFrameSetRow(LBAudioDetectiveFrameRef inFrame, Float32* i
                                     UInt32 inCount) {  // :86-105
     if (LBAudioDetectiveFrameFull(inFrame)) return 0;
     if (inRowIndex >= inFrame->max_rows) return 0;   // upstream writes past its row table here
-    inFrame->rows[inRowIndex].assign(inRow, inRow + inCount);
+    try {
+        inFrame->rows[inRowIndex].assign(inRow, inRow + inCount);
+    } catch (const std::exception&) {
+        return 0;
+    }
     inFrame->row_length = inFrame->row_length == 0 ? inCount : std::min(inFrame->row_length, inCount);
     inFrame->n_rows++;
     return 1;
@@ -121,6 +139,7 @@ void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame) {  // :113
     LBAudioDetectiveFrame* f = inFrame;
     const uint32_t rows = f->n_rows, cols = f->row_length;
     if (rows == 0 || cols == 0) return;
+    try {
     std::vector<float> m;
     if (!dense(f, m)) return;
     if (!lbad::device_ready()) {
@@ -139,6 +158,8 @@ void LBAudioDetectiveFrameDecompose(LBAudioDetectiveFrameRef inFrame) {  // :113
     if (!ok) return;
     for (uint32_t r = 0; r < rows; ++r)
         std::memcpy(f->rows[r].data(), m.data() + (size_t)r * cols, cols * sizeof(float));
+    } catch (const std::exception&) {               // out of host memory: the frame stays as it was
+    }
 }
 
 void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, UInt32 inNumberOfWavelets,
@@ -146,6 +167,7 @@ void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, U
     LBAudioDetectiveFrame* f = inFrame;
     const uint32_t n = f->n_rows * f->row_length;
     if (n == 0 || inNumberOfWavelets == 0) return;
+    try {
     std::vector<float> m;
     if (!dense(f, m)) return;
     if (!lbad::device_ready()) {
@@ -168,6 +190,8 @@ void LBAudioDetectiveFrameExtractFingerprint(LBAudioDetectiveFrameRef inFrame, U
     // upstream only ever writes TRUE into the caller's (pre-zeroed) buffer
     for (size_t i = 0; i < flags.size(); ++i)
         if (flags[i]) outFingerprint[i] = 1;
+    } catch (const std::exception&) {               // out of host memory: nothing is written
+    }
 }
 
 }  // extern "C"

@@ -12,7 +12,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "liblbad_oracle.so")
+# LBAD_ORACLE_LIB: another build of the SAME two sources (the `asan` target of oracle/Makefile); never a different oracle
+_LIB_PATH = os.path.abspath(os.environ["LBAD_ORACLE_LIB"]) if os.environ.get("LBAD_ORACLE_LIB") else \
+    os.path.join(_HERE, "_build", "liblbad_oracle.so")
 
 ROWS_PER_FRAME = 128
 
@@ -35,7 +37,8 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(_HERE, n) for n in ("lbad_oracle.c", "lbad_file_oracle.c", "lbad_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"] + (["-B"] if force else []))
+        target = ["asan"] if os.path.basename(_LIB_PATH) == "liblbad_oracle_asan.so" else []
+        subprocess.check_call(["make", "-C", _HERE, "--no-print-directory"] + target + (["-B"] if force else []))
     return _LIB_PATH
 
 

@@ -361,3 +361,38 @@ def test_files_in_parallel_equal_files_one_by_one():
     for p, got in zip(paths[:3], many[:3]):
         assert np.array_equal(got, O.fingerprint_file(p, cfg, 1, O.TAIL_NOTHING, 0))
     assert all(m.shape[1] == cfg.subfp_len for m in many)
+
+
+def test_oracle_under_sanitizers():
+    """SURVEY section 5, "ASan/UBSan build of the CPU oracle": oracle/Makefile's `asan` target (both sources at -O1 with
+    AddressSanitizer + UBSan, no recovery) runs this file's known answers, the committed vectors, the tail modes of the
+    file loop and upstream's sixty fixtures through oracle/lbad_file_oracle.c (the essay-figure check) in a child
+    interpreter with the sanitizer runtime preloaded.  Any report aborts the child.  CPU build only: sanitizers never run
+    on the GPU box."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("LBAD_ORACLE_LIB"):
+        pytest.skip("already inside the sanitizer run")
+    if shutil.which("gcc") is None:
+        pytest.skip("no host compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    build = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "--no-print-directory", "asan"], capture_output=True, text=True)
+    if build.returncode != 0 and "sanitize" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    runtime = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(runtime) or not os.path.exists(runtime):
+        pytest.skip("libasan.so not found")
+    env = dict(os.environ)
+    env.update({"LBAD_ORACLE_LIB": os.path.join(root, "oracle", "_build", "liblbad_oracle_asan.so"), "LD_PRELOAD": runtime,
+                # the interpreter itself is not instrumented: its arenas are not leaks of ours
+                "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1:halt_on_error=1", "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1",
+                "OMP_NUM_THREADS": "4"})
+    picked = ("haar or band or fft_against or fft_packing or twiddle or extract or compare or popcount or ragged or framing "
+              "or committed or truncation or synth or batch_threads or tail_modes or essay_figures or in_parallel")
+    run = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", picked],
+                         capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    assert run.returncode == 0, (run.stdout[-3000:], run.stderr[-3000:])
+    assert "AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+    assert " passed" in run.stdout and "failed" not in run.stdout, run.stdout[-1000:]

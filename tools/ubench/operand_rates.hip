@@ -13,6 +13,9 @@
 #define FMA(d, a, b, c) "v_fma_f32 v" #d ", v" #a ", v" #b ", v" #c "\n"
 #define AND2(d, a, b) "v_and_b32 v" #d ", v" #a ", v" #b "\n"
 #define ADDF(d, a, b) "v_add_f32 v" #d ", v" #a ", v" #b "\n"
+#define PKF(d, a, b, c) "v_pk_fma_f32 v[" #d ":" #d "+1], v[" #a ":" #a "+1], v[" #b ":" #b "+1], v[" #c ":" #c "+1]\n"
+#define PKA(d, a, b) "v_pk_add_f32 v[" #d ":" #d "+1], v[" #a ":" #a "+1], v[" #b ":" #b "+1]\n"
+#define PKFS(d, a, c) "v_pk_fma_f32 v[" #d ":" #d "+1], v[" #a ":" #a "+1], s[4:5], v[" #c ":" #c "+1]\n"
 #define BCNT(d, a, b) "v_bcnt_u32_b32 v" #d ", v" #a ", v" #b "\n"
 
 static __device__ __forceinline__ void init_regs() {
@@ -75,6 +78,19 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters) {
             { REP8(asm volatile(B3(16, 0, 2, 1) BCNT(20, 17, 20) B3(18, 4, 6, 5) BCNT(21, 19, 21) B3(12, 8, 10, 9) BCNT(22, 13, 22) B3(14, 0, 6, 9) BCNT(23, 15, 23) ::: CLOB);) }
         else if (OP == 20)  // fast only, but DEPENDENT pairs back to back (second reads the first's result)
             { REP8(asm volatile(B3(16, 0, 2, 1) B3(17, 16, 2, 3) B3(18, 4, 6, 5) B3(19, 18, 6, 7) B3(12, 8, 10, 9) B3(13, 12, 10, 11) B3(14, 0, 6, 9) B3(15, 14, 6, 3) ::: CLOB);) }
+
+        else if (OP == 21)  // v_pk_fma_f32, the three source pairs on banks (0 1) (2 3) (0 1)
+            { REP8(asm volatile(PKF(16, 0, 2, 4) PKF(18, 0, 2, 4) PKF(20, 0, 2, 4) PKF(22, 0, 2, 4) PKF(16, 0, 2, 4) PKF(18, 0, 2, 4) PKF(20, 0, 2, 4) PKF(22, 0, 2, 4) ::: CLOB);) }
+        else if (OP == 22)  // v_pk_fma_f32, all three source pairs on banks (0 1)
+            { REP8(asm volatile(PKF(16, 0, 4, 8) PKF(18, 0, 4, 8) PKF(20, 0, 4, 8) PKF(22, 0, 4, 8) PKF(16, 0, 4, 8) PKF(18, 0, 4, 8) PKF(20, 0, 4, 8) PKF(22, 0, 4, 8) ::: CLOB);) }
+        else if (OP == 23)  // v_pk_fma_f32, two sources the same pair
+            { REP8(asm volatile(PKF(16, 0, 0, 2) PKF(18, 0, 0, 2) PKF(20, 0, 0, 2) PKF(22, 0, 0, 2) PKF(16, 0, 0, 2) PKF(18, 0, 0, 2) PKF(20, 0, 0, 2) PKF(22, 0, 0, 2) ::: CLOB);) }
+        else if (OP == 24)  // v_pk_add_f32, source pairs on banks (0 1) (2 3)
+            { REP8(asm volatile(PKA(16, 0, 2) PKA(18, 0, 2) PKA(20, 0, 2) PKA(22, 0, 2) PKA(16, 0, 2) PKA(18, 0, 2) PKA(20, 0, 2) PKA(22, 0, 2) ::: CLOB);) }
+        else if (OP == 25)  // v_pk_add_f32, both source pairs on banks (0 1)
+            { REP8(asm volatile(PKA(16, 0, 4) PKA(18, 0, 4) PKA(20, 0, 4) PKA(22, 0, 4) PKA(16, 0, 4) PKA(18, 0, 4) PKA(20, 0, 4) PKA(22, 0, 4) ::: CLOB);) }
+        else if (OP == 26)  // v_pk_fma_f32 with an SGPR pair as the middle source
+            { REP8(asm volatile(PKFS(16, 0, 4) PKFS(18, 0, 4) PKFS(20, 0, 4) PKFS(22, 0, 4) PKFS(16, 0, 4) PKFS(18, 0, 4) PKFS(20, 0, 4) PKFS(22, 0, 4) ::: CLOB);) }
     }
     unsigned s;
     asm volatile("v_add_u32 %0, v16, v17\nv_add_u32 %0, %0, v18\nv_add_u32 %0, %0, v19\nv_add_u32 %0, %0, v20\nv_add_u32 %0, %0, v21\n"
@@ -83,8 +99,8 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters) {
 }
 static const char* kNames[] = {"bitop3 3 distinct, banks 0 1 2", "bitop3 3 distinct, one bank", "bitop3 a b a", "bitop3 d a d (dest = source)",
                                "bitop3 3 distinct, varying", "v_fma_f32 3 distinct", "v_and_b32 2 distinct", "v_add_f32 2 distinct",
-                               "scan pair mix (6 bitop3 + 3 bcnt)", "bitop3 a a b", "bitop3 banks 0 0 1", "bitop3 banks 0 1 0", "bitop3 banks 1 0 0", "v_fma_f32 one bank", "v_and_b32 one bank", "v_bcnt two banks", "pair mix, conflict-free (8 bitop3 + 4 bcnt)", "grouped 8 bitop3 then 4 bcnt", "grouped 16 bitop3 then 8 bcnt", "alternating bitop3 / bcnt (4 + 4)", "8 bitop3, dependent pairs"};
-static const int kPer[] = {8, 8, 8, 8, 8, 8, 8, 8, 9, 8, 8, 8, 8, 8, 8, 8, 12, 12, 24, 8, 8};
+                               "scan pair mix (6 bitop3 + 3 bcnt)", "bitop3 a a b", "bitop3 banks 0 0 1", "bitop3 banks 0 1 0", "bitop3 banks 1 0 0", "v_fma_f32 one bank", "v_and_b32 one bank", "v_bcnt two banks", "pair mix, conflict-free (8 bitop3 + 4 bcnt)", "grouped 8 bitop3 then 4 bcnt", "grouped 16 bitop3 then 8 bcnt", "alternating bitop3 / bcnt (4 + 4)", "8 bitop3, dependent pairs", "v_pk_fma_f32 banks (01)(23)(01)", "v_pk_fma_f32 all pairs on (01)", "v_pk_fma_f32 a a b", "v_pk_add_f32 banks (01)(23)", "v_pk_add_f32 both on (01)", "v_pk_fma_f32 v s v"};
+static const int kPer[] = {8, 8, 8, 8, 8, 8, 8, 8, 9, 8, 8, 8, 8, 8, 8, 8, 12, 12, 24, 8, 8, 8, 8, 8, 8, 8, 8};
 template <int OP>
 void run(unsigned* d_out) {
     const int iters = 1000;
@@ -105,7 +121,7 @@ void run(unsigned* d_out) {
         ns[w] = ms * 1e6 / ((double)iters * 8 * kPer[OP] * waves);
     }
     printf("%-36s %5.2f / %5.2f ns per instruction and SIMD at 4 / 8 waves per SIMD\n", kNames[OP], ns[0], ns[1]);
-    if constexpr (OP + 1 < 21) run<OP + 1>(d_out);
+    if constexpr (OP + 1 < 27) run<OP + 1>(d_out);
 }
 int main() {
     unsigned* d_out;
