@@ -69,19 +69,14 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-# Float operations a stage-1 kernel EXECUTES per window, as a fraction of SURVEY 8(d)'s canonical count (2.5 W log2 W of a
-# real radix-2 FFT): static counts from the kernels' own headers.  The canonical figure is what the metric is priced in;
-# the executed one is what the vector ALU actually did -- both are reported, neither as the other.
-EXECUTED_OVER_CANONICAL = {
-    # k_rows_pruned.hip header: ~10.3 k operations per window instead of 25.6 k (only the outputs that feed bins 0..21)
-    (44100, 1024): (10.3e3 / 25.6e3, "k_rows_pruned.hip: 10.3 k of 25.6 k operations per window survive the output pruning"),
-    # k_rows_stream2.hip header: 4.1 k of 5.1 k butterflies (stages 1-4 shared by consecutive windows), split pass and
-    # band sums in full: (4.1 k x 10 + 1024 x 12 + 2.3 k) / 56.3 k
-    (5512, 2048): ((4.1e3 * 10 + 1024 * 12 + 2.3e3) / (2.5 * 2048 * 11), "k_rows_stream2.hip: 4.1 k of 5.1 k butterflies per window, split pass and bands in full"),
-    # k_rows_stream.hip: 32 new 32-point transforms (2560 butterflies), 1024 of stage 6, 64 cross transforms pruned to 12
-    # of 32 outputs (~50 of 80 butterflies), split pass over 384 bins: (6.8 k x 10 + 384 x 12 + 1 k) / 122.9 k
-    (48000, 4096): ((6.8e3 * 10 + 384 * 12 + 1.0e3) / (2.5 * 4096 * 12), "k_rows_stream.hip: ~6.8 k of 11.3 k butterflies per window (five shared stages, cross transform pruned to 12 of 32 outputs)"),
-}
+# Float operations a stage-1 kernel EXECUTES per window beside SURVEY 8(d)'s canonical count (2.5 W log2 W of a real radix-2
+# FFT, what the metric is priced in).  Until round 5 this was a constant typed from the kernels' header comments; the round-5
+# review asked for the counter.  Now: profiles/traffic.json carries, per stage-1 kernel, SQ_INSTS_VALU per launch (committed
+# rocprofv3 --pmc pass) x 64 lanes x the float operations per vector instruction of the COMPILED kernel (FMA = 2, packed = 2
+# lanes; tools/update_traffic.py) = the float operations the vector ALU ISSUED per window.  (The typed constants were 10.3 k,
+# 55.6 k and 73.6 k operations per window; the counters say 15.8 k, 44.6 k and 91.6 k -- off by 0.65 .. 1.5 x, because a
+# butterfly that is "10 operations" on paper is four packed FMAs = 16 issued ones, and shared stages were counted twice.)
+STAGE1_TRAFFIC_KEY = {(44100, 1024): "stage1_pruned", (5512, 2048): "stage1_stream_2048", (48000, 4096): "stage1_stream_4096"}
 
 
 def algorithmic_bytes_per_clip(n_samples: int, window: int, stride: int) -> int:
@@ -91,12 +86,26 @@ def algorithmic_bytes_per_clip(n_samples: int, window: int, stride: int) -> int:
 
 
 def executed_fields(rate: int, window: int, canonical_tflops: float, variant: int) -> dict:
-    """fp32_executed_tflops / fp32_frac_executed beside the canonical figures (the specialised kernels only)."""
-    f = EXECUTED_OVER_CANONICAL.get((rate, window)) if variant != 1 else None
-    if f is None:
-        return {"fp32_executed_tflops": None, "fp32_frac_executed": None}
-    return {"fp32_executed_tflops": round(canonical_tflops * f[0], 3), "fp32_frac_executed": round(canonical_tflops * f[0] / FP32_PEAK_TFLOPS, 4),
-            "executed_over_canonical": round(f[0], 3), "executed_count_source": f[1]}
+    """fp32_executed_tflops / fp32_frac_executed beside the canonical figures (the specialised kernels only): the float
+    operations the vector ALU issued (FMA = 2), from the committed SQ_INSTS_VALU pass and the compiled kernel's instruction mix."""
+    none = {"fp32_executed_tflops": None, "fp32_frac_executed": None}
+    key = STAGE1_TRAFFIC_KEY.get((rate, window)) if variant != 1 else None
+    if key is None:
+        return none
+    try:
+        raw = open(os.path.join(ROOT, "profiles", "traffic.json"), "rb").read()
+        e = json.loads(raw)[key]
+        issued = float(e["issued_float_ops_per_window"])
+    except (OSError, ValueError, KeyError, TypeError):
+        return none
+    f = issued / (2.5 * window * (window.bit_length() - 1))
+    return {"fp32_executed_tflops": round(canonical_tflops * f, 3), "fp32_frac_executed": round(canonical_tflops * f / FP32_PEAK_TFLOPS, 4),
+            "executed_over_canonical": round(f, 3),
+            "executed_count_source": {"file": "profiles/traffic.json", "sha256": hashlib.sha256(raw).hexdigest()[:16], "entry": key, "round": e.get("round"),
+                                      "issued_float_ops_per_window": issued, "valu_instructions_per_launch": e.get("valu_instructions_per_launch"),
+                                      "float_ops_per_vector_instruction": e.get("float_ops_per_vector_instruction"),
+                                      "how": "SQ_INSTS_VALU (committed rocprofv3 --pmc pass) x 64 lanes x float operations per vector "
+                                             "instruction of the compiled kernel (FMA = 2) / windows per launch"}}
 
 
 def per_call_stage_times(stage1_ms_sum: float, stage2_ms_sum: float, launches: int, calls: int):
@@ -339,15 +348,17 @@ def launch_ranks(args) -> int:
     return 0
 
 
-def profile_traffic(variant: int, clips_per_launch: float):
+def profile_traffic(variant: int, clips_per_launch: float, key: str = None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate
     passes, corrected as MI355X_MICROARCH.md prescribes).  They cannot be collected from inside this
-    process, so the value is only reported together with the file it comes from and that file's hash."""
+    process, so the value is only reported together with the file it comes from and that file's hash.
+    key: the entry of profiles/traffic.json (default: the headline's stage-1 kernel)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         raw = open(tpath, "rb").read()
         tj = json.loads(raw)
-        key = "stage1_pruned" if variant != 1 else "stage1_generic"
+        if key is None:
+            key = "stage1_pruned" if variant != 1 else "stage1_generic"
         if key not in tj:
             return None, None
         return (round(tj[key]["hbm_bytes_per_clip"] * clips_per_launch),
@@ -631,14 +642,17 @@ def run_rank(args) -> int:
         return 2
     dry = args.backend == "gloo"
     dist_on = world > 1 or args.force_dist          # every branch below that talks to torch.distributed
-    if dist_on and "MASTER_PORT" not in os.environ:
+    # a free port only where ONE process makes the whole group (--force-dist at one rank): ranks started by hand without
+    # MASTER_PORT must agree on a port, and each picking its own free one never meets the others (round-5 advice) -- they
+    # keep the fixed default below
+    if dist_on and world == 1 and "MASTER_PORT" not in os.environ:
         os.environ["MASTER_PORT"] = str(free_port())
     if dry and args.clips != 0:
         sys.stderr.write("bench.py: --backend gloo is the CPU dry run and needs --clips 0\n")
         return 2
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     if dry:
-        os.environ.setdefault("MASTER_PORT", "29533")
         dev = torch.device("cpu")
         if dist_on:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -654,10 +668,28 @@ def run_rank(args) -> int:
     rccl_ranks = dist.get_world_size() if (dist_on and dist.is_initialized()) else 1
     me = {"rank": rank, "local_rank": local_rank, "device": (str(dev)),
           "name": (torch.cuda.get_device_name(dev) if not dry else "cpu"), "pid": os.getpid()}
+    if not dry:
+        # what a first multi-GPU run needs to see per rank (round 6): which device the rank really sits on, and how the chip
+        # is partitioned -- 256 CUs = the eight XCDs as one device (SPX), 32 = one XCD per device (CPX): the kernels' XCD-aware
+        # claim order (blockIdx & 7) and one-workgroup-per-CU grids assume the first and only lose speed on the second
+        prop = torch.cuda.get_device_properties(dev)
+        cus = int(prop.multi_processor_count)
+        me.update({"device_index": int(torch.cuda.current_device()), "compute_units": cus, "xcds": max(1, cus // 32),
+                   "partition": "SPX (one device = the whole chip)" if cus >= 256 else f"{cus} CUs: a partition of the chip",
+                   "arch": getattr(prop, "gcnArchName", "?"), "hbm_GB": round(prop.total_memory / 1e9, 1)})
     devices = [me]
-    if dist_on:
-        devices = [None] * world
-        dist.all_gather_object(devices, me)
+
+    def regather_devices():
+        """the ranks' descriptions again (after the library's communicator was made: comm_count / comm_rank)"""
+        nonlocal devices
+        if dist_on:
+            devices = [None] * world
+            dist.all_gather_object(devices, me)
+        else:
+            devices = [me]
+        return devices
+
+    regather_devices()
 
     from lbaudiodetective_amd import sharded
     sharded.FORCE_COLLECTIVES = bool(args.force_dist)
@@ -858,6 +890,7 @@ def run_rank(args) -> int:
                 ach = ab * clips_per_launch_o / (k1 * 1e-3) / 1e9
                 want = O.fingerprint_batch(c2[:4].cpu().numpy(), O.Config(rate, window), nthreads=4)
                 got = lb.unpack_packed(p2[:4].cpu().numpy(), 200).reshape(4, per2, 200)
+                traffic_o, traffic_src_o = profile_traffic(0, clips_per_launch_o, "stage1_stream_2048" if window == 2048 else "stage1_stream_4096")
                 others[key] = {
                     "workload": f"{n_o} clips x {seconds} s @ {rate} Hz{' stereo-summed' if stereo else ''}, {window}-pt FFT, stride 64",
                     "calls_timed": calls_o, "launches_per_call": lpc,
@@ -867,7 +900,8 @@ def run_rank(args) -> int:
                     "roofline": {
                         "bound": "valu", "kernel": "stage 1 (rows_stream2_kernel at 2048-sample windows, rows_stream_kernel at 4096)",
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": None, "algorithmic_bytes_per_clip": ab, "clips_per_launch": clips_per_launch_o,
+                        "traffic": traffic_o, "traffic_source": traffic_src_o,
+                        "algorithmic_bytes_per_clip": ab, "clips_per_launch": clips_per_launch_o,
                         "kernel_ms_avg": round(k1, 4), "stage2_kernel_ms_avg": round(k2, 4),
                         "fp32_canonical_tflops": round(canon * clips_per_launch_o / (k1 * 1e-3) / 1e12, 2),
                         "fp32_peak_tflops": FP32_PEAK_TFLOPS,
@@ -923,6 +957,9 @@ def run_rank(args) -> int:
             except Exception as e:                          # noqa: BLE001 -- keep the scaling run alive, say what happened
                 comm_note = f"LBAudioDetectiveCommInitRank failed ({e}); keys reduced through torch.distributed instead"
                 sys.stderr.write("bench.py: " + comm_note + "\n")
+            # the library's communicator as RCCL itself describes it: ncclCommCount must be the world size on EVERY rank
+            me["comm_count"], me["comm_rank"] = (comm.info() if comm is not None else (0, -1))
+            result["devices"] = regather_devices()
             if dist_on:                                     # all ranks on the same path, or none
                 ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
                 dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -1106,6 +1143,14 @@ def run_rank(args) -> int:
         if bad:
             sys.stderr.write("bench.py: SELF-CHECK FAILED: " + "; ".join(bad) + "\n")
             rc = 4
+        wrong = [d for d in result.get("devices", []) if "comm_count" in d and (d["comm_count"] != world or d["comm_rank"] != d["rank"])]
+        if wrong:
+            sys.stderr.write("bench.py: the library's RCCL communicator does not span the run: " + "; ".join(
+                f"rank {d['rank']} (device {d.get('device_index')}, pid {d['pid']}) reports {d['comm_count']} rank(s), "
+                f"itself as rank {d['comm_rank']}" for d in wrong) + f" -- expected {world}\n")
+            rc = rc or 6
+        result["library_comm_count"] = (sorted({d["comm_count"] for d in result.get("devices", []) if "comm_count" in d}) or [None])[0] \
+            if len({d.get("comm_count") for d in result.get("devices", []) if "comm_count" in d}) <= 1 else "differs between ranks"
         if dist_on and result.get("compare", {}).get("collective_fallback"):
             sys.stderr.write("bench.py: the library's RCCL communicator could not be created; the compare leg fell back to "
                              "torch.distributed -- a scaling run must not pass like this\n")

@@ -476,6 +476,10 @@ unsigned long long* LBAudioDetectiveCorpusShardKeysHost(LBAudioDetectiveCorpusRe
 OSStatus LBAudioDetectiveCommGetUniqueId(void* outUniqueId);
 OSStatus LBAudioDetectiveCommInitRank(void** outComm, SInt32 inNumberOfRanks, const void* inUniqueId, SInt32 inRank);
 OSStatus LBAudioDetectiveCommDestroy(void* inComm);
+/* What the communicator itself says (ncclCommCount / ncclCommUserRank): the number of ranks that joined it and this
+ * rank's number in it.  Round 6: a multi-rank run can check that the library's communicator -- not only the host's own
+ * process group -- spans every rank (bench.py --gpus N refuses a line whose count differs from N and names the rank). */
+OSStatus LBAudioDetectiveCommGetInfo(void* inComm, SInt32* outNumberOfRanks, SInt32* outRank);
 /* Several queries against one pass over the corpus -- the shape of the reference's own test, Q originals against N
  * candidates (LBAudioDetectiveTests.m:57-91).  Uniform corpus: up to 8 queries share each read of an entry.  Ragged
  * corpus (round 5): queries of ONE length share their passes over the records, four per launch (eight in the scan of short

@@ -154,6 +154,7 @@ _SIGNATURES = {
     "LBAudioDetectiveCommGetUniqueId": (OSStatus, [C.c_void_p]),
     "LBAudioDetectiveCommInitRank": (OSStatus, [_P(C.c_void_p), SInt32, C.c_void_p, SInt32]),
     "LBAudioDetectiveCommDestroy": (OSStatus, [C.c_void_p]),
+    "LBAudioDetectiveCommGetInfo": (OSStatus, [C.c_void_p, _P(SInt32), _P(SInt32)]),
     "LBAudioDetectiveCorpusDispose": (None, [Ref]),
     "LBAudioDetectiveCorpusGetCount": (UInt64, [Ref]),
     "LBAudioDetectiveCorpusGetEntryStrideBytes": (UInt32, [Ref]),

@@ -665,6 +665,12 @@ class Comm:
         _check(self._L.LBAudioDetectiveCommInitRank(C.byref(ref), n_ranks, unique_id, rank), "CommInitRank")
         self._ref = ref
 
+    def info(self):
+        """(ranks that joined the communicator, this rank's number in it) -- ncclCommCount / ncclCommUserRank."""
+        n, r = N.SInt32(0), N.SInt32(0)
+        _check(self._L.LBAudioDetectiveCommGetInfo(self._ref, C.byref(n), C.byref(r)), "CommGetInfo")
+        return int(n.value), int(r.value)
+
     def dispose(self):
         if getattr(self, "_ref", None):
             self._L.LBAudioDetectiveCommDestroy(self._ref)

@@ -96,7 +96,10 @@ OSStatus launch_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFingerpr
         // have -- nothing is trusted after one: everything that may still touch the words finishes, then they are cleared
         for (hipEvent_t e : c->query_ev)
             if (e) (void)hipEventSynchronize(e);
-        LBAD_HIP(hipMemset(c->d_scan_out, 0, (size_t)kQuerySlots * kScanOutWords * 8));
+        // on the scan's own stream and awaited: the scan may run on a non-blocking stream, which a null-stream memset does
+        // not order itself against (round-5 advice)
+        LBAD_HIP(hipMemsetAsync(c->d_scan_out, 0, (size_t)kQuerySlots * kScanOutWords * 8, stream));
+        LBAD_HIP(hipStreamSynchronize(stream));
         c->scan_out_dirty = false;
     }
     const uint32_t slot = (uint32_t)(c->query_seq++ % kQuerySlots);
@@ -156,7 +159,7 @@ OSStatus run_queries_ragged(LBAudioDetectiveCorpus* c, const LBAudioDetectiveFin
         return noErr;
     }
     bool any_short = false;                                // the systolic scan of short queries max-es its keys in place
-    for (uint32_t i = 0; i < n; ++i) any_short = any_short || sliding_short(qs[i]->count, c->ne_max);
+    for (uint32_t i = 0; i < n; ++i) any_short = any_short || sliding_short(qs[i]->count, c->ne_max) || (n > 1 && sliding_multi(qs[i]->count, c->ne_max));
     if (any_short) LBAD_HIP(hipMemsetAsync(keys, 0, (size_t)n * sizeof(unsigned long long), stream));
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
@@ -433,6 +436,7 @@ void LBAudioDetectiveCorpusDispose(LBAudioDetectiveCorpusRef c) {
     if (c->d_key) (void)hipFree(c->d_key);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->append_event) (void)hipEventDestroy(c->append_event);
+    if (c->shard_stale_event) (void)hipEventDestroy(c->shard_stale_event);
     if (c->d_fast_key) (void)hipFree(c->d_fast_key);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -83,12 +83,12 @@ OSStatus rccl_all_reduce_max(void* context, UInt64* keys, UInt32 count, void* st
                                    static_cast<hipStream_t>(stream)), "ncclAllReduce");
 }
 
-// wait for `stream` without hanging for ever on a peer that never joined the exchange
-OSStatus wait_with_deadline(hipStream_t stream) {
+// wait for `stream` (or, stream == nullptr, for `event`) without hanging for ever on a peer that never joined the exchange
+OSStatus wait_with_deadline(hipStream_t stream, hipEvent_t event = nullptr) {
     const uint32_t limit = g_exchange_timeout_ms.load();
     const auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 0;; ++spins) {
-        const hipError_t e = hipStreamQuery(stream);
+        const hipError_t e = event ? hipEventQuery(event) : hipStreamQuery(stream);
         if (e == hipSuccess) return noErr;
         if (e != hipErrorNotReady) return hip_status(e, "sharded query", __LINE__);
         if (limit && (spins & 0x3FF) == 0 &&
@@ -136,6 +136,19 @@ OSStatus LBAudioDetectiveCommDestroy(void* inComm) {
     return lbad::nccl_status(r.CommDestroy(static_cast<ncclComm_t>(inComm)), "ncclCommDestroy");
 }
 
+OSStatus LBAudioDetectiveCommGetInfo(void* inComm, SInt32* outNumberOfRanks, SInt32* outRank) {
+    if (!inComm) return kLBAudioDetectiveArgumentInvalid;
+    lbad::Rccl& r = lbad::rccl();
+    if (!r.ok) return kLBAudioDetectiveCollectiveError;
+    int count = 0, rank = 0;
+    OSStatus st = lbad::nccl_status(r.CommCount(static_cast<ncclComm_t>(inComm), &count), "ncclCommCount");
+    if (st == noErr) st = lbad::nccl_status(r.CommUserRank(static_cast<ncclComm_t>(inComm), &rank), "ncclCommUserRank");
+    if (st != noErr) return st;
+    if (outNumberOfRanks) *outNumberOfRanks = count;
+    if (outRank) *outRank = rank;
+    return noErr;
+}
+
 void LBAudioDetectiveSetExchangeTimeout(UInt32 inMilliseconds) { lbad::g_exchange_timeout_ms.store(inMilliseconds); }
 
 // The sharded query, exchange step as a parameter.  Nothing between "the other ranks may already be waiting" and the
@@ -153,20 +166,24 @@ OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef i
     // the key block is ONE per corpus: two threads with sharded queries on the same corpus take turns (round-4 advice)
     std::unique_lock<std::mutex> keys_lock;
     if (inCorpus) keys_lock = std::unique_lock<std::mutex>(inCorpus->shard_lock);
+    bool block_busy = false;          // the corpus' key block may still be written by a call that gave up: hands off
     if (inCorpus && inCorpus->shard_stale) {
         // an earlier call gave up waiting: its copy and its collective may still be queued behind the block -- they must
-        // have drained before the block is written again (this wait has the same deadline; a stream that is still stuck
-        // fails the call, on every rank alike)
-        OSStatus drained = lbad::wait_with_deadline(inCorpus->shard_stale_stream);
-        if (drained != noErr) first_error = drained;
+        // have drained before the block is written again.  What is awaited is an EVENT recorded behind that work when the
+        // call gave up (round-5 advice: the caller may have destroyed the stream since; an event outlives it), with the
+        // same deadline.  Still stuck: this call fails on every rank alike, and -- so that the ranks stay in step -- still
+        // joins the exchange, with zero keys from the spare block and WITHOUT a local scan into the busy one.
+        OSStatus drained = inCorpus->shard_stale_event ? lbad::wait_with_deadline(nullptr, inCorpus->shard_stale_event) : noErr;
+        if (drained != noErr) { first_error = drained; block_busy = true; }
         else inCorpus->shard_stale = false;
     }
     for (UInt32 done = 0; done < inCount; done += lbad::kKeysPerExchange) {
         const UInt32 n = inCount - done < lbad::kKeysPerExchange ? inCount - done : lbad::kKeysPerExchange;
-        unsigned long long* keys = inCorpus ? LBAudioDetectiveCorpusShardKeysDevice(inCorpus) : nullptr;
-        unsigned long long* host = inCorpus ? LBAudioDetectiveCorpusShardKeysHost(inCorpus) : nullptr;
+        unsigned long long* keys = inCorpus && !block_busy ? LBAudioDetectiveCorpusShardKeysDevice(inCorpus) : nullptr;
+        unsigned long long* host = inCorpus && !block_busy ? LBAudioDetectiveCorpusShardKeysHost(inCorpus) : nullptr;
         OSStatus local = noErr;
-        if (!inCorpus || !inQueries || !keys || !host) local = kLBAudioDetectiveArgumentInvalid;
+        if (block_busy) local = first_error;
+        else if (!inCorpus || !inQueries || !keys || !host) local = kLBAudioDetectiveArgumentInvalid;
         else if (inIndexBase + LBAudioDetectiveCorpusGetCount(inCorpus) > 0x100000000ull) local = kLBAudioDetectiveArgumentInvalid;
         else
             local = n == 1 ? LBAudioDetectiveCorpusQueryKeyDevice(inCorpus, inQueries[done], inRange, inIndexBase, keys, stream)
@@ -182,7 +199,13 @@ OSStatus LBAudioDetectiveCorpusQueryBatchShardedWith(LBAudioDetectiveCorpusRef i
             st = lbad::hip_status(hipMemcpyAsync(host, keys, (size_t)n * 8, hipMemcpyDeviceToHost, stream), "keys D2H", __LINE__);
         if (st == noErr) {
             st = lbad::wait_with_deadline(stream);
-            if (st != noErr && inCorpus) { inCorpus->shard_stale = true; inCorpus->shard_stale_stream = stream; }
+            if (st != noErr && inCorpus && !block_busy) {
+                // remember WHERE the stuck work ends, not the stream it sits on
+                inCorpus->shard_stale = true;
+                if (!inCorpus->shard_stale_event &&
+                    hipEventCreateWithFlags(&inCorpus->shard_stale_event, hipEventDisableTiming) != hipSuccess) inCorpus->shard_stale_event = nullptr;
+                if (inCorpus->shard_stale_event) (void)hipEventRecord(inCorpus->shard_stale_event, stream);
+            }
         }
         if (st == noErr && local == noErr)
             for (UInt32 i = 0; i < n; ++i)

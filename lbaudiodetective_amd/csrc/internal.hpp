@@ -282,6 +282,7 @@ constexpr uint32_t kSlideMaxGrid = 1024;
 SlideShape sliding_shape(uint64_t tasks_a, uint64_t tasks_b, uint32_t n_q = 1);
 // how many of n_left queries of one length a single launch takes (1, 2, 4; 8 for the systolic scan of short queries)
 uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t n_left);
+bool sliding_multi(uint32_t n_query, uint32_t ne_max);    // a batch of such queries takes compare_short_multi_kernel (keys max-ed in place)
 // One launch of the scan: n_q queries of one length.  d_queries: their blocks (build_sliding_query without the header),
 // (n_query + 1) * 16 words each, on the device; h_query: the same block of a single query on the host -- short enough it
 // travels in the kernel's arguments and d_queries may be null.  d_acc (n_q words) and d_ticket are zero between scans
@@ -481,6 +482,6 @@ struct LBAudioDetectiveCorpus {
     bool scan_out_dirty = false;                 // a scan's launch failed: clear the words before the next one
     std::mutex shard_lock;                       // the sharded query's key block is one per corpus (api_rccl.cpp)
     bool shard_stale = false;                    // a sharded query timed out: work may still be queued behind the key block
-    hipStream_t shard_stale_stream = nullptr;
+    hipEvent_t shard_stale_event = nullptr;      // ... recorded behind that work when the call gave up (the stream may be gone by the next call)
     uint64_t query_seq = 0;
 };

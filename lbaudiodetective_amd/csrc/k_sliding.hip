@@ -1340,7 +1340,12 @@ __global__ __launch_bounds__(kSlThreads, (K == 4 && QN == 1) ? 4 : 1) void compa
 //     With equal static shares the waves did not finish together: the SIMD serves its oldest wave first, the workgroups
 //     placed first ended at 0.51 ms, the last at 1.09 (tools/exp/short_multi_stamps.py), and a SIMD's last wave, alone,
 //     issues at a fraction of the rate four waves reach together -- the vector ALU idled 60 % of the scan.
-constexpr uint32_t kShortMultiMaxQuery = 7;          // queries of up to seven sub-fingerprints (windows reach back six records)
+#ifndef LBAD_SHORT_MULTI_MAX
+#define LBAD_SHORT_MULTI_MAX 12
+#endif
+// longest query of a BATCH this kernel takes (instantiated for 1..12; the records' place fields reach 15).  Crossover re-measured in round 6,
+// eight queries against 1 M entries of 20..70: 1.00 / 1.05 / 1.14 / 1.36 ms at 8 / 9 / 10 / 12 here, 1.24 / 1.25 / 1.34 / 1.45 through the task kernel.
+static_assert(LBAD_SHORT_MULTI_MAX >= 7 && LBAD_SHORT_MULTI_MAX <= 12, "compare_short_multi_kernel is instantiated for query lengths 1..12");
 constexpr int kShortMultiK = 4;
 constexpr int kSmThreads = 1024;
 
@@ -1792,6 +1797,8 @@ hipError_t launch_synth_ragged(uint32_t seed, uint64_t first_entry, uint64_t n_e
 #endif
 constexpr uint32_t kShortEntries = 15;
 bool sliding_short(uint32_t n_query, uint32_t ne_max) { return n_query <= LBAD_SHORT_QUERY || ne_max <= kShortEntries; }
+// A BATCH of such queries goes through compare_short_multi_kernel (defined above; needs an entry longer than the query)
+bool sliding_multi(uint32_t n_query, uint32_t ne_max) { return n_query <= LBAD_SHORT_MULTI_MAX && ne_max > n_query; }
 
 static void sliding_variant(uint32_t subfp_len, uint32_t n_query, uint32_t range, uint32_t n_q, bool& full, bool& qlds, uint32_t& dyn_lds) {
     const uint4 rm = sliding_range_mask(subfp_len, range);
@@ -1818,6 +1825,7 @@ constexpr uint32_t kMultiLdsWords = 7000;           // dynamic LDS a launch of s
 // eight, the task scan four or two while their blocks fit the LDS next to the tables.
 uint32_t sliding_queries_per_launch(uint32_t n_query, uint32_t ne_max, uint32_t n_left) {
     if (n_left <= 1) return n_left;
+    if (sliding_multi(n_query, ne_max)) return n_left >= 8 ? 8u : (n_left >= 4 ? 4u : 2u);    // compare_short_multi_kernel
     if (sliding_short(n_query, ne_max)) {
         // one record per lane (windows of up to seven records): eight queries side by side; four records per lane: four (eight
         // would need 213 registers -- two waves per SIMD -- and gain nothing over two launches of four)
@@ -1938,6 +1946,16 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
 #define LBAD_SHORT_MULTI(QQ, NN)                                                                                                  \
     hipLaunchKernelGGL((compare_short_multi_kernel<QQ, NN>), dim3(grid), dim3(kSmThreads), 0, stream, d_recs, n_pos, scan.d_queries, \
                        step, n_chunks, per_group, rm4, index_base, out)
+#if LBAD_SHORT_MULTI_MAX > 7
+#define LBAD_SHORT_MULTI_MORE(QQ)                                                                                                 \
+        case 8: LBAD_SHORT_MULTI(QQ, 8); break;                                                                                   \
+        case 9: LBAD_SHORT_MULTI(QQ, 9); break;                                                                                   \
+        case 10: LBAD_SHORT_MULTI(QQ, 10); break;                                                                                 \
+        case 11: LBAD_SHORT_MULTI(QQ, 11); break;                                                                                 \
+        case 12: LBAD_SHORT_MULTI(QQ, 12); break;
+#else
+#define LBAD_SHORT_MULTI_MORE(QQ)
+#endif
 #define LBAD_SHORT_MULTI_N(QQ)                                                                                                    \
     switch (n_query) {                                                                                                            \
         case 1: LBAD_SHORT_MULTI(QQ, 1); break;                                                                                   \
@@ -1947,6 +1965,7 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         case 5: LBAD_SHORT_MULTI(QQ, 5); break;                                                                                   \
         case 6: LBAD_SHORT_MULTI(QQ, 6); break;                                                                                   \
         case 7: LBAD_SHORT_MULTI(QQ, 7); break;                                                                                   \
+        LBAD_SHORT_MULTI_MORE(QQ)                                                                                                 \
         default: return hipErrorInvalidValue;                                                                                     \
     }
         if (n_q == 2) { LBAD_SHORT_MULTI_N(2) } else if (n_q == 4) { LBAD_SHORT_MULTI_N(4) } else if (n_q == 8) { LBAD_SHORT_MULTI_N(8) }
@@ -1957,10 +1976,8 @@ hipError_t launch_compare_sliding(const uint4* d_recs, uint64_t n_pos, const uin
         if (launched != hipSuccess || tasks_b == 0) return launched;
         return run_short(look, n_query);
     };
-    if (sliding_short(n_query, ne_max)) {
-        if (n_q > 1 && n_query <= kShortMultiMaxQuery && tasks_a != 0 && !d_score_bits) return run_short_multi();
-        return run_short((n_query < ne_max ? n_query : ne_max) - 1u, 0u);
-    }
+    if (n_q > 1 && sliding_multi(n_query, ne_max) && tasks_a != 0 && !d_score_bits) return run_short_multi();
+    if (sliding_short(n_query, ne_max)) return run_short((n_query < ne_max ? n_query : ne_max) - 1u, 0u);
     SlideArgs a;
     a.index_base = index_base; a.n_entries = n_entries; a.nq = n_query; a.zero_rec = zero_rec;
     const uint4 rm = sliding_range_mask(subfp_len, range);

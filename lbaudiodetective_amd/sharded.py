@@ -17,7 +17,10 @@ FORCE_COLLECTIVES = False
 
 def _collective(group=None) -> bool:
     """Is there a process group this call should talk to?"""
-    import torch.distributed as dist
+    try:
+        import torch.distributed as dist
+    except ImportError:                 # a torch built without distributed support: one rank, no group
+        return False
     if not (dist.is_available() and dist.is_initialized()):
         return False
     return FORCE_COLLECTIVES or dist.get_world_size(group) > 1
@@ -116,6 +119,8 @@ def make_comm(rank: int = 0, world_size: int = 1, group=None):
         except Exception as e:          # noqa: BLE001 -- the other ranks are waiting in the broadcast: tell them
             err = e
     if world_size > 1 or _collective(group):
+        # (one rank without FORCE_COLLECTIVES never touches torch.distributed; FORCE_COLLECTIVES must be set identically on
+        # every rank BEFORE any helper of this module is called, or the ranks' broadcast calls do not pair up)
         import torch.distributed as dist
         dist.broadcast_object_list(uid, src=0, group=group)
     if uid[0] is None:

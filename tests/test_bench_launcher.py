@@ -67,7 +67,7 @@ def test_world_size_eight_with_empty_shards():
 
 
 def test_force_dist_takes_the_collective_branches_at_one_rank():
-    """`--force-dist` at world size 1 (gloo here; tests/test_gpu_parity.py runs the same switch on the nccl backend):
+    """`--force-dist` at world size 1 (gloo here; tests/test_gpu_ragged.py::test_bench_collective_paths_on_nccl_at_one_rank runs the same switch on the nccl backend):
     the process group exists, the reduction goes through torch.distributed and the line says so."""
     out = _run("--gpus", "1", "--force-dist", "--backend", "gloo", "--clips", "0", "--corpus", "2000")
     assert out.returncode == 0, out.stderr[-2000:]

@@ -19,7 +19,8 @@ if [ "$R" != "r02" ]; then
       PROF_DRIVER=tools/prof_sliding_batch.py PROF_SETS=short tools/prof_run.sh ${R}_sliding_batch8_q5 1000000 5 8 5
     fi
   fi
-  exit 0
+  # round 6: SWEEP=1 repeats round 2's LDS-tile sizing sweep of configs[4] on the generic kernel as it is now
+  if [ "$SWEEP" != "1" ]; then exit 0; fi
 fi
 # LDS-tile sizing sweep of BASELINE configs[4] on the generic kernel: waves per workgroup x twiddle cache
 for w in 1 2 4 6 7; do for c in 1 0; do
