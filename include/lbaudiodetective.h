@@ -483,7 +483,8 @@ OSStatus LBAudioDetectiveCommGetInfo(void* inComm, SInt32* outNumberOfRanks, SIn
 /* Several queries against one pass over the corpus -- the shape of the reference's own test, Q originals against N
  * candidates (LBAudioDetectiveTests.m:57-91).  Uniform corpus: up to 8 queries share each read of an entry.  Ragged
  * corpus (round 5): queries of ONE length share their passes over the records, four per launch (eight in the scan of short
- * queries); a batch of mixed lengths runs one group per length.  Results are those of inCount separate
+ * queries -- round 6: queries of up to 12 sub-fingerprints, eight per launch in a kernel of their own: eight queries of 5
+ * cost 2.2 x one); a batch of mixed lengths runs one group per length.  Results are those of inCount separate
  * LBAudioDetectiveCorpusQuery calls, bit for bit.  The KeysDevice form writes inCount keys to the device pointer
  * outKeys for a sharded max-reduction. */
 OSStatus LBAudioDetectiveCorpusQueryBatch(LBAudioDetectiveCorpusRef inCorpus, const LBAudioDetectiveFingerprintRef* inQueries,

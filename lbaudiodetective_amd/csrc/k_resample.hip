@@ -218,7 +218,14 @@ __device__ __forceinline__ float sinc_sample_tiled(const float* __restrict__ in,
 #define LBAD_RS_PERIODS 3
 #endif
 constexpr int kPeriods = LBAD_RS_PERIODS;
-constexpr int kInStride = kInMax + kInMax / 32 + 1;     // one pad word per 32 samples: lanes 8 samples apart, 32 lanes, 32 distinct banks
+// Round 6: one pad word per EIGHT samples (sample q at word q + (q >> 3)): lanes 8 samples apart are 9 words apart, 32 lanes
+// on 32 banks as before -- but now the pad a thread meets while it walks its taps repeats every eight taps, so the LDS
+// address of tap 8 m + r is (a per-thread constant for r) + 9 m: the step loop below has no address arithmetic per tap.
+// With a pad per 32 samples every (tap, output) paid an add, a shift, a mask and an add -- 48 integer instructions beside
+// the 36 double-precision ones of four taps x three outputs: as much time as the arithmetic itself.
+constexpr int kInMaxR = 2816;                           // samples of a staged range (256 outputs at ratio 8.7 + 420 taps: 2640)
+constexpr int kInStride = kInMaxR + kInMaxR / 8 + 1;    // 3169 words, as before (three ranges: 38 KB, four workgroups per CU)
+static_assert(kInMaxR <= kInMax, "the rational path's ranges fit the block sized for the tiled path");
 
 __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __restrict__ in, float* __restrict__ out,
                                               float (*s_in)[kInStride]) {
@@ -243,11 +250,11 @@ __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __
             const uint64_t nl = nf + lanes - 1 < f.n_write ? nf + lanes - 1 : f.n_write - 1;
             kbase[k] = (long)((nf * P) / Q) + (long)f.ph_m_min;
             const long kend = (long)((nl * P) / Q) + (long)f.ph_m_min + (long)f.ph_m_span - 1;
-            staged[k] = kend - kbase[k] + 1 <= (long)kInMax;
+            staged[k] = kend - kbase[k] + 1 <= (long)kInMaxR;
             if (staged[k]) {
                 for (long p = threadIdx.x; p <= kend - kbase[k]; p += kThreads) {
                     const long kk = kbase[k] + p;
-                    s_in[k][p + (p >> 5)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
+                    s_in[k][p + (p >> 3)] = kk >= 0 && (uint64_t)kk < f.n_in ? in[(uint64_t)kk] : 0.0f;
                 }
             }
         }
@@ -258,7 +265,10 @@ __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __
         const uint64_t np = n0 * P, r = np % Q;
         const long ip0 = (long)(np / Q), m0 = (long)f.ph_first[r];
         const uint32_t cnt = f.ph_count[r];
-        const double* w = f.ph_w + (size_t)(m0 - (long)f.ph_m_min) * Q + r;
+        // (a global-memory pointer, said so: as a generic one every weight was a flat load that also counts as an LDS access,
+        // and the waits for the samples' LDS reads then wait for the weights as well)
+        typedef const __attribute__((address_space(1))) double* gdouble_p;
+        gdouble_p w = (gdouble_p)(f.ph_w + (size_t)(m0 - (long)f.ph_m_min) * Q + r);
         double acc[kPeriods];
         bool act[kPeriods];
         uint32_t q[kPeriods];
@@ -272,11 +282,45 @@ __device__ __forceinline__ void rational_file(const FileDesc& f, const float* __
             all_staged = all_staged && (staged[k] || !any[k]);
         }
         if (all_staged) {                                                   // (uniform) the usual case
-            for (uint32_t j = 0; j < cnt; ++j, w += Q) {
+            // tap j = 8 m + r of output k reads sample q[k] + j, i.e. word (q[k] + (q[k] >> 3)) + 9 m + r + ((q[k] & 7) + r >> 3):
+            // eight per-thread pointers per output, all moved on by 9 words per eight taps; taps in ascending order, the three
+            // outputs side by side -- the operations and their order are those of the loop this replaces
+            const float* at[kPeriods][8];
+#pragma unroll
+            for (int k = 0; k < kPeriods; ++k)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) at[k][r] = &s_in[k][q[k] + (q[k] >> 3) + (uint32_t)r + (((q[k] & 7u) + (uint32_t)r) >> 3)];
+            uint32_t j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                // eight taps at a time: their weights and the 24 samples are all requested before the first product (left to
+                // itself the scheduler, short of registers, waited for every load right behind it)
+                double wv[8];
+                float x[kPeriods][8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) wv[r] = w[(size_t)r * Q];
+#pragma unroll
+                for (int k = 0; k < kPeriods; ++k)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) x[k][r] = *at[k][r];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int k = 0; k < kPeriods; ++k) acc[k] += wv[r] * (double)x[k][r];
+                w += 8 * Q;
+#pragma unroll
+                for (int k = 0; k < kPeriods; ++k)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) at[k][r] += 9;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k < kPeriods; ++k) q[k] += j;
+            for (; j < cnt; ++j, w += Q) {                                  // (the last cnt mod 16 taps)
                 const double wv = *w;
 #pragma unroll
                 for (int k = 0; k < kPeriods; ++k) {
-                    acc[k] += wv * (double)s_in[k][q[k] + (q[k] >> 5)];
+                    acc[k] += wv * (double)s_in[k][q[k] + (q[k] >> 3)];
                     ++q[k];
                 }
             }

@@ -552,7 +552,7 @@ def test_bench_collective_paths_on_nccl_at_one_rank(gpu):
 @pytest.mark.parametrize("L,seed", [(200, 1), (199, 2), (64, 3)])
 def test_ragged_batches_equal_single_queries(lb, gpu, oracle, L, seed):
     """Round 5: several queries of ONE length share their passes over the records (four per launch of the task scan, eight of
-    the systolic scan of short queries); a batch of mixed lengths runs a group per length.  Upstream's caller is Q x N
+    the scan of short queries -- since round 6 compare_short_multi_kernel, lengths 1..12); a batch of mixed lengths runs a group per length.  Upstream's caller is Q x N
     (LBAudioDetectiveTests.m:57-91: ten originals against ten candidates).  Every (index, score bits) of a batch equals the
     single query's and the oracle's, whatever the order and the group sizes (1, 2, 4, 8 and what is left over)."""
     rng = np.random.default_rng(4200 + seed)
@@ -570,8 +570,11 @@ def test_ragged_batches_equal_single_queries(lb, gpu, oracle, L, seed):
         q[::3, : max(1, L // 7)] ^= 1
         return q
 
+    # (round 6: batches of queries of up to 12 sub-fingerprints go through compare_short_multi_kernel -- every length 1..12,
+    # groups of 8 / 4 / 2 and a single left over; 13 is the first length of the task kernel's batches again)
     for lengths in ([21] * 4, [21] * 8, [48] * 7, [5] * 8, [5] * 3 + [12] * 9, [21, 48, 21, 5, 48, 21, 21, 64, 21, 2, 70, 21, 48],
-                    [30, 30], [16] * 5, [33] * 11):
+                    [30, 30], [16] * 5, [33] * 11, [1] * 2 + [2] * 3 + [3] * 4 + [4] * 2, [6] * 8 + [7] * 7, [8] * 15, [9] * 4 + [10] * 6,
+                    [11] * 2 + [12] * 8 + [13] * 8):
         qs = [make(nq) for nq in lengths]
         fps = [lb.Fingerprint.from_bools(q) for q in qs]
         for rg in (0, max(1, L // 2), 7):

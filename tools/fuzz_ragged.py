@@ -58,7 +58,7 @@ for t in range(trials):
     if rng.integers(0, 4) == 0:
         entries[int(rng.integers(0, n))][:] = 0
     counts = np.array([e.shape[0] for e in entries], np.uint32)
-    nq = int(rng.choice([1, 2, 3, 5, 8, 21, 33, 48, 64, 65, 100, 130]))
+    nq = int(rng.choice([1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 12, 13, 21, 33, 48, 64, 65, 100, 130]))
     src = entries[int(rng.integers(0, n))]
     q = rand_fp(nq, L, p_zero, p_both)
     k = min(nq, src.shape[0])
@@ -92,7 +92,7 @@ for t in range(trials):
         # round 5: a batch of 2..11 queries, one or two lengths mixed, in one call (groups of four / eight share a pass) --
         # every (index, score bits) against the oracle
         nb = int(rng.integers(2, 12))
-        nq2 = int(rng.choice([1, 4, 8, 16, 21, 33, 48, 70]))
+        nq2 = int(rng.choice([1, 4, 7, 8, 10, 12, 16, 21, 33, 48, 70]))
         qs = []
         for b in range(nb):
             m = nq if (b % 3 or rng.integers(0, 2)) else nq2
