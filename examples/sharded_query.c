@@ -67,6 +67,14 @@ int main(int argc, char** argv) {
     }
     void* comm = NULL;
     CHECK(LBAudioDetectiveCommInitRank(&comm, n_ranks, id, rank));
+    {   /* what RCCL itself says about the communicator: every rank joined, and this one is who it thinks it is */
+        SInt32 joined = 0, me = -1;
+        CHECK(LBAudioDetectiveCommGetInfo(comm, &joined, &me));
+        if (joined != n_ranks || me != rank) {
+            fprintf(stderr, "rank %d: the communicator reports %d rank(s), this one as %d\n", rank, (int)joined, (int)me);
+            return 3;
+        }
+    }
 
     /* this rank's contiguous index range, sizes differing by at most one */
     const UInt64 base = total / n_ranks, extra = total % n_ranks;
