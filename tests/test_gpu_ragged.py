@@ -597,6 +597,54 @@ def test_ragged_batches_equal_single_queries(lb, gpu, oracle, L, seed):
         assert (idx, _bits(sc)) == (bi + 1000, _bits(bs))
 
 
+def test_full_size_short_query_batches(lb, gpu, oracle):
+    """Round 6, compare_short_multi_kernel at BASELINE size: 1 M synthetic entries of 4..70 sub-fingerprints (37 M records), eight
+    queries of 5 and eight of 11 in one call each -- cut out of entries spread over the corpus (one of them an entry of exactly
+    the query's length, which the batch kernel leaves to the systolic scan's second launch), a few sign pairs flipped.  Every
+    key of a batch equals the single query's (another kernel) and the planted entry; around every planted entry the per-entry
+    scores of the single query equal the oracle's bit for bit; a twin appended behind everything loses the tie."""
+    n = 1_000_000
+    counts = oracle.synth_ragged_counts(CSEED, 0, n, 4, 70)
+    total = int(counts.sum())
+    packed = lb.synth_ragged_corpus_device(CSEED, 0, counts, 200)
+    corpus = lb.Corpus.ragged(200, n + 8, total + 200)
+    corpus.append_ragged_packed_device(packed, counts)
+    del packed
+    rng = np.random.default_rng(66)
+    for nq in (5, 11):
+        exact = int(np.nonzero(counts == nq)[0][3])                      # an entry of exactly nq sub-fingerprints ("B": not longer)
+        homes = [123, 100_777, 250_001, exact, 499_999, 640_000, 777_777, n - 2]
+        qs, planted = [], []
+        for e in homes:
+            while counts[e] < nq:
+                e += 1
+            src = oracle.synth_entry(CSEED, e, int(counts[e]), 200)
+            o = int(rng.integers(0, counts[e] - nq + 1))
+            q = src[o:o + nq].copy()
+            flip = rng.random((nq, 100)) < 0.04
+            pos = q[:, 0::2].copy()
+            q[:, 0::2] = np.where(flip, q[:, 1::2], pos)
+            q[:, 1::2] = np.where(flip, pos, q[:, 1::2])
+            qs.append(q)
+            planted.append(e)
+        fps = [lb.Fingerprint.from_bools(q) for q in qs]
+        got = corpus.query_batch(fps)
+        for q, fq, e, g in zip(qs, fps, planted, got):
+            one = corpus.query(fq)
+            assert (g[0], _bits(g[1])) == (one[0], _bits(one[1])), (nq, e, g, one)
+            assert g[0] == e and g[1] > 0.9, (nq, e, g)
+            lo, hi = max(0, e - 300), min(n, e + 300)
+            ent = oracle.synth_ragged_entries(CSEED, lo, counts[lo:hi], 200)
+            bi, bs, want = oracle.corpus_best_ragged(q, (ent, counts[lo:hi]), 200, nthreads=8, want_scores=True)
+            assert lo + bi == e and _bits(bs) == _bits(g[1])
+            scores = corpus.scores_device(fq).cpu().numpy()
+            assert np.array_equal(scores[lo:hi].view(np.uint32), want.view(np.uint32))
+        # a twin of the first planted entry behind everything: equal score, the lower index keeps the result (T.m:80)
+        corpus.append_fingerprint(lb.Fingerprint.from_bools(oracle.synth_entry(CSEED, planted[0], int(counts[planted[0]]), 200)))
+        again = corpus.query_batch(fps)
+        assert [(a[0], _bits(a[1])) for a in again] == [(g[0], _bits(g[1])) for g in got]
+
+
 @pytest.mark.parametrize("nq", [21, 200, 2000])
 def test_bound_pruning_against_adversarial_layouts(lb, gpu, oracle, nq):
     """The bound that lets a top-1 scan give up groups of offsets (k_sliding.hip: kPruneMargin) against the layouts that
