@@ -56,6 +56,12 @@
 // (QN: LBAudioDetectiveTests.m:57-91 is Q originals against N candidates), eight in the systolic scan of short queries;
 // a single query travels as a kernel argument and the scan clears its own result words (ScanOut: no copy, no memset on
 // the stream in front of a scan).
+//
+// Round 6: BATCHES of queries of up to 12 sub-fingerprints against the entries longer than them go through a kernel of their
+// own, compare_short_multi_kernel (four records per lane, query words in vector registers on register banks the record words
+// do not use, pairs 96..99 from an LDS table, chunks claimed from an LDS cursor: eight queries of 5 in 0.63 ms where the
+// systolic scan took 1.00); the task scan's query quads lie rotated by one word in LDS for the same bank reason, and no
+// instance of either kernel spills a register (tests/test_isa.py checks the compiled code for both).
 #include "internal.hpp"
 
 #include <cmath>
