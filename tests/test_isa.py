@@ -67,3 +67,17 @@ def test_no_three_sources_on_one_register_bank(sliding_isa):
         assert bad == 0, (name, ops, bad)
         checked += 1
     assert checked >= 6 + 21
+
+
+def test_ratio_without_the_table_is_the_ieee_quotient(tmp_path):
+    """compare_short_multi_kernel computes hits / possible as fma(hf, rh, RN(hf * rl)) with rh = RN(1 / pf), rl = RN(fma(-pf, rh, 1) * rh)
+    instead of reading the table of 5151 quotients: tools/verify_ratio_fma.c runs exactly those correctly rounded operations for
+    every 0 <= hits <= possible <= 100 and compares the bits with (float)hits / (float)possible (LBAudioDetectiveFingerprint.m:175)."""
+    if shutil.which("gcc") is None:
+        pytest.skip("no host compiler")
+    exe = tmp_path / "verify_ratio_fma"
+    build = subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", os.path.join(ROOT, "tools", "verify_ratio_fma.c"), "-o", str(exe), "-lm"],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0 and "5151 pairs checked, 0 disagree" in run.stdout, run.stdout[-500:]
