@@ -464,8 +464,9 @@ def sliding_leg(args, torch, np):
                                          "layout_GBps": round(32 * total / (mo * 1e-3) / 1e9, 1)}
     out["other_query_lengths"] = others
     # Q x N, the shape of the reference's own test (LBAudioDetectiveTests.m:57-91: ten originals against ten candidates):
-    # eight queries of one length in ONE call (four per pass of the task scan, eight of the systolic scan of short queries)
-    # against eight single calls; every key of the batch must equal the single query's
+    # eight queries of one length in ONE call (four per pass of the task scan; queries of up to 12 sub-fingerprints eight per
+    # launch of compare_short_multi_kernel, round 6) against eight single calls -- which run through OTHER kernels (the task
+    # scan / the systolic scan of one query): every key of the batch must equal the single query's
     corpus.set_bound_pruning(False)
     batches = {}
     for n_b in (21, 5):
@@ -493,7 +494,8 @@ def sliding_leg(args, torch, np):
             "one_call_ms": round(mb, 4), "eight_single_calls_ms": round(t_single, 4), "speedup": round(t_single / mb, 2),
             "times_one_query": round(mb / (t_single / 8), 2), "same_keys": bool(torch.equal(keys8, single8)),
             # (the records are fetched once per launch of four / eight queries: bytes over time is NOT eight times an HBM rate)
-            "launches": 1 if n_b <= 7 else 2, "subfingerprint_compares_per_s": round(8 * n_b * total / (mb * 1e-3), 1)}
+            "launches": 1 if n_b <= 12 else 2,
+            "kernel": ("compare_short_multi_kernel<8, %d>" % n_b) if n_b <= 12 else "compare_sliding_kernel<FULL, false, true, 4, 1024> x 2", "subfingerprint_compares_per_s": round(8 * n_b * total / (mb * 1e-3), 1)}
     corpus.set_bound_pruning(True)
     out["query_batches"] = batches
     if not args.no_cpu_baseline:
