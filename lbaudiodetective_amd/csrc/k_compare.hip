@@ -22,6 +22,8 @@
 //            HBM traffic for 125 bytes of information.
 #include "internal.hpp"
 
+#include <cmath>
+
 #include <cstring>
 
 namespace lbad {
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void pack_planes_kernel(const uint32_t* _
 constexpr uint32_t kLp = 200;
 constexpr uint32_t kSubSpan = 7;  // a 200-bit field at an even multiple-of-8 bit offset touches <= 7 words
 
-constexpr uint32_t kPlaneQueryWords = 8 * 4 * 2 + 8 * kSubSpan + 8;   // room for NSUB = 8 (13 planes)
+constexpr uint32_t kPlaneQueryWords = 144;   // room for NSUB = 8: 13 planes x 4 + 8 x kSubSpan masks + 8 possible + 8 + 8 reciprocal pairs = 132
 
 template <int NSUB>
 struct PlaneShape {
@@ -306,7 +308,10 @@ struct PlaneShape {
     // constant block handed to the kernel: query stream, per-(sub, span word) NZ masks, possible counts
     static constexpr uint32_t off_mask = planes * 4;
     static constexpr uint32_t off_possible = off_mask + NSUB * kSubSpan;
-    static constexpr uint32_t total = off_possible + NSUB;
+    // round 6 (the batch scan): rh = RN(1 / possible), rl = RN(fma(-possible, rh, 1) * rh) per sub-fingerprint, 0 0 where nothing is possible
+    static constexpr uint32_t off_rh = off_possible + NSUB;
+    static constexpr uint32_t off_rl = off_rh + NSUB;
+    static constexpr uint32_t total = off_rl + NSUB;
 };
 
 // The query block travels in the kernel-argument segment: every lane reads the same words, so the
@@ -372,9 +377,14 @@ __global__ __launch_bounds__(kPlaneThreads) void compare_planes_kernel(const uin
     block_max_key_finish<kPlaneThreads / 64>(best, key_out, fin);
 }
 
-// Batch form: up to QB queries share one pass over the corpus (the scan is HBM-bound, so a handful of
-// extra popcount rounds per entry are free).  Query blocks (kPlaneQueryWords each) sit in global memory and
+// Batch form: up to QB queries share one pass over the corpus.  Query blocks (kPlaneQueryWords each) sit in global memory and
 // are read with wave-uniform indices, i.e. through the scalar cache.
+// Round 6: eight queries took 0.65 ms against 10 M entries (3.0 x one query; tools/exp/uniform_batch_time.py) -- not HBM-bound
+// as the round-2 comment here assumed but 280 vector instructions per (entry, query).  Now per 32-bit word of a sub-fingerprint's
+// span TWO three-input operations and a count: u = mask & ~(b ^ q), t = u & ~((b >> 1) ^ (q >> 1)) -- at an even bit the first
+// is "first Booleans equal", the second "second Booleans equal"; b >> 1 is taken once per entry for all queries, q >> 1 is a
+// scalar instruction -- and the quotient by two fused multiply-adds on (rh, rl) from the query block instead of an IEEE division
+// per sub-fingerprint: 125 instructions per (entry, query).
 constexpr int kQueryBatch = 8;
 
 template <int NSUB>
@@ -389,12 +399,14 @@ __global__ __launch_bounds__(kThreads) void compare_planes_batch_kernel(const ui
     for (int q = 0; q < kQueryBatch; ++q) best[q] = 0ull;
     for (uint64_t e = (uint64_t)blockIdx.x * kThreads + threadIdx.x; e < n_entries;
          e += (uint64_t)gridDim.x * kThreads) {
-        uint32_t b[S::planes * 4];
+        uint32_t b[S::planes * 4], b1[S::planes * 4];
 #pragma unroll
         for (uint32_t p = 0; p < S::planes; ++p) {
             const uint4 v = planes[(uint64_t)p * stride + e];
             b[4 * p + 0] = v.x; b[4 * p + 1] = v.y; b[4 * p + 2] = v.z; b[4 * p + 3] = v.w;
         }
+#pragma unroll
+        for (uint32_t w = 0; w < S::planes * 4; ++w) b1[w] = b[w] >> 1;       // (pairs never straddle a word: bit 2 p + 1 lands on 2 p)
 #pragma unroll
         for (int q = 0; q < kQueryBatch; ++q) {
             if ((uint32_t)q < n_queries) {
@@ -403,17 +415,19 @@ __global__ __launch_bounds__(kThreads) void compare_planes_batch_kernel(const ui
 #pragma unroll
                 for (uint32_t s = 0; s < (uint32_t)NSUB; ++s) {
                     const uint32_t w0 = (s * kLp) >> 5;
-                    uint32_t hits = 0;
+                    uint32_t h = 0x4B000000u;                      // hits counted on top of the bits of 2^23
 #pragma unroll
                     for (uint32_t j = 0; j < kSubSpan; ++j) {
                         if (w0 + j < S::planes * 4) {
-                            const uint32_t x = b[w0 + j] ^ qc[w0 + j];
-                            hits += __popc(~(x | (x >> 1)) & qc[S::off_mask + s * kSubSpan + j]);
+                            const uint32_t qw = qc[w0 + j];
+                            const uint32_t u = __builtin_amdgcn_bitop3_b32(qc[S::off_mask + s * kSubSpan + j], b[w0 + j], qw, 0x90);   // a & ~(b ^ c)
+                            const uint32_t t = __builtin_amdgcn_bitop3_b32(u, b1[w0 + j], qw >> 1, 0x90);
+                            h += __popc(t);
                         }
                     }
-                    const float possible = __uint_as_float(qc[S::off_possible + s]);
-                    const float ratio = possible > 0.0f ? __fdiv_rn((float)hits, possible) : 0.0f;
-                    sum = __fadd_rn(sum, ratio);
+                    const float hf = __fsub_rn(__uint_as_float(h), 8388608.0f);
+                    const float rh = __uint_as_float(qc[S::off_rh + s]), rl = __uint_as_float(qc[S::off_rl + s]);
+                    sum = __fadd_rn(sum, __fmaf_rn(hf, rh, __fmul_rn(hf, rl)));      // == hits / possible, 0 where nothing is possible
                 }
                 const float cand = __fdiv_rn(sum, (float)NSUB);
                 const float match = (0.0f < cand) ? cand : 0.0f;
@@ -514,7 +528,7 @@ bool planes_fast_supported(uint32_t subfp_len, uint32_t n_sub, uint32_t n_query)
 
 uint32_t planes_fast_const_words(uint32_t n_sub) {
     const uint32_t planes = (n_sub * kLp + 127) / 128;
-    return planes * 4 + n_sub * kSubSpan + n_sub;
+    return planes * 4 + n_sub * kSubSpan + 3 * n_sub;
 }
 
 // Host: build the constant block of the specialised kernel from the query's slot words.
@@ -547,6 +561,11 @@ void build_plane_query(const uint32_t* q_slots, uint32_t n_sub, uint32_t range, 
         uint32_t pbits;
         memcpy(&pbits, &pf, 4);
         out[words + n_sub * kSubSpan + s] = pbits;
+        // the quotient hits / possible by two fused multiply-adds (tools/verify_ratio_fma.c: exact for every hits <= possible)
+        const float rh = possible ? 1.0f / pf : 0.0f;
+        const float rl = std::fmaf(-pf, rh, possible ? 1.0f : 0.0f) * rh;
+        memcpy(&out[words + n_sub * kSubSpan + n_sub + s], &rh, 4);
+        memcpy(&out[words + n_sub * kSubSpan + 2 * n_sub + s], &rl, 4);
     }
 }
 

@@ -12,11 +12,15 @@
 #include <stdio.h>
 #include <string.h>
 
+#ifndef LIMIT
+#define LIMIT 100          /* pairs of a sub-fingerprint: 100 at 200 Booleans; -DLIMIT=128 for the uniform corpus' 256 */
+#endif
+
 static inline uint32_t to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 int main(void) {
     int bad = 0, n = 0;
-    for (int p = 0; p <= 100; ++p) {
+    for (int p = 0; p <= LIMIT; ++p) {
         const float pf = (float)p;
         volatile float rh = p ? 1.0f / pf : 0.0f;
         volatile float e = fmaf(-pf, rh, p ? 1.0f : 0.0f);
