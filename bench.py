@@ -1123,6 +1123,30 @@ def run_rank(args) -> int:
                                  "frac": round(25 * per * n_big / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                  "layout_GBps": round(big.entry_stride_bytes * n_big / (ms * 1e-3) / 1e9, 1)},
                 }
+                # Q x N on the uniform corpus (LBAudioDetectiveTests.m:57-91): eight queries share ONE pass over the planes;
+                # every key must equal the single query's
+                fps8 = []
+                for k8 in range(8):
+                    src8 = lb.unpack_packed(lb.synth_corpus_device(CSEED, (1_234_567 * (k8 + 1)) % n_big, 1, per, 200).cpu().numpy(), 200)
+                    fps8.append(lb.Fingerprint.from_bools(src8.reshape(per, 200)))
+                keys8 = torch.zeros(8, dtype=torch.int64, device=dev)
+                single8 = torch.zeros(8, dtype=torch.int64, device=dev)
+                for i8, f8 in enumerate(fps8):
+                    big.query_key_device(f8, single8[i8:i8 + 1])
+                for _ in range(3):
+                    big.query_batch_keys_device(fps8, keys8)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    big.query_batch_keys_device(fps8, keys8)
+                e1.record()
+                torch.cuda.synchronize()
+                ms8 = e0.elapsed_time(e1) / 10
+                result["compare_hbm"]["eight_queries_one_call"] = {
+                    "one_call_ms": round(ms8, 4), "times_one_query": round(ms8 / ms, 2), "same_keys": bool(torch.equal(keys8, single8)),
+                    "kernel": "compare_planes_batch_kernel<5> (round 6: two three-input operations and a count per word, the quotient by "
+                              "fused multiply-adds; vector-ALU-bound, DESIGN 9.8)",
+                    "subfingerprint_compares_per_s": round(8 * per * n_big / (ms8 * 1e-3), 1)}
                 big.dispose()
 
     # =========================== sliding compare on a ragged corpus (side measurement) ====================
